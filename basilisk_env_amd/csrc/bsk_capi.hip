@@ -1,0 +1,552 @@
+// bsk_capi.hip — C-ABI of libbskgpu.so (see include/bskgpu.h for the contract and the reference
+// interfaces each entry point replaces).  Host side only: handle management, HBM allocation,
+// uploads/downloads, launch geometry.  No CPU compute path exists here by design: without a
+// gfx950 device bsk_create fails with BSK_ENODEV.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bskgpu.h"
+#include "bsk_launch.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? BSK_ENOMEM : BSK_EHIP,                              \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                             \
+    } while (0)
+
+bool inv3(const double* m, double* o) {
+    double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+    double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+    if (!(std::fabs(det) > 0.0)) return false;
+    double id = 1.0 / det;
+    o[0] = c00 * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    o[3] = c01 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    o[6] = c02 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+    return true;
+}
+
+// Low-precision solar position (Astronomical Almanac), equatorial frame, metres, Earth-centred.
+// Stands in for the SPICE de430 lookup at reference leoPowerAttitudeSimulator.py:219-225.
+void sun_position(double jd, double out[3]) {
+    const double D2R = M_PI / 180.0, AU = 149597870700.0;
+    double n = jd - 2451545.0;
+    double L = std::fmod(280.460 + 0.9856474 * n, 360.0), g = std::fmod(357.528 + 0.9856003 * n, 360.0) * D2R;
+    double lam = (L + 1.915 * std::sin(g) + 0.020 * std::sin(2 * g)) * D2R;
+    double eps = (23.439 - 0.0000004 * n) * D2R;
+    double R = (1.00014 - 0.01671 * std::cos(g) - 0.00014 * std::cos(2 * g)) * AU;
+    out[0] = R * std::cos(lam);
+    out[1] = R * std::cos(eps) * std::sin(lam);
+    out[2] = R * std::sin(eps) * std::sin(lam);
+}
+
+int build_devcfg(const bsk_config& c, bsk::DevCfg& d) {
+    std::memset(&d, 0, sizeof d);
+    d.dt = c.dt;
+    d.mu = c.mu;
+    d.req = c.req;
+    d.j2k = 1.5 * c.j2 * c.mu * c.req * c.req;
+    std::memcpy(d.inertia, c.inertia, sizeof d.inertia);
+    double D[9];
+    std::memcpy(D, c.inertia, sizeof D);
+    for (int i = 0; i < c.n_rw; ++i) {
+        double nrm = std::sqrt(c.gs[i][0] * c.gs[i][0] + c.gs[i][1] * c.gs[i][1] + c.gs[i][2] * c.gs[i][2]);
+        if (!(std::fabs(nrm - 1.0) < 1e-9)) return fail(BSK_EINVAL, "wheel spin axis is not a unit vector");
+        if (!(c.js[i] > 0.0)) return fail(BSK_EINVAL, "wheel inertia js must be positive");
+        for (int a = 0; a < 3; ++a) {
+            d.gs[i][a] = c.gs[i][a];
+            for (int b = 0; b < 3; ++b) D[3 * a + b] -= c.js[i] * c.gs[i][a] * c.gs[i][b];
+        }
+        d.js[i] = c.js[i];
+        d.inv_js[i] = 1.0 / c.js[i];
+    }
+    if (!inv3(D, d.dinv)) return fail(BSK_EINVAL, "hub inertia minus wheel inertia is singular");
+    if (c.n_rw > 0) {
+        // rwMotorTorque: map = CGs^T (CGs CGs^T)^-1 C,  CGs = C Gs
+        double cgs[3][BSK_MAX_RW], M[9] = {0}, Mi[9];
+        for (int a = 0; a < 3; ++a)
+            for (int i = 0; i < c.n_rw; ++i)
+                cgs[a][i] = c.ctrl_axes[3 * a] * c.gs[i][0] + c.ctrl_axes[3 * a + 1] * c.gs[i][1] +
+                            c.ctrl_axes[3 * a + 2] * c.gs[i][2];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b)
+                for (int i = 0; i < c.n_rw; ++i) M[3 * a + b] += cgs[a][i] * cgs[b][i];
+        if (!inv3(M, Mi)) return fail(BSK_EINVAL, "wheel set does not span the control axes");
+        for (int i = 0; i < c.n_rw; ++i) {
+            double t[3];
+            for (int a = 0; a < 3; ++a) t[a] = cgs[0][i] * Mi[a] + cgs[1][i] * Mi[3 + a] + cgs[2][i] * Mi[6 + a];
+            for (int b = 0; b < 3; ++b)
+                d.map[i][b] = t[0] * c.ctrl_axes[b] + t[1] * c.ctrl_axes[3 + b] + t[2] * c.ctrl_axes[6 + b];
+        }
+    }
+    d.u_max = c.u_max;
+    d.u_min = c.u_min;
+    d.f_coulomb = c.f_coulomb;
+    d.K = c.K;
+    d.P = c.P;
+    std::memcpy(d.sigma_R0N, c.sigma_R0N, sizeof d.sigma_R0N);
+    d.inv_wheel_limit = 1.0 / c.wheel_limit;
+    d.charge_scale = 1.0 / 3600.0 / c.power_max;
+    d.reward_mult = c.reward_mult;
+    d.failure_penalty = c.failure_penalty;
+    d.r_min2 = c.r_min * c.r_min;
+    d.fsw_every = c.fsw_every;
+    d.max_length = c.max_length;
+    return BSK_OK;
+}
+
+}  // namespace
+
+struct bsk_handle {
+    bsk_config cfg;
+    bsk::DevCfg dc;
+    int n = 0, nf = 0, device = 0, block = 64;
+    int64_t stride = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    double* d_state = nullptr;
+    int2* d_cnt = nullptr;
+    int* d_act = nullptr;
+    double* d_obs = nullptr;
+    double* d_reward = nullptr;
+    unsigned long long* d_done_mask = nullptr;
+    unsigned char* d_reason = nullptr;
+    double* d_wave_reward = nullptr;
+    double* d_stat_sum = nullptr;
+    long long* d_stat_done = nullptr;
+    // masked-reset staging
+    double* d_ic_stage = nullptr;
+    int* d_idx_stage = nullptr;
+    size_t stage_cap = 0;
+    // profiling
+    std::vector<hipEvent_t> ev;
+    int ev_used = 0;
+    bool prof = false;
+    double sim_time = 0.0;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int validate(const bsk_config& c) {
+    if (c.abi_version != BSK_ABI_VERSION || c.struct_size != sizeof(bsk_config))
+        return fail(BSK_EABI, "bsk_config abi_version/struct_size mismatch (header " + std::to_string(BSK_ABI_VERSION) +
+                                  "/" + std::to_string(sizeof(bsk_config)) + ")");
+    if (!(c.dt > 0.0)) return fail(BSK_EINVAL, "dt must be positive");
+    if (c.fsw_every < 1) return fail(BSK_EINVAL, "fsw_every must be >= 1");
+    if (c.n_rw != 0 && c.n_rw != 3 && c.n_rw != 4) return fail(BSK_EINVAL, "n_rw must be 0, 3 or 4");
+    if (c.gravity_model != BSK_GRAV_PM && c.gravity_model != BSK_GRAV_PM_J2 && c.gravity_model != BSK_GRAV_SH)
+        return fail(BSK_EINVAL, "unknown gravity_model");
+    if (c.gravity_model == BSK_GRAV_SH) return fail(BSK_EINVAL, "gravity_model BSK_GRAV_SH is not built in this version");
+    const uint32_t unbuilt = BSK_FLAG_SUN_THIRD_BODY | BSK_FLAG_POWER | BSK_FLAG_DESAT | BSK_FLAG_DRAG |
+                             BSK_FLAG_AUTO_RESET | BSK_FLAG_LDS_SCRATCH;
+    if (c.flags & unbuilt) return fail(BSK_EINVAL, "config flag requests a feature that is not built in this version");
+    if (!(c.mu > 0.0) || !(c.req > 0.0)) return fail(BSK_EINVAL, "mu and req must be positive");
+    if (!(c.wheel_limit > 0.0) || !(c.power_max > 0.0)) return fail(BSK_EINVAL, "wheel_limit and power_max must be positive");
+    return BSK_OK;
+}
+
+int ensure_stage(bsk_handle* h, size_t m) {
+    if (m <= h->stage_cap) return BSK_OK;
+    if (h->d_ic_stage) (void)hipFree(h->d_ic_stage);
+    if (h->d_idx_stage) (void)hipFree(h->d_idx_stage);
+    h->d_ic_stage = nullptr;
+    h->d_idx_stage = nullptr;
+    h->stage_cap = 0;
+    HIP_TRY(hipMalloc(&h->d_ic_stage, m * h->nf * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->d_idx_stage, m * sizeof(int)));
+    h->stage_cap = m;
+    return BSK_OK;
+}
+
+int do_step(bsk_handle* h, const int* d_actions, int substeps) {
+    bsk::StepArgs a;
+    a.c = h->dc;
+    a.st = h->d_state;
+    a.cnt = h->d_cnt;
+    a.act = d_actions;
+    a.obs = h->d_obs;
+    a.reward = h->d_reward;
+    a.done_mask = h->d_done_mask;
+    a.reason = h->d_reason;
+    a.wave_reward = h->d_wave_reward;
+    a.stride = h->stride;
+    a.n = h->n;
+    a.substeps = substeps;
+    const bool timed = h->prof && h->ev_used + 2 <= (int)h->ev.size();
+    if (timed) HIP_TRY(hipEventRecord(h->ev[h->ev_used], h->stream));
+    HIP_TRY(bsk::launch_step(h->cfg.gravity_model, h->cfg.n_rw, a, h->block, h->stream));
+    if (timed) {
+        HIP_TRY(hipEventRecord(h->ev[h->ev_used + 1], h->stream));
+        h->ev_used += 2;
+    }
+    h->sim_time += substeps * h->cfg.dt;
+    return BSK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* bsk_last_error(void) { return g_err.c_str(); }
+const char* bsk_version(void) { return "bskgpu 0.1 (gfx950)"; }
+
+int bsk_default_config(bsk_config* c, int n_rw, int gravity_model) {
+    if (!c) return fail(BSK_EINVAL, "cfg is NULL");
+    if (n_rw != 0 && n_rw != 3 && n_rw != 4) return fail(BSK_EINVAL, "n_rw must be 0, 3 or 4");
+    std::memset(c, 0, sizeof *c);
+    c->abi_version = BSK_ABI_VERSION;
+    c->struct_size = sizeof *c;
+    c->dt = 0.1;
+    c->fsw_every = 10;
+    c->gravity_model = gravity_model;
+    c->sh_degree = 0;
+    c->n_rw = n_rw;
+    c->flags = 0;
+    c->max_length = 540;
+    c->mu = 0.3986004415e15;
+    c->req = 6378136.6;
+    c->j2 = std::sqrt(5.0) * 4.841693e-4;
+    c->planet_rate = 7.2921159e-5;
+    const double m = 330.0, w = 1.38, dpt = 1.04, ht = 1.58;
+    c->mass = m;
+    c->inertia[0] = 1. / 12. * m * (w * w + dpt * dpt);
+    c->inertia[4] = 1. / 12. * m * (dpt * dpt + ht * ht);
+    c->inertia[8] = 1. / 12. * m * (w * w + ht * ht);
+    const double D2R = M_PI / 180.0;
+    if (n_rw == 3) {
+        for (int i = 0; i < 3; ++i) c->gs[i][i] = 1.0;
+    } else if (n_rw == 4) {
+        const double el = 40.0 * D2R, az[4] = {45.0 * D2R, 135.0 * D2R, 225.0 * D2R, 315.0 * D2R};
+        for (int i = 0; i < 4; ++i) {
+            c->gs[i][0] = std::cos(az[i]) * std::cos(el);
+            c->gs[i][1] = std::sin(az[i]) * std::cos(el);
+            c->gs[i][2] = std::sin(el);
+        }
+    }
+    for (int i = 0; i < n_rw; ++i) c->js[i] = 50.0 / (6000.0 * M_PI * 2.0 / 60.0);
+    c->u_max = 0.2;
+    c->u_min = 0.00001;
+    c->f_coulomb = 0.0005;
+    c->K = 7.0;
+    c->P = 35.0;
+    c->sigma_R0N[0] = 1.0;
+    c->ctrl_axes[0] = c->ctrl_axes[4] = c->ctrl_axes[8] = 1.0;
+    c->wheel_limit = 3000.0 * (2.0 * M_PI / 60.0);
+    c->power_max = 20.0;
+    c->reward_mult = 1.0 / 540.0;
+    c->failure_penalty = 1.0;
+    c->r_min = 6378.1366 / 1000.0;
+    c->panel_normal[1] = -1.0;
+    c->panel_area = 0.2 * 0.3;
+    c->panel_efficiency = 0.20;
+    c->power_draw = -5.0;
+    c->storage_capacity = 20.0 * 3600.0;
+    c->solar_flux = 1372.5398;
+    // epoch 2021 MAY 04 07:47:48.965 UTC (JD 2459338.5 + 07:47:48.965)
+    const double jd0 = 2459338.5 + (7.0 * 3600.0 + 47.0 * 60.0 + 48.965) / 86400.0;
+    double p0[3], p1[3];
+    sun_position(jd0, p0);
+    sun_position(jd0 + 1.0, p1);
+    for (int k = 0; k < 3; ++k) {
+        c->sun_r0[k] = p0[k];
+        c->sun_v[k] = (p1[k] - p0[k]) / 86400.0;
+    }
+    c->mu_sun = 1.32712440018e20;
+    c->hs_min = 4.0;
+    c->thr_max_counter = 4;
+    c->thr_min_fire_time = 0.002;
+    c->base_density = 1.22;
+    c->scale_height = 8.0e3;
+    return BSK_OK;
+}
+
+int bsk_create(const bsk_config* cfg, int n_envs, int device_id, void* stream, bsk_handle** out) {
+    if (!cfg || !out) return fail(BSK_EINVAL, "cfg/out is NULL");
+    *out = nullptr;
+    if (n_envs < 1) return fail(BSK_EINVAL, "n_envs must be >= 1");
+    int rc = validate(*cfg);
+    if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(BSK_ENODEV, "no HIP device visible: libbskgpu has no CPU fallback");
+    if (device_id < 0 || device_id >= ndev) return fail(BSK_ENODEV, "device_id out of range");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(BSK_ENODEV, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    DeviceGuard guard(device_id);
+
+    bsk_handle* h = new bsk_handle();
+    h->cfg = *cfg;
+    rc = build_devcfg(*cfg, h->dc);
+    if (rc) { delete h; return rc; }
+    h->n = n_envs;
+    h->nf = BSK_NF_BASE + cfg->n_rw + BSK_NF_TAIL;
+    h->device = device_id;
+    h->stride = ((int64_t)n_envs + 255) / 256 * 256;
+    // 64-lane workgroups spread a small batch over more CUs (65 536 envs = 1 024 waves = 4 per CU);
+    // large batches use 256 so the dispatcher has fewer workgroups to place.
+    h->block = n_envs >= (1 << 20) ? 256 : 64;
+    if (stream) { h->stream = (hipStream_t)stream; h->own_stream = false; }
+    else {
+        hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete h; return fail(BSK_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+        h->own_stream = true;
+    }
+    const int64_t S = h->stride;
+    auto alloc = [&](void** p, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(p, bytes);
+        if (e == hipSuccess) e = hipMemsetAsync(*p, 0, bytes, h->stream);
+        return e;
+    };
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = alloc((void**)&h->d_state, (size_t)h->nf * S * sizeof(double));
+    if (e == hipSuccess) e = alloc((void**)&h->d_cnt, (size_t)S * sizeof(int2));
+    if (e == hipSuccess) e = alloc((void**)&h->d_act, (size_t)S * sizeof(int));
+    if (e == hipSuccess) e = alloc((void**)&h->d_obs, (size_t)5 * S * sizeof(double));
+    if (e == hipSuccess) e = alloc((void**)&h->d_reward, (size_t)S * sizeof(double));
+    if (e == hipSuccess) e = alloc((void**)&h->d_done_mask, (size_t)(S / 64) * sizeof(unsigned long long));
+    if (e == hipSuccess) e = alloc((void**)&h->d_reason, (size_t)S);
+    if (e == hipSuccess) e = alloc((void**)&h->d_wave_reward, (size_t)(S / 64) * sizeof(double));
+    if (e == hipSuccess) e = alloc((void**)&h->d_stat_sum, sizeof(double));
+    if (e == hipSuccess) e = alloc((void**)&h->d_stat_done, sizeof(long long));
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+        int code = fail(e == hipErrorOutOfMemory ? BSK_ENOMEM : BSK_EHIP, std::string("device allocation: ") + hipGetErrorString(e));
+        bsk_destroy(h);
+        return code;
+    }
+    *out = h;
+    return BSK_OK;
+}
+
+void bsk_destroy(bsk_handle* h) {
+    if (!h) return;
+    DeviceGuard guard(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (hipEvent_t ev : h->ev) (void)hipEventDestroy(ev);
+    void* bufs[] = {h->d_state, h->d_cnt, h->d_act, h->d_obs, h->d_reward, h->d_done_mask, h->d_reason,
+                    h->d_wave_reward, h->d_stat_sum, h->d_stat_done, h->d_ic_stage, h->d_idx_stage};
+    for (void* p : bufs)
+        if (p) (void)hipFree(p);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int bsk_set_gravity_sh(bsk_handle* h, int, const double*, const double*) {
+    if (!h) return fail(BSK_EINVAL, "handle is NULL");
+    return fail(BSK_EINVAL, "spherical-harmonic gravity is not built in this version");
+}
+
+int bsk_n_fields(const bsk_handle* h) { return h ? h->nf : BSK_EINVAL; }
+
+int bsk_reset(bsk_handle* h, const uint8_t* mask, const double* ic) {
+    if (!h || !ic) return fail(BSK_EINVAL, "handle/ic is NULL");
+    DeviceGuard guard(h->device);
+    const size_t row = (size_t)h->n * sizeof(double);
+    if (!mask) {
+        HIP_TRY(hipMemcpy2DAsync(h->d_state, (size_t)h->stride * sizeof(double), ic, row, row, h->nf,
+                                 hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemsetAsync(h->d_cnt, 0, (size_t)h->stride * sizeof(int2), h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        return BSK_OK;
+    }
+    std::vector<int> idx;
+    for (int i = 0; i < h->n; ++i)
+        if (mask[i]) idx.push_back(i);
+    const size_t m = idx.size();
+    if (m == 0) return BSK_OK;
+    std::vector<double> compact(m * h->nf);
+    for (int f = 0; f < h->nf; ++f)
+        for (size_t t = 0; t < m; ++t) compact[(size_t)f * m + t] = ic[(size_t)f * h->n + idx[t]];
+    int rc = ensure_stage(h, m);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h->d_ic_stage, compact.data(), compact.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_idx_stage, idx.data(), m * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(bsk::launch_scatter_reset(h->d_state, h->stride, h->nf, h->d_ic_stage, h->d_idx_stage, (int)m, h->d_cnt, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return BSK_OK;
+}
+
+int bsk_step(bsk_handle* h, const int32_t* actions, int substeps) {
+    if (!h || !actions) return fail(BSK_EINVAL, "handle/actions is NULL");
+    if (substeps < 1) return fail(BSK_EINVAL, "substeps must be >= 1");
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipMemcpyAsync(h->d_act, actions, (size_t)h->n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    return do_step(h, h->d_act, substeps);
+}
+
+int bsk_step_device(bsk_handle* h, const int32_t* d_actions, int substeps) {
+    if (!h || !d_actions) return fail(BSK_EINVAL, "handle/actions is NULL");
+    if (substeps < 1) return fail(BSK_EINVAL, "substeps must be >= 1");
+    DeviceGuard guard(h->device);
+    return do_step(h, d_actions, substeps);
+}
+
+int bsk_get_obs(bsk_handle* h, double* obs, double* reward, uint8_t* done, uint8_t* done_reason) {
+    if (!h) return fail(BSK_EINVAL, "handle is NULL");
+    DeviceGuard guard(h->device);
+    const size_t row = (size_t)h->n * sizeof(double);
+    if (obs)
+        HIP_TRY(hipMemcpy2DAsync(obs, row, h->d_obs, (size_t)h->stride * sizeof(double), row, 5, hipMemcpyDeviceToHost, h->stream));
+    if (reward) HIP_TRY(hipMemcpyAsync(reward, h->d_reward, row, hipMemcpyDeviceToHost, h->stream));
+    std::vector<unsigned char> why;
+    unsigned char* wp = done_reason;
+    if (done && !done_reason) { why.resize(h->n); wp = why.data(); }
+    if (wp) HIP_TRY(hipMemcpyAsync(wp, h->d_reason, (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (done)
+        for (int i = 0; i < h->n; ++i) done[i] = wp[i] != 0;
+    return BSK_OK;
+}
+
+int bsk_get_obs_device(bsk_handle* h, double** d_obs, double** d_reward, uint64_t** d_done_mask, uint8_t** d_done_reason,
+                       int64_t* stride) {
+    if (!h) return fail(BSK_EINVAL, "handle is NULL");
+    if (d_obs) *d_obs = h->d_obs;
+    if (d_reward) *d_reward = h->d_reward;
+    if (d_done_mask) *d_done_mask = (uint64_t*)h->d_done_mask;
+    if (d_done_reason) *d_done_reason = h->d_reason;
+    if (stride) *stride = h->stride;
+    return BSK_OK;
+}
+
+int bsk_get_batch_stats(bsk_handle* h, double* reward_sum, int64_t* n_done) {
+    if (!h) return fail(BSK_EINVAL, "handle is NULL");
+    DeviceGuard guard(h->device);
+    const int n_waves = (h->n + 63) / 64;
+    HIP_TRY(bsk::launch_stats(h->d_wave_reward, h->d_done_mask, n_waves, h->d_stat_sum, h->d_stat_done, h->stream));
+    double s = 0;
+    long long d = 0;
+    HIP_TRY(hipMemcpyAsync(&s, h->d_stat_sum, sizeof s, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(&d, h->d_stat_done, sizeof d, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (reward_sum) *reward_sum = s;
+    if (n_done) *n_done = d;
+    return BSK_OK;
+}
+
+int bsk_get_state(bsk_handle* h, double* state) {
+    if (!h || !state) return fail(BSK_EINVAL, "handle/state is NULL");
+    DeviceGuard guard(h->device);
+    const size_t row = (size_t)h->n * sizeof(double);
+    HIP_TRY(hipMemcpy2DAsync(state, row, h->d_state, (size_t)h->stride * sizeof(double), row, h->nf, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return BSK_OK;
+}
+
+int bsk_set_state(bsk_handle* h, const double* state) {
+    if (!h || !state) return fail(BSK_EINVAL, "handle/state is NULL");
+    DeviceGuard guard(h->device);
+    const size_t row = (size_t)h->n * sizeof(double);
+    HIP_TRY(hipMemcpy2DAsync(h->d_state, (size_t)h->stride * sizeof(double), state, row, row, h->nf, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return BSK_OK;
+}
+
+int bsk_get_counters(bsk_handle* h, int32_t* steps, int32_t* ticks) {
+    if (!h) return fail(BSK_EINVAL, "handle is NULL");
+    DeviceGuard guard(h->device);
+    std::vector<int2> tmp(h->n);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), h->d_cnt, (size_t)h->n * sizeof(int2), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < h->n; ++i) {
+        if (steps) steps[i] = tmp[i].x;
+        if (ticks) ticks[i] = tmp[i].y;
+    }
+    return BSK_OK;
+}
+
+int bsk_set_ic_pool(bsk_handle* h, int, const double*) {
+    if (!h) return fail(BSK_EINVAL, "handle is NULL");
+    return fail(BSK_EINVAL, "device-side auto-reset is not built in this version");
+}
+
+int bsk_set_sim_time(bsk_handle* h, double t) {
+    if (!h) return fail(BSK_EINVAL, "handle is NULL");
+    h->sim_time = t;
+    return BSK_OK;
+}
+
+int bsk_sync(bsk_handle* h) {
+    if (!h) return fail(BSK_EINVAL, "handle is NULL");
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return BSK_OK;
+}
+
+int bsk_profile_begin(bsk_handle* h, int capacity) {
+    if (!h || capacity < 1) return fail(BSK_EINVAL, "handle is NULL or capacity < 1");
+    DeviceGuard guard(h->device);
+    while ((int)h->ev.size() < 2 * capacity) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        h->ev.push_back(e);
+    }
+    h->ev_used = 0;
+    h->prof = true;
+    return BSK_OK;
+}
+
+int bsk_profile_end(bsk_handle* h, double* mean_kernel_ms, int* n_launches) {
+    if (!h) return fail(BSK_EINVAL, "handle is NULL");
+    DeviceGuard guard(h->device);
+    h->prof = false;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    double tot = 0.0;
+    const int n = h->ev_used / 2;
+    for (int k = 0; k < n; ++k) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev[2 * k], h->ev[2 * k + 1]));
+        tot += ms;
+    }
+    if (mean_kernel_ms) *mean_kernel_ms = n ? tot / n : 0.0;
+    if (n_launches) *n_launches = n;
+    h->ev_used = 0;
+    return BSK_OK;
+}
+
+int bsk_kernel_info(bsk_handle* h, char* name, int name_cap, int* vgprs, int* lds_bytes, int* block, int* grid) {
+    if (!h) return fail(BSK_EINVAL, "handle is NULL");
+    DeviceGuard guard(h->device);
+    const void* fp = bsk::step_kernel_ptr(h->cfg.gravity_model, h->cfg.n_rw);
+    if (!fp) return fail(BSK_EINVAL, "no kernel variant for this config");
+    hipFuncAttributes at;
+    HIP_TRY(hipFuncGetAttributes(&at, fp));
+    if (name && name_cap > 0)
+        std::snprintf(name, name_cap, "step_kernel<%s,%d>", h->cfg.gravity_model == BSK_GRAV_PM ? "PM" : "PM_J2", h->cfg.n_rw);
+    if (vgprs) *vgprs = at.numRegs;
+    if (lds_bytes) *lds_bytes = (int)at.sharedSizeBytes;
+    if (block) *block = h->block;
+    if (grid) *grid = (h->n + h->block - 1) / h->block;
+    return BSK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,258 @@
+// bsk_device.hpp — per-spacecraft fp64 physics for gfx950 (CDNA4), one spacecraft per lane.
+//
+// Everything a lane needs that is the same for every spacecraft (inertia, wheel geometry, gains,
+// gravity constants) travels in DevCfg, passed BY VALUE as a kernel argument: the compiler keeps
+// it in SGPRs (s_load from the kernarg segment), so the fp64 VALU stream carries no loads for it.
+// Per-spacecraft state lives in VGPRs as named scalars (no runtime-indexed arrays -> no scratch).
+//
+// What this replaces: the Basilisk modules wired by the reference scenario
+//   spacecraftPlus + RK4        basilisk_env/simulators/leoPowerAttitudeSimulator.py:213-259,356
+//   gravityEffector             :217-232   (J2 / harmonics: opNav_models/BSK_OpNavDynamics.py:211-214)
+//   reactionWheelStateEffector  :301-310 + dynamics/effectorPrimatives/actuatorPrimatives.py:7-63
+//   extForceTorque              :291-298
+//   hillPoint / inertial3D / attTrackingError / MRP_Feedback / rwMotorTorque   :407-449, 481-486
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bskgpu.h"
+
+namespace bsk {
+
+struct V3 {
+    double x, y, z;
+};
+__device__ __forceinline__ V3 mk(double x, double y, double z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(double s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ double dot(V3 a, V3 b) { return fma(a.x, b.x, fma(a.y, b.y, a.z * b.z)); }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+// y = a*x + y
+__device__ __forceinline__ V3 axpy(double a, V3 x, V3 y) { return V3{fma(a, x.x, y.x), fma(a, x.y, y.y), fma(a, x.z, y.z)}; }
+__device__ __forceinline__ V3 mv(const double* m, V3 v) {
+    return V3{fma(m[0], v.x, fma(m[1], v.y, m[2] * v.z)), fma(m[3], v.x, fma(m[4], v.y, m[5] * v.z)),
+              fma(m[6], v.x, fma(m[7], v.y, m[8] * v.z))};
+}
+
+// Uniform (per-handle) constants.  Built on the host in bsk_capi.hip from bsk_config.
+struct DevCfg {
+    double dt;
+    double mu, req, j2k;  // j2k = 1.5 * J2 * mu * req^2
+    double inertia[9];
+    double dinv[9];  // (I_sc - sum Js g g^T)^-1
+    double gs[BSK_MAX_RW][3];
+    double js[BSK_MAX_RW], inv_js[BSK_MAX_RW];
+    double map[BSK_MAX_RW][3];  // rwMotorTorque pseudo-inverse rows
+    double u_max, u_min, f_coulomb;
+    double K, P;
+    double sigma_R0N[3];
+    double inv_wheel_limit, charge_scale, reward_mult, failure_penalty, r_min2;
+    int32_t fsw_every, max_length;
+};
+
+template <int NRW>
+struct State {
+    V3 r, v, s, w;    // position, velocity, sigma_BN, omega_BN_B
+    double Om[NRW > 0 ? NRW : 1];
+};
+
+// ---------------------------------------------------------------------------------------------
+// gravity: point mass (+ closed-form J2).  One rsqrt-shaped chain: r2 -> 1/r -> 1/r^2, 1/r^3.
+template <int GRAV>
+__device__ __forceinline__ V3 gravity(const DevCfg& c, V3 r) {
+    double r2 = dot(r, r);
+    double ir = 1.0 / sqrt(r2);
+    double ir2 = ir * ir;
+    double ir3 = ir * ir2;
+    double k0 = -c.mu * ir3;
+    if constexpr (GRAV == BSK_GRAV_PM_J2) {
+        double z2 = r.z * r.z * ir2;          // (z/r)^2
+        double kj = c.j2k * ir3 * ir2;        // 1.5 J2 mu Re^2 / r^5
+        double kxy = fma(kj, fma(5.0, z2, -1.0), k0);
+        double kz = fma(kj, fma(5.0, z2, -3.0), k0);
+        return V3{kxy * r.x, kxy * r.y, kz * r.z};
+    } else {
+        return k0 * r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// equations of motion.  u = held wheel motor torques, lext = external body torque.
+template <int GRAV, int NRW>
+__device__ __forceinline__ void eom(const DevCfg& c, const State<NRW>& x, const double* u, V3 lext, State<NRW>& d) {
+    d.r = x.v;
+    d.v = gravity<GRAV>(c, x.r);
+    // sigma' = 1/4 [(1 - s^2) w + 2 s x w + 2 (s.w) s]
+    double s2 = dot(x.s, x.s), sw = dot(x.s, x.w);
+    V3 sxw = cross(x.s, x.w);
+    double a = 0.25 * (1.0 - s2), b = 0.5 * sw;
+    d.s = V3{fma(a, x.w.x, fma(0.5, sxw.x, b * x.s.x)), fma(a, x.w.y, fma(0.5, sxw.y, b * x.s.y)),
+             fma(a, x.w.z, fma(0.5, sxw.z, b * x.s.z))};
+    // [I - sum Js g g^T] w' = -w x (I w + h_w) + L_ext - Gs (u + tau_f),  h_w = sum Js Om g
+    V3 H = mv(c.inertia, x.w);
+    V3 rhs = lext;
+    double tq[NRW > 0 ? NRW : 1];
+#pragma unroll
+    for (int i = 0; i < NRW; ++i) {
+        double fr = x.Om[i] > 0.0 ? -c.f_coulomb : (x.Om[i] < 0.0 ? c.f_coulomb : 0.0);
+        tq[i] = u[i] + fr;
+        V3 g = mk(c.gs[i][0], c.gs[i][1], c.gs[i][2]);
+        H = axpy(c.js[i] * x.Om[i], g, H);
+        rhs = axpy(-tq[i], g, rhs);
+    }
+    rhs = rhs - cross(x.w, H);
+    d.w = mv(c.dinv, rhs);
+#pragma unroll
+    for (int i = 0; i < NRW; ++i) {
+        V3 g = mk(c.gs[i][0], c.gs[i][1], c.gs[i][2]);
+        d.Om[i] = fma(tq[i], c.inv_js[i], -dot(g, d.w));
+    }
+}
+
+template <int NRW>
+__device__ __forceinline__ void st_axpy(double a, const State<NRW>& k, const State<NRW>& x, State<NRW>& o) {
+    o.r = axpy(a, k.r, x.r);
+    o.v = axpy(a, k.v, x.v);
+    o.s = axpy(a, k.s, x.s);
+    o.w = axpy(a, k.w, x.w);
+#pragma unroll
+    for (int i = 0; i < NRW; ++i) o.Om[i] = fma(a, k.Om[i], x.Om[i]);
+}
+
+// classic RK4, sequential accumulation x0 + h/6 k1 + h/3 k2 + h/3 k3 + h/6 k4, then the MRP
+// shadow-set switch once per completed step.
+template <int GRAV, int NRW>
+__device__ __forceinline__ void rk4_step(const DevCfg& c, State<NRW>& x, const double* u, V3 lext) {
+    const double h = c.dt, h2 = 0.5 * h, h6 = h / 6.0, h3 = h / 3.0;
+    State<NRW> k, xt, acc;
+    eom<GRAV, NRW>(c, x, u, lext, k);
+    st_axpy<NRW>(h6, k, x, acc);
+    st_axpy<NRW>(h2, k, x, xt);
+    eom<GRAV, NRW>(c, xt, u, lext, k);
+    st_axpy<NRW>(h3, k, acc, acc);
+    st_axpy<NRW>(h2, k, x, xt);
+    eom<GRAV, NRW>(c, xt, u, lext, k);
+    st_axpy<NRW>(h3, k, acc, acc);
+    st_axpy<NRW>(h, k, x, xt);
+    eom<GRAV, NRW>(c, xt, u, lext, k);
+    st_axpy<NRW>(h6, k, acc, x);
+    double s2 = dot(x.s, x.s);
+    if (s2 > 1.0) x.s = (-1.0 / s2) * x.s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// attitude kinematics helpers
+__device__ __forceinline__ void mrp2c(V3 q, double* C) {
+    double q2 = dot(q, q), op = 1.0 + q2, id = 1.0 / (op * op);
+    double a = 8.0 * id, b = 4.0 * (1.0 - q2) * id;
+    // t~^2 = q q^T - q2 I
+    C[0] = fma(a, q.x * q.x - q2, 1.0);
+    C[4] = fma(a, q.y * q.y - q2, 1.0);
+    C[8] = fma(a, q.z * q.z - q2, 1.0);
+    double xy = a * q.x * q.y, xz = a * q.x * q.z, yz = a * q.y * q.z;
+    C[1] = fma(b, q.z, xy);
+    C[3] = fma(-b, q.z, xy);
+    C[2] = fma(-b, q.y, xz);
+    C[6] = fma(b, q.y, xz);
+    C[5] = fma(b, q.x, yz);
+    C[7] = fma(-b, q.x, yz);
+}
+
+// DCM -> MRP through Euler parameters (Sheppard), b0 >= 0
+__device__ __forceinline__ V3 c2mrp(const double* C) {
+    double tr = C[0] + C[4] + C[8];
+    double b20 = 0.25 * (1.0 + tr), b21 = 0.25 * (1.0 + 2.0 * C[0] - tr), b22 = 0.25 * (1.0 + 2.0 * C[4] - tr),
+           b23 = 0.25 * (1.0 + 2.0 * C[8] - tr);
+    int i = 0;
+    double mx = b20;
+    if (b21 > mx) { mx = b21; i = 1; }
+    if (b22 > mx) { mx = b22; i = 2; }
+    if (b23 > mx) { mx = b23; i = 3; }
+    double p = sqrt(mx), q4 = 0.25 / p;
+    double b0, b1, b2, b3;
+    if (i == 0) {
+        b0 = p; b1 = (C[5] - C[7]) * q4; b2 = (C[6] - C[2]) * q4; b3 = (C[1] - C[3]) * q4;
+    } else if (i == 1) {
+        b1 = p; b0 = (C[5] - C[7]) * q4; b2 = (C[1] + C[3]) * q4; b3 = (C[6] + C[2]) * q4;
+    } else if (i == 2) {
+        b2 = p; b0 = (C[6] - C[2]) * q4; b1 = (C[1] + C[3]) * q4; b3 = (C[5] + C[7]) * q4;
+    } else {
+        b3 = p; b0 = (C[1] - C[3]) * q4; b1 = (C[6] + C[2]) * q4; b2 = (C[5] + C[7]) * q4;
+    }
+    if (b0 < 0.0) { b0 = -b0; b1 = -b1; b2 = -b2; b3 = -b3; }
+    double id = 1.0 / (1.0 + b0);
+    return V3{b1 * id, b2 * id, b3 * id};
+}
+
+// q1 (-) q2 with the near-singular guard and the map to the inner set
+__device__ __forceinline__ V3 submrp(V3 q1, V3 q2) {
+    double d1 = dot(q1, q1), d2 = dot(q2, q2);
+    double den = 1.0 + d1 * d2 + 2.0 * dot(q1, q2);
+    if (fabs(den) < 0.1) {
+        q1 = (-1.0 / d1) * q1;
+        d1 = dot(q1, q1);
+        den = 1.0 + d1 * d2 + 2.0 * dot(q1, q2);
+    }
+    V3 t = cross(q1, q2);
+    double id = 1.0 / den;
+    V3 q = id * ((1.0 - d2) * q1 - (1.0 - d1) * q2 + 2.0 * t);
+    double m = dot(q, q);
+    if (m > 1.0) q = (-1.0 / m) * q;
+    return q;
+}
+
+struct Guid {
+    V3 sigma_BR, omega_BR_B, omega_RN_B, domega_RN_B;
+};
+
+// hillPoint | inertial3D  ->  attTrackingError
+template <int NRW>
+__device__ __forceinline__ Guid guidance(const DevCfg& c, const State<NRW>& x, int action) {
+    V3 sRN, wRN_N, dwRN_N;
+    if (action == 0) {
+        double ir = 1.0 / sqrt(dot(x.r, x.r));
+        V3 h = cross(x.r, x.v);
+        double hm = sqrt(dot(h, h)), ih = 1.0 / hm;
+        V3 e_r = ir * x.r, e_h = ih * h, e_t = cross(e_h, e_r);
+        double C[9] = {e_r.x, e_r.y, e_r.z, e_t.x, e_t.y, e_t.z, e_h.x, e_h.y, e_h.z};
+        sRN = c2mrp(C);
+        double dfdt = hm * ir * ir;
+        double ddfdt2 = -2.0 * dot(x.v, e_r) * ir * dfdt;
+        wRN_N = dfdt * e_h;
+        dwRN_N = ddfdt2 * e_h;
+    } else {
+        sRN = mk(c.sigma_R0N[0], c.sigma_R0N[1], c.sigma_R0N[2]);
+        wRN_N = mk(0, 0, 0);
+        dwRN_N = mk(0, 0, 0);
+    }
+    Guid g;
+    g.sigma_BR = submrp(x.s, sRN);
+    double BN[9];
+    mrp2c(x.s, BN);
+    g.omega_RN_B = mv(BN, wRN_N);
+    g.domega_RN_B = mv(BN, dwRN_N);
+    g.omega_BR_B = x.w - g.omega_RN_B;
+    return g;
+}
+
+// MRP_Feedback -> rwMotorTorque -> wheel saturation / dead-band
+template <int NRW>
+__device__ __forceinline__ void control(const DevCfg& c, const Guid& g, double* u) {
+    V3 wBN = g.omega_BR_B + g.omega_RN_B;
+    V3 Lr = c.K * g.sigma_BR + c.P * g.omega_BR_B;
+    Lr = Lr - cross(g.omega_RN_B, mv(c.inertia, wBN));
+    Lr = Lr + mv(c.inertia, cross(wBN, g.omega_RN_B) - g.domega_RN_B);
+    // module output is -Lr (torque on the body); wheels need u_s = -map * (-Lr) = map * Lr
+#pragma unroll
+    for (int i = 0; i < NRW; ++i) {
+        double us = fma(c.map[i][0], Lr.x, fma(c.map[i][1], Lr.y, c.map[i][2] * Lr.z));
+        if (c.u_max > 0.0) us = fmin(fmax(us, -c.u_max), c.u_max);
+        if (fabs(us) < c.u_min) us = 0.0;
+        u[i] = us;
+    }
+}
+
+}  // namespace bsk

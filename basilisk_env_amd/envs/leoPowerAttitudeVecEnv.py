@@ -1,0 +1,139 @@
+"""LeoPowerAttVecEnv — N independent LEO power/attitude environments stepped by one HIP launch.
+
+The batched sibling of ``leoPowerAttEnv``: the same observation (5 entries, normalised as in
+reference envs/leoPowerAttitudeEnvironment.py:107-108), reward (:161-170) and termination
+(:98-127) per env, with the stable-baselines ``VecEnv`` calling convention
+(``reset() -> (N,5,1)``, ``step_async``/``step_wait``, ``step(actions) -> (obs, rews, dones,
+infos)``, auto-reset of finished envs, ``get_attr``/``set_attr``/``env_method``).  Reward and
+done flags are computed on the device by the step kernel.
+"""
+import numpy as np
+
+from .. import spaces
+from .._lib import GRAV_PM_J2, DONE_BATTERY, DONE_LENGTH, DONE_ORBIT, DONE_WHEELS
+from ..simulators.dynamics.config import default_config
+from ..simulators.dynamics.propagator import BatchedPropagator
+from ..simulators.initial_conditions.batch import sample_ic_batch
+
+_EMPTY = {}
+
+
+class LeoPowerAttVecEnv(object):
+    def __init__(self, num_envs, n_rw=4, gravity_model=GRAV_PM_J2, step_duration=180., dynRate=0.1, fswRate=1.0,
+                 seed=0, device=0, cfg=None, auto_reset=True, propagator_factory=None):
+        self.num_envs = int(num_envs)
+        self.observation_space = spaces.Box(-1e16, 1e16, shape=(5, 1))
+        self.action_space = spaces.Discrete(3)
+        self.auto_reset = bool(auto_reset)
+        if cfg is None:
+            cfg = default_config(n_rw=n_rw, gravity_model=gravity_model)
+            cfg.dt = float(dynRate)
+            cfg.fsw_every = int(round(fswRate / dynRate))
+        self.cfg = cfg
+        self.n_rw = int(cfg.n_rw)
+        self.max_length = int(cfg.max_length)
+        self.step_duration = float(step_duration)
+        self.substeps = int(round(step_duration / cfg.dt))
+        self.wheel_limit = cfg.wheel_limit
+        self.power_max = cfg.power_max
+        self.reward_mult = cfg.reward_mult
+        self.failure_penalty = cfg.failure_penalty
+        self._rng = np.random.Generator(np.random.PCG64(seed))
+        self.propagator = (propagator_factory or BatchedPropagator)(cfg, self.num_envs, device=device)
+        self._ic = None
+        self._actions = None
+        self.episode_returns = np.zeros(self.num_envs)
+        self.episode_lengths = np.zeros(self.num_envs, dtype=np.int64)
+
+    # ------------------------------------------------------------------ VecEnv API
+    def seed(self, seed=None):
+        self._rng = np.random.Generator(np.random.PCG64(seed))
+        return [seed] * self.num_envs
+
+    def _initial_obs(self, ic, cols=None):
+        """Observation of freshly reset envs: [|sigma_BN|, |omega|, |Omega|/limit, charge/3600/max, 1]
+        (the reference reports |sigma_BN| at reset too, :348; wheel speeds here are in rad/s,
+        consistently with every later step)."""
+        sel = slice(None) if cols is None else cols
+        t = 12 + self.n_rw
+        ob = np.empty((5, ic[:, sel].shape[1]))
+        ob[0] = np.linalg.norm(ic[6:9, sel], axis=0)
+        ob[1] = np.linalg.norm(ic[9:12, sel], axis=0)
+        ob[2] = np.linalg.norm(ic[12:12 + self.n_rw, sel], axis=0) / self.wheel_limit if self.n_rw else 0.0
+        ob[3] = ic[t + 7, sel] / 3600. / self.power_max
+        ob[4] = 1.0
+        return ob
+
+    def reset(self, ic=None):
+        """Reset every env (fresh random ICs unless ``ic`` [n_fields, N] is given) -> obs (N,5,1)."""
+        self._ic = sample_ic_batch(self.num_envs, self.n_rw, rng=self._rng) if ic is None else np.array(ic, dtype=np.float64)
+        self.propagator.reset(self._ic)
+        self.episode_returns[:] = 0
+        self.episode_lengths[:] = 0
+        return self._initial_obs(self._ic).T.reshape(self.num_envs, 5, 1)
+
+    def reset_init(self):
+        """Replay the current initial conditions (reference reset_init, :202-216)."""
+        return self.reset(self._ic)
+
+    def step_async(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.int32).reshape(self.num_envs)
+        if a.min() < 0 or a.max() > 2:
+            raise ValueError("actions must be in {0, 1, 2}")
+        self._actions = a
+        self.propagator.step(a, self.substeps)
+
+    def step_wait(self):
+        obs, rew, done, why = self.propagator.get_obs()
+        self.episode_returns += rew
+        infos = [_EMPTY] * self.num_envs
+        obs_out = obs.T.reshape(self.num_envs, 5, 1).copy()
+        idx = np.flatnonzero(done)
+        if idx.size:
+            for i in idx:
+                infos[i] = {
+                    "episode": {"r": float(self.episode_returns[i]), "l": int(self.episode_lengths[i])},
+                    "terminal_observation": obs_out[i].copy(),
+                    "done_reason": {"length": bool(why[i] & DONE_LENGTH), "wheels": bool(why[i] & DONE_WHEELS),
+                                    "battery": bool(why[i] & DONE_BATTERY), "orbit": bool(why[i] & DONE_ORBIT)},
+                }
+            if self.auto_reset:
+                fresh = sample_ic_batch(idx.size, self.n_rw, rng=self._rng)
+                self._ic[:, idx] = fresh
+                mask = np.zeros(self.num_envs, dtype=np.uint8)
+                mask[idx] = 1
+                self.propagator.reset(self._ic, mask=mask)
+                obs_out[idx] = self._initial_obs(fresh).T.reshape(idx.size, 5, 1)
+                self.episode_returns[idx] = 0
+                self.episode_lengths[idx] = -1
+        self.episode_lengths += 1
+        return obs_out, rew, done, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self):
+        self.propagator.close()
+
+    def get_attr(self, attr_name, indices=None):
+        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
+        return [getattr(self, attr_name)] * n
+
+    def set_attr(self, attr_name, value, indices=None):
+        setattr(self, attr_name, value)
+
+    def env_method(self, method_name, *args, indices=None, **kwargs):
+        return [getattr(self, method_name)(*args, **kwargs)]
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
+        return [False] * n
+
+    # ------------------------------------------------------------------ extras
+    def get_state(self):
+        return self.propagator.get_state()
+
+    def batch_stats(self):
+        """(sum of rewards, number of done envs) of the last step, reduced on the device."""
+        return self.propagator.batch_stats()

@@ -1,0 +1,173 @@
+"""BatchedPropagator — Python face of the HIP propagator (libbskgpu.so, include/bskgpu.h).
+
+Replaces, for N spacecraft at once, what the reference does per env step by calling into the
+Basilisk engine: ``ConfigureStopTime`` + ``ExecuteSimulation`` + ``pullMultiMessageLogData``
+(reference simulators/leoPowerAttitudeSimulator.py:590-619).  numpy arrays in, numpy arrays out;
+device memory belongs to the library.  There is no CPU path: construction raises
+``BskGpuUnavailable`` when the library or a gfx950 device is missing.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ... import _lib
+from ..._lib import BskConfig, check, n_fields
+
+
+def pack_ic(n_rw, rN, vN, sigma, omega, wheelSpeeds=None, lext=None, charge=None, ucmd=None):
+    """Assemble the SoA initial-condition block ``[n_fields, N]`` (field order of include/bskgpu.h).
+
+    rN, vN, sigma, omega: (N,3); wheelSpeeds: (N,n_rw) [rad/s]; lext: (N,3) [N m]; charge: (N,) [W s].
+    """
+    rN = np.atleast_2d(np.asarray(rN, dtype=np.float64))
+    n = rN.shape[0]
+    nf = n_fields(n_rw)
+    ic = np.zeros((nf, n), dtype=np.float64)
+    ic[_lib.F_R:_lib.F_R + 3] = rN.T
+    ic[_lib.F_V:_lib.F_V + 3] = np.atleast_2d(vN).T
+    ic[_lib.F_SIGMA:_lib.F_SIGMA + 3] = np.atleast_2d(sigma).T
+    ic[_lib.F_OMEGA:_lib.F_OMEGA + 3] = np.atleast_2d(omega).T
+    if n_rw:
+        ic[_lib.NF_BASE:_lib.NF_BASE + n_rw] = np.atleast_2d(wheelSpeeds).T
+    t = _lib.NF_BASE + n_rw
+    if lext is not None:
+        ic[t + _lib.T_LEXT:t + _lib.T_LEXT + 3] = np.atleast_2d(lext).T
+    if ucmd is not None:
+        ic[t + _lib.T_UCMD:t + _lib.T_UCMD + n_rw] = np.atleast_2d(ucmd).T
+    if charge is not None:
+        ic[t + _lib.T_CHARGE] = np.asarray(charge, dtype=np.float64).reshape(n)
+    return ic
+
+
+class _DevArray(object):
+    """Minimal ``__cuda_array_interface__`` view of a library-owned device buffer (zero-copy
+    hand-off to torch for the RCCL gather)."""
+
+    def __init__(self, ptr, shape, typestr, strides=None, owner=None):
+        self._owner = owner
+        self.__cuda_array_interface__ = {
+            "shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2, "strides": strides,
+        }
+
+
+class BatchedPropagator(object):
+    def __init__(self, cfg, n_envs, device=0, stream=None):
+        if not isinstance(cfg, BskConfig):
+            raise TypeError("cfg must be a BskConfig")
+        self._lib = _lib.load()
+        self.cfg = cfg.copy()
+        self.n_envs = int(n_envs)
+        self.n_rw = int(cfg.n_rw)
+        self.n_fields = n_fields(self.n_rw)
+        self.device = int(device)
+        h = C.c_void_p()
+        check(self._lib.bsk_create(C.byref(self.cfg), self.n_envs, self.device,
+                                   C.c_void_p(stream) if stream else None, C.byref(h)))
+        self._h = h
+
+    # ------------------------------------------------------------------ lifecycle
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bsk_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _handle(self):
+        if not self._h:
+            raise RuntimeError("propagator is closed")
+        return self._h
+
+    # ------------------------------------------------------------------ state
+    def reset(self, ic, mask=None):
+        ic = np.ascontiguousarray(ic, dtype=np.float64)
+        if ic.shape != (self.n_fields, self.n_envs):
+            raise ValueError("ic must have shape (%d, %d), got %r" % (self.n_fields, self.n_envs, ic.shape))
+        mp = None
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+            if mask.shape != (self.n_envs,):
+                raise ValueError("mask must have shape (%d,)" % self.n_envs)
+            mp = mask.ctypes.data
+        check(self._lib.bsk_reset(self._handle(), mp, ic.ctypes.data))
+
+    def get_state(self):
+        out = np.empty((self.n_fields, self.n_envs), dtype=np.float64)
+        check(self._lib.bsk_get_state(self._handle(), out.ctypes.data))
+        return out
+
+    def set_state(self, state):
+        state = np.ascontiguousarray(state, dtype=np.float64)
+        if state.shape != (self.n_fields, self.n_envs):
+            raise ValueError("state must have shape (%d, %d)" % (self.n_fields, self.n_envs))
+        check(self._lib.bsk_set_state(self._handle(), state.ctypes.data))
+
+    def get_counters(self):
+        steps = np.empty(self.n_envs, dtype=np.int32)
+        ticks = np.empty(self.n_envs, dtype=np.int32)
+        check(self._lib.bsk_get_counters(self._handle(), steps.ctypes.data, ticks.ctypes.data))
+        return steps, ticks
+
+    # ------------------------------------------------------------------ stepping
+    def step(self, actions, substeps):
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        if a.shape != (self.n_envs,):
+            raise ValueError("actions must have shape (%d,)" % self.n_envs)
+        self._last_actions = a  # keep alive until the async H2D copy has been consumed
+        check(self._lib.bsk_step(self._handle(), a.ctypes.data, int(substeps)))
+
+    def step_device(self, d_actions_ptr, substeps):
+        check(self._lib.bsk_step_device(self._handle(), C.c_void_p(int(d_actions_ptr)), int(substeps)))
+
+    def get_obs(self):
+        """-> obs (5, N) f64, reward (N,) f64, done (N,) bool, reason (N,) uint8."""
+        obs = np.empty((5, self.n_envs), dtype=np.float64)
+        rew = np.empty(self.n_envs, dtype=np.float64)
+        done = np.empty(self.n_envs, dtype=np.uint8)
+        why = np.empty(self.n_envs, dtype=np.uint8)
+        check(self._lib.bsk_get_obs(self._handle(), obs.ctypes.data, rew.ctypes.data, done.ctypes.data, why.ctypes.data))
+        return obs, rew, done.astype(bool), why
+
+    def batch_stats(self):
+        s, d = C.c_double(), C.c_int64()
+        check(self._lib.bsk_get_batch_stats(self._handle(), C.byref(s), C.byref(d)))
+        return s.value, d.value
+
+    def device_views(self):
+        """Zero-copy ``__cuda_array_interface__`` views: obs (5, N) with the padded env stride,
+        reward (N,), done_mask (ceil(N/64),) uint64, reason (N,) uint8."""
+        po, pr, pm, pw, st = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64()
+        check(self._lib.bsk_get_obs_device(self._handle(), C.byref(po), C.byref(pr), C.byref(pm), C.byref(pw), C.byref(st)))
+        n = self.n_envs
+        return {
+            "obs": _DevArray(po.value, (5, n), "<f8", strides=(st.value * 8, 8), owner=self),
+            "reward": _DevArray(pr.value, (n,), "<f8", owner=self),
+            "done_mask": _DevArray(pm.value, ((n + 63) // 64,), "<u8", owner=self),
+            "reason": _DevArray(pw.value, (n,), "|u1", owner=self),
+            "stride": st.value,
+        }
+
+    def sync(self):
+        check(self._lib.bsk_sync(self._handle()))
+
+    def set_sim_time(self, t):
+        check(self._lib.bsk_set_sim_time(self._handle(), float(t)))
+
+    # ------------------------------------------------------------------ measurement
+    def profile_begin(self, capacity):
+        check(self._lib.bsk_profile_begin(self._handle(), int(capacity)))
+
+    def profile_end(self):
+        ms, n = C.c_double(), C.c_int()
+        check(self._lib.bsk_profile_end(self._handle(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def kernel_info(self):
+        name = C.create_string_buffer(128)
+        v, l, b, g = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        check(self._lib.bsk_kernel_info(self._handle(), name, 128, C.byref(v), C.byref(l), C.byref(b), C.byref(g)))
+        return {"name": name.value.decode(), "vgprs": v.value, "lds_bytes": l.value, "block": b.value, "grid": g.value}

@@ -1,0 +1,163 @@
+"""LEOPowerAttitudeSimulator — the scenario object the gym env owns, with the Basilisk engine
+replaced by the batched HIP propagator.
+
+Mirrors the inner surface of reference ``simulators/leoPowerAttitudeSimulator.py``:
+``LEOPowerAttitudeSimulator(dynRate, fswRate, step_duration, initial_conditions=None)`` (:67),
+``.initial_conditions`` dict with the schema of ``set_ICs`` (:119-193), ``.obs`` (5,1) (:105,
+filled from the ICs at :348-351), ``.run_sim(action) -> (obs, sim_states, sim_over)`` (:535-644)
+and ``.close_gracefully()`` (:646-652).  One instance drives ONE spacecraft (a batch of 1); the
+batched surface is ``envs.LeoPowerAttVecEnv``.
+"""
+import math
+
+import numpy as np
+
+from .._lib import GRAV_PM
+from .dynamics import config as _config
+from .dynamics.effectorPrimatives import actuatorPrimatives as ap
+from .dynamics.propagator import BatchedPropagator, pack_ic
+from .initial_conditions import leo_orbit, sc_attitudes
+
+RPM = _config.RPM
+
+
+def ic_dict_to_block(ic, n_rw):
+    """One reference-style IC dict -> SoA block ``[n_fields, 1]`` for the propagator."""
+    wheel = np.zeros(n_rw)
+    ws = np.asarray(ic.get("wheelSpeeds", np.zeros(3)), dtype=float) * RPM  # dict holds RPM (:155,303-305)
+    wheel[:min(n_rw, ws.size)] = ws[:n_rw]
+    lext = float(ic.get("disturbance_magnitude", 0.0)) * np.asarray(ic.get("disturbance_vector", np.zeros(3)), dtype=float)
+    return pack_ic(n_rw, np.asarray(ic["rN"], float).reshape(1, 3), np.asarray(ic["vN"], float).reshape(1, 3),
+                   np.asarray(ic["sigma_init"], float).reshape(1, 3), np.asarray(ic["omega_init"], float).reshape(1, 3),
+                   wheelSpeeds=wheel.reshape(1, -1) if n_rw else None, lext=lext.reshape(1, 3),
+                   charge=[float(ic.get("storedCharge_Init", 0.0))])
+
+
+class LEOPowerAttitudeSimulator(object):
+    """Drop-in for the reference simulator class; see the module docstring for the surface.
+
+    Extra keyword-only knobs (not in the reference): ``n_rw`` (3 = the reference's triad),
+    ``gravity_model``, ``device`` and ``propagator_factory`` (dependency injection for tests).
+    """
+
+    def __init__(self, dynRate, fswRate, step_duration, initial_conditions=None, *, n_rw=3,
+                 gravity_model=GRAV_PM, device=0, propagator_factory=None):
+        self.dynRate = dynRate
+        self.fswRate = fswRate
+        self.step_duration = step_duration
+        self.simTime = 0.0
+        self.n_rw = n_rw
+
+        if initial_conditions is None:
+            self.initial_conditions = self.set_ICs()
+        else:
+            self.initial_conditions = initial_conditions
+        self.mass = self.initial_conditions.get("mass")
+        self.powerDraw = self.initial_conditions.get("powerDraw")
+
+        self.obs = np.zeros([5, 1])
+        self.sim_states = np.zeros([11, 1])
+        self.sim_over = False
+        self.modeRequest = None
+
+        ic = self.initial_conditions
+        cfg = _config.default_config(n_rw=n_rw, gravity_model=gravity_model, mass=ic.get("mass"), width=ic.get("width"),
+                                     depth=ic.get("depth"), height=ic.get("height"))
+        cfg.dt = float(dynRate)
+        k = float(fswRate) / float(dynRate)
+        if abs(k - round(k)) > 1e-9 or round(k) < 1:
+            raise ValueError("fswRate must be a positive integer multiple of dynRate")
+        cfg.fsw_every = int(round(k))
+        n_sub = float(step_duration) / float(dynRate)
+        if abs(n_sub - round(n_sub)) > 1e-9 or round(n_sub) < 1:
+            raise ValueError("step_duration must be a positive integer multiple of dynRate")
+        self.substeps = int(round(n_sub))
+        cfg.K, cfg.P = float(ic.get("K")), float(ic.get("P"))
+        for j in range(3):
+            cfg.sigma_R0N[j] = float(ic.get("sigma_R0N")[j])
+        for j in range(9):
+            cfg.ctrl_axes[j] = float(ic.get("controlAxes_B")[j])
+        cfg.power_draw = float(ic.get("powerDraw"))
+        cfg.storage_capacity = float(ic.get("storageCapacity"))
+        cfg.panel_area = float(ic.get("panelArea"))
+        cfg.panel_efficiency = float(ic.get("panelEfficiency"))
+        for j in range(3):
+            cfg.panel_normal[j] = float(ic.get("nHat_B")[j])
+        self.cfg = cfg
+
+        factory = propagator_factory or BatchedPropagator
+        self.propagator = factory(cfg, 1, device=device)
+        self.propagator.reset(ic_dict_to_block(ic, n_rw))
+
+        # initial observation exactly as the reference fills it (:348-351): |sigma_BN| (not
+        # sigma_BR), |omega|, |wheel speeds| in RPM (every later step reports rad/s), charge in W h
+        self.sim_states[0:3, 0] = np.asarray(ic["sigma_init"]).flatten()
+        self.sim_states[3:6, 0] = np.asarray(ic["rN"]).flatten()
+        self.sim_states[6:9, 0] = np.asarray(ic["vN"]).flatten()
+        self.sim_states[9, 0] = ic.get("storedCharge_Init")
+        self.obs[0, 0] = np.linalg.norm(ic["sigma_init"])
+        self.obs[1, 0] = np.linalg.norm(ic["omega_init"])
+        self.obs[2, 0] = np.linalg.norm(ic["wheelSpeeds"])
+        self.obs[3, 0] = ic.get("storedCharge_Init") / 3600.0
+
+    def set_ICs(self):
+        """Random initial conditions with the reference's schema, distributions and legacy-RNG draw
+        order (:119-193): orbit, tumble, disturbance vector, wheel speeds, battery charge."""
+        oe, rN, vN = leo_orbit.sampled_400km()
+        sigma_init, omega_init = sc_attitudes.random_tumble(maxSpinRate=0.00001)
+        initial_conditions = {
+            "mass": 330,
+            "oe": oe, "rN": rN, "vN": vN,
+            "width": 1.38, "depth": 1.04, "height": 1.58,
+            "sigma_init": sigma_init, "omega_init": omega_init,
+            "planetRadius": _config.REQ_EARTH_KM * 1000., "baseDensity": 1.22, "scaleHeight": 8e3,
+            "disturbance_magnitude": 2e-4,
+            "disturbance_vector": np.random.standard_normal(3),
+            "wheelSpeeds": np.random.uniform(-800, 800, 3),  # RPM
+            "nHat_B": np.array([0, -1, 0]), "panelArea": 0.2 * 0.3, "panelEfficiency": 0.20,
+            "powerDraw": -5.0,
+            "storageCapacity": 20.0 * 3600.,
+            "storedCharge_Init": np.random.uniform(8. * 3600., 20. * 3600., 1)[0],
+            "sigma_R0N": [1, 0, 0],
+            "controlAxes_B": [1, 0, 0, 0, 1, 0, 0, 0, 1],
+            "K": 7, "Ki": -1.0, "P": 35,
+            "hs_min": 4.,
+            "thrForceSign": 1,
+            "maxCounterValue": 4,
+            "thrMinFireTime": 0.002,
+        }
+        # the reference's set_dynamics draws (and discards) one more wheel-speed triple inside
+        # balancedHR16Triad(useRandom=True) (:301, actuatorPrimatives.py:18); keep the stream aligned
+        ap.balancedHR16Triad(useRandom=True, randomBounds=(-800, 800))
+        return initial_conditions
+
+    def run_sim(self, action):
+        """Advance ``step_duration`` seconds under mode ``action`` (0 nadir, 1 sun-point, 2 desat)
+        and return ``(obs (5,1), sim_states, sim_over)`` like the reference (:535-644)."""
+        self.modeRequest = str(action)
+        if self.modeRequest not in ("0", "1", "2"):
+            raise ValueError("action must be 0, 1 or 2, got %r" % (action,))
+        self.sim_over = False
+        self.simTime += self.step_duration
+        self.propagator.step(np.array([int(self.modeRequest)], dtype=np.int32), self.substeps)
+        dev_obs, _, _, _ = self.propagator.get_obs()
+        st = self.propagator.get_state()
+        omega = st[9:12, 0]
+        wheels = st[12:12 + min(self.n_rw, 3), 0]  # the reference logs wheelSpeeds[0:3] (:606,614)
+        charge = st[12 + self.n_rw + 7, 0]
+        obs = np.hstack([dev_obs[0, 0], np.linalg.norm(omega), np.linalg.norm(wheels), charge / 3600., dev_obs[4, 0]])
+        self.obs = obs.reshape(len(obs), 1)
+        self.sim_states = []
+        if np.linalg.norm(st[0:3, 0]) < (_config.REQ_EARTH_KM / 1000.):
+            self.sim_over = True
+        return self.obs, self.sim_states, self.sim_over
+
+    def close_gracefully(self):
+        """The reference unloads SPICE kernels here (:646-652); this build has none to unload.
+        The device buffers stay valid until the object is deleted (reset_init reads
+        ``initial_conditions`` after this call)."""
+        return
+
+
+def create_leoPowerAttSimulator():
+    return LEOPowerAttitudeSimulator(0.1, 0.1, 60.)

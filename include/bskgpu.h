@@ -1,0 +1,221 @@
+/*
+ * bskgpu.h — C-ABI of libbskgpu.so: batched MI355X (gfx950) spacecraft propagator.
+ *
+ * This is the drop-in boundary for ONE hot path of atharris/basilisk_env: the per-env-step
+ * call into the Basilisk engine,
+ *     LEOPowerAttitudeSimulator.run_sim -> ConfigureStopTime + ExecuteSimulation
+ *     (reference basilisk_env/simulators/leoPowerAttitudeSimulator.py:535-644, hot call :594-595)
+ * for N independent spacecraft at once.  Plain pointers and sizes only; no torch / numpy types.
+ * Every entry point returns 0 on success or a negative BSK_E* code and never throws.
+ * `bsk_last_error()` returns a thread-local message for the last failure on this thread.
+ *
+ * Ownership: the caller owns every host buffer; the library owns every device buffer.
+ * One handle <-> one device <-> one HIP stream.  A handle is not thread-safe; distinct handles are.
+ * There is NO CPU fallback: bsk_create fails with BSK_ENODEV when no gfx950 device is usable.
+ *
+ * Layouts are structure-of-arrays, fp64: field f of env i lives at buf[f * n_envs + i]
+ * on the host side of this ABI (the device side pads the env stride to a multiple of 256).
+ */
+#ifndef BSKGPU_H
+#define BSKGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSK_ABI_VERSION 1u
+#define BSK_MAX_RW 4
+#define BSK_MAX_THR 8
+#define BSK_MAX_SH_DEGREE 70
+
+/* error codes */
+#define BSK_OK 0
+#define BSK_EINVAL (-1)   /* bad argument / config */
+#define BSK_ENODEV (-2)   /* no usable gfx950 device */
+#define BSK_ENOMEM (-3)   /* device allocation failed */
+#define BSK_EHIP (-4)     /* HIP runtime error (see bsk_last_error) */
+#define BSK_EABI (-5)     /* bsk_config abi_version / struct_size mismatch */
+
+/* gravity models (reference: gravBodyFactory, leoPowerAttitudeSimulator.py:217-232; the only
+ * spherical-harmonics call site is opNav_models/BSK_OpNavDynamics.py:211-214) */
+enum { BSK_GRAV_PM = 0, BSK_GRAV_PM_J2 = 1, BSK_GRAV_SH = 2 };
+
+/* flags */
+#define BSK_FLAG_SUN_THIRD_BODY 0x1u /* Sun third-body gravity (leoPowerAttitudeSimulator.py:227) */
+#define BSK_FLAG_POWER 0x2u          /* eclipse + solar panel + battery (…Simulator.py:286-288,326-345) */
+#define BSK_FLAG_DESAT 0x4u          /* action 2 fires the thruster octet (…Simulator.py:574-588) */
+#define BSK_FLAG_DRAG 0x8u           /* exponential atmosphere + facet drag (…Simulator.py:265-284) */
+#define BSK_FLAG_AUTO_RESET 0x10u    /* device-side masked auto-reset from a staged IC pool */
+#define BSK_FLAG_LDS_SCRATCH 0x20u   /* stage the RK4 scratch in LDS instead of VGPRs */
+
+/* State field indices of the SoA state block, bsk_get_state / bsk_set_state / bsk_reset `ic`.
+ * n_fields = BSK_NF_BASE + n_rw (wheel speeds) + BSK_NF_TAIL.                                   */
+enum {
+    BSK_F_R = 0,      /* r_BN_N   [m]      3 fields  (scObject.hub.r_CN_NInit,  …Simulator.py:252) */
+    BSK_F_V = 3,      /* v_BN_N   [m/s]    3 fields  (…Simulator.py:253)                            */
+    BSK_F_SIGMA = 6,  /* sigma_BN [-]      3 fields  (…Simulator.py:258)                            */
+    BSK_F_OMEGA = 9,  /* omega_BN_B [rad/s] 3 fields (…Simulator.py:259)                            */
+    BSK_NF_BASE = 12, /* wheel speeds Omega_i [rad/s] follow: n_rw fields (…Simulator.py:303-305)   */
+};
+/* tail fields after the wheel speeds */
+enum {
+    BSK_T_LEXT = 0,    /* external disturbance torque L_B [N m] 3 fields (…Simulator.py:291-298)    */
+    BSK_T_UCMD = 3,    /* held wheel motor torque u_s [N m]: BSK_MAX_RW fields (zero-order hold)    */
+    BSK_T_CHARGE = 7,  /* battery stored charge [W s] 1 field (…Simulator.py:343)                   */
+    BSK_NF_TAIL = 8,
+};
+
+typedef struct bsk_config {
+    uint32_t abi_version; /* = BSK_ABI_VERSION */
+    uint32_t struct_size; /* = sizeof(bsk_config) */
+
+    /* integrator / schedule (reference: dynRate .1, fswRate 1.0 — leoPowerAttitudeEnvironment.py:185) */
+    double dt;         /* RK4 step [s]                                                       */
+    int32_t fsw_every; /* RK4 steps per FSW update (fswRate / dynRate)                       */
+    int32_t gravity_model;
+    int32_t sh_degree; /* used when gravity_model == BSK_GRAV_SH                             */
+    int32_t n_rw;      /* 0..BSK_MAX_RW                                                      */
+    uint32_t flags;
+    int32_t max_length; /* episode length in env steps (leoPowerAttitudeEnvironment.py:25)   */
+
+    /* gravity constants (leo_orbit.py:30; REQ_EARTH at …Simulator.py:146) */
+    double mu;      /* m^3/s^2 */
+    double req;     /* m       */
+    double j2;      /* -        */
+    double planet_rate; /* rad/s, planet-fixed frame rotation about inertial z (SH only)     */
+
+    /* hub (…Simulator.py:245-250) */
+    double inertia[9]; /* I_sc about B, body frame, row-major [kg m^2] */
+    double mass;       /* kg */
+
+    /* reaction wheels (actuatorPrimatives.py:7-63; 4-wheel pyramid BSK_OpNavDynamics.py:278-291) */
+    double gs[BSK_MAX_RW][3]; /* spin axes, body frame, unit */
+    double js[BSK_MAX_RW];    /* spin-axis inertia [kg m^2]   */
+    double u_max;             /* motor torque saturation [N m] */
+    double u_min;             /* motor torque dead-band [N m]  */
+    double f_coulomb;         /* Coulomb friction torque [N m] */
+
+    /* FSW (…Simulator.py:170-180, 407-449) */
+    double K, P;            /* MRP_Feedback gains (Ki < 0: integral feedback off) */
+    double sigma_R0N[3];    /* inertial3D reference                               */
+    double ctrl_axes[9];    /* rwMotorTorque controlAxes_B, row-major             */
+
+    /* env constants (leoPowerAttitudeEnvironment.py:36-42; …Simulator.py:641) */
+    double wheel_limit;     /* rad/s */
+    double power_max;       /* W h   */
+    double reward_mult;
+    double failure_penalty;
+    double r_min;           /* |r| below this ends the episode ("orbit decayed") */
+
+    /* power system (…Simulator.py:158-167) */
+    double panel_normal[3]; /* nHat_B */
+    double panel_area, panel_efficiency;
+    double power_draw;       /* W, negative = sink */
+    double storage_capacity; /* W s */
+    double solar_flux;       /* W/m^2 at 1 AU */
+
+    /* Sun (replaces spice_interface, …Simulator.py:219-225): position at t = 0 and velocity,
+       inertial, Earth-centred; advanced linearly once per env step like the 180 s SPICE task */
+    double sun_r0[3];
+    double sun_v[3];
+    double mu_sun;
+
+    /* desaturation (actuatorPrimatives.py:66-161; …Simulator.py:183-190, 452-478) */
+    int32_t n_thr;
+    int32_t thr_max_counter;
+    double thr_pos[BSK_MAX_THR][3];
+    double thr_dir[BSK_MAX_THR][3];
+    double thr_max_thrust;
+    double thr_min_fire_time;
+    double hs_min;
+
+    /* drag (…Simulator.py:147-148, 272-281) */
+    double base_density, scale_height;
+    int32_t n_facets;
+    int32_t pad0_;
+    double facet_area[8], facet_cd[8];
+    double facet_normal[8][3], facet_pos[8][3];
+} bsk_config;
+
+typedef struct bsk_handle bsk_handle;
+
+/* Fill `cfg` with the reference scenario's constants (…Simulator.py:127-191) for `n_rw` wheels
+ * (3 = actuatorPrimatives.py triad, 4 = BSK_OpNavDynamics.py:278-291 pyramid, 0 = none). */
+int bsk_default_config(bsk_config* cfg, int n_rw, int gravity_model);
+
+/* Replaces LEOPowerAttitudeSimulator.__init__ (…Simulator.py:67-117) for n_envs spacecraft.
+ * `stream` may be NULL (the library creates its own hipStream_t) or an existing hipStream_t. */
+int bsk_create(const bsk_config* cfg, int n_envs, int device_id, void* stream, bsk_handle** out);
+void bsk_destroy(bsk_handle* h);
+
+/* Normalised spherical-harmonic coefficients Cbar/Sbar, index l*(l+1)/2+m, 0<=m<=l<=degree. */
+int bsk_set_gravity_sh(bsk_handle* h, int degree, const double* cbar, const double* sbar);
+
+/* Replaces set_ICs + hub/wheel/battery initialisation (…Simulator.py:119-193, 249-259, 303-305, 343)
+ * and reset_init's IC replay (leoPowerAttitudeEnvironment.py:202-216).
+ * mask: NULL = all envs, else uint8[n_envs] (non-zero = reset this env).
+ * ic: host SoA [n_fields][n_envs] as in the field enums above; step counters are zeroed. */
+int bsk_reset(bsk_handle* h, const uint8_t* mask, const double* ic);
+
+/* Replaces run_sim(action) (…Simulator.py:535-644) + the env's reward/done logic
+ * (leoPowerAttitudeEnvironment.py:98-127,161-170) for every env: mode switch, `substeps` RK4
+ * steps with the FSW chain every fsw_every steps, observation/reward/done.  Asynchronous on
+ * the handle's stream.  actions: int32[n_envs] in {0,1,2} (host pointer; copied H2D). */
+int bsk_step(bsk_handle* h, const int32_t* actions, int substeps);
+/* Same, actions already resident in device memory (no PCIe traffic on the step path). */
+int bsk_step_device(bsk_handle* h, const int32_t* d_actions, int substeps);
+
+/* Host copies of the last step's outputs (synchronises the stream).  Any pointer may be NULL.
+ * obs: f64[5][n_envs] = [|sigma_BR|, |omega_BN_B|, |Omega|/wheel_limit, charge/3600/power_max,
+ * shadow factor] (…Simulator.py:636-638 + leoPowerAttitudeEnvironment.py:107-108);
+ * reward f64[n_envs]; done uint8[n_envs]; done_reason uint8[n_envs] bit-or of BSK_DONE_*. */
+#define BSK_DONE_LENGTH 0x1
+#define BSK_DONE_WHEELS 0x2
+#define BSK_DONE_BATTERY 0x4
+#define BSK_DONE_ORBIT 0x8
+int bsk_get_obs(bsk_handle* h, double* obs, double* reward, uint8_t* done, uint8_t* done_reason);
+
+/* Device pointers of the output buffers (for the RCCL gather / zero-copy hand-off).
+ * obs stride (envs per field) is returned in *stride; done_mask is uint64[ceil(n/64)]. */
+int bsk_get_obs_device(bsk_handle* h, double** d_obs, double** d_reward, uint64_t** d_done_mask,
+                       uint8_t** d_done_reason, int64_t* stride);
+
+/* Batch scalars produced with wavefront reductions: sum of rewards and number of done envs
+ * of the last step (synchronises). */
+int bsk_get_batch_stats(bsk_handle* h, double* reward_sum, int64_t* n_done);
+
+/* Full state read-back / injection, host SoA [n_fields][n_envs] (parity tests, reset_init). */
+int bsk_n_fields(const bsk_handle* h);
+int bsk_get_state(bsk_handle* h, double* state);
+int bsk_set_state(bsk_handle* h, const double* state);
+/* per-env counters: env steps and RK4 ticks since reset, int32[n_envs] each (may be NULL) */
+int bsk_get_counters(bsk_handle* h, int32_t* steps, int32_t* ticks);
+
+/* Stage a pool of initial conditions for BSK_FLAG_AUTO_RESET: host SoA [n_fields][n_pool]. */
+int bsk_set_ic_pool(bsk_handle* h, int n_pool, const double* ic_pool);
+
+/* Sun state override for the next steps (inertial, Earth-centred) — see sun_r0/sun_v. */
+int bsk_set_sim_time(bsk_handle* h, double t_seconds);
+
+int bsk_sync(bsk_handle* h);
+
+/* Per-launch timing of the step kernel with hipEvents recorded on the handle's stream around
+ * each launch.  begin() arms it (capacity launches); end() synchronises and reports the mean
+ * kernel duration in milliseconds over the launches seen since begin(). */
+int bsk_profile_begin(bsk_handle* h, int capacity);
+int bsk_profile_end(bsk_handle* h, double* mean_kernel_ms, int* n_launches);
+
+/* Kernel resource facts for DESIGN.md / bench: name of the kernel variant selected for this
+ * handle, its VGPR count, static LDS bytes and the launch geometry. */
+int bsk_kernel_info(bsk_handle* h, char* name, int name_cap, int* vgprs, int* lds_bytes,
+                    int* block, int* grid);
+
+const char* bsk_last_error(void);
+const char* bsk_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSKGPU_H */

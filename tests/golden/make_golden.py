@@ -1,0 +1,318 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/trajectories.json: 50-digit mpmath trajectories of the hot path.
+
+An independent restatement (plain Python lists of mpf, no numpy, no C) of the same step
+sequence the CPU oracle (oracle/bsk_oracle.c) and the HIP kernels execute: FSW chain every
+``fsw_every`` ticks -> classic RK4 -> MRP shadow switch, then the observation.  Inputs (ICs and
+config constants) are exact doubles; every derived constant and every operation is carried at
+50 significant digits and only the final values are rounded to double.  The fp64
+implementations must agree with these to ~1e-12 relative, far inside the 1e-9 budget of
+BASELINE.json.
+
+Run from the repo root:  python tests/golden/make_golden.py      (about two minutes)
+No file under /root/reference is read: Basilisk itself is not available, so
+this pins the restated equations, not Basilisk's binaries ("parity unpinned").
+"""
+import json
+import os
+import sys
+
+import mpmath as mp
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from basilisk_env_amd._lib import GRAV_PM, GRAV_PM_J2, n_fields  # noqa: E402
+from basilisk_env_amd.simulators.dynamics.config import config_to_dict, default_config  # noqa: E402
+from basilisk_env_amd.simulators.initial_conditions.batch import sample_ic_batch  # noqa: E402
+
+mp.mp.dps = 50
+M = mp.mpf
+
+
+# ------------------------------------------------------------------ vectors
+def dot(a, b):
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]
+
+
+def cross(a, b):
+    return [a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]]
+
+
+def scale(s, a):
+    return [s * x for x in a]
+
+
+def add(a, b):
+    return [x + y for x, y in zip(a, b)]
+
+
+def sub(a, b):
+    return [x - y for x, y in zip(a, b)]
+
+
+def norm(a):
+    return mp.sqrt(dot(a, a))
+
+
+def matvec(m, v):
+    return [dot(m[0], v), dot(m[1], v), dot(m[2], v)]
+
+
+def inv3(m):
+    return (mp.matrix(m) ** -1).tolist()
+
+
+# ------------------------------------------------------------------ attitude kinematics
+def mrp2c(q):
+    q2 = dot(q, q)
+    t = [[0, -q[2], q[1]], [q[2], 0, -q[0]], [-q[1], q[0], 0]]
+    d = (1 + q2) ** 2
+    C = [[M(int(i == j)) for j in range(3)] for i in range(3)]
+    for i in range(3):
+        for j in range(3):
+            t2 = sum(t[i][k] * t[k][j] for k in range(3))
+            C[i][j] += (8 * t2 - 4 * (1 - q2) * t[i][j]) / d
+    return C
+
+
+def c2mrp(C):
+    tr = C[0][0] + C[1][1] + C[2][2]
+    b2 = [(1 + tr) / 4, (1 + 2 * C[0][0] - tr) / 4, (1 + 2 * C[1][1] - tr) / 4, (1 + 2 * C[2][2] - tr) / 4]
+    i = 0
+    for j in range(1, 4):
+        if b2[j] > b2[i]:
+            i = j
+    b = [None] * 4
+    if i == 0:
+        b[0] = mp.sqrt(b2[0])
+        b[1] = (C[1][2] - C[2][1]) / 4 / b[0]
+        b[2] = (C[2][0] - C[0][2]) / 4 / b[0]
+        b[3] = (C[0][1] - C[1][0]) / 4 / b[0]
+    elif i == 1:
+        b[1] = mp.sqrt(b2[1])
+        b[0] = (C[1][2] - C[2][1]) / 4 / b[1]
+        if b[0] < 0:
+            b[1], b[0] = -b[1], -b[0]
+        b[2] = (C[0][1] + C[1][0]) / 4 / b[1]
+        b[3] = (C[2][0] + C[0][2]) / 4 / b[1]
+    elif i == 2:
+        b[2] = mp.sqrt(b2[2])
+        b[0] = (C[2][0] - C[0][2]) / 4 / b[2]
+        if b[0] < 0:
+            b[2], b[0] = -b[2], -b[0]
+        b[1] = (C[0][1] + C[1][0]) / 4 / b[2]
+        b[3] = (C[1][2] + C[2][1]) / 4 / b[2]
+    else:
+        b[3] = mp.sqrt(b2[3])
+        b[0] = (C[0][1] - C[1][0]) / 4 / b[3]
+        if b[0] < 0:
+            b[3], b[0] = -b[3], -b[0]
+        b[1] = (C[2][0] + C[0][2]) / 4 / b[3]
+        b[2] = (C[1][2] + C[2][1]) / 4 / b[3]
+    return [b[k + 1] / (1 + b[0]) for k in range(3)]
+
+
+def submrp(q1, q2):
+    s1 = list(q1)
+    d1, d2 = dot(s1, s1), dot(q2, q2)
+    den = 1 + d1 * d2 + 2 * dot(s1, q2)
+    if abs(den) < M("0.1"):
+        s1 = scale(-1 / d1, s1)
+        d1 = dot(s1, s1)
+        den = 1 + d1 * d2 + 2 * dot(s1, q2)
+    t = cross(s1, q2)
+    q = [((1 - d2) * s1[k] - (1 - d1) * q2[k] + 2 * t[k]) / den for k in range(3)]
+    m = dot(q, q)
+    if m > 1:
+        q = scale(-1 / m, q)
+    return q
+
+
+# ------------------------------------------------------------------ model
+class Model(object):
+    def __init__(self, cfg):
+        c = config_to_dict(cfg)
+        self.n_rw = int(c["n_rw"])
+        self.grav = int(c["gravity_model"])
+        self.dt = M(float(c["dt"]))
+        self.fsw_every = int(c["fsw_every"])
+        self.mu, self.req, self.j2 = M(float(c["mu"])), M(float(c["req"])), M(float(c["j2"]))
+        self.I = [[M(float(c["inertia"][3 * i + j])) for j in range(3)] for i in range(3)]
+        self.gs = [[M(float(c["gs"][i][k])) for k in range(3)] for i in range(self.n_rw)]
+        self.js = [M(float(c["js"][i])) for i in range(self.n_rw)]
+        self.u_max, self.u_min, self.fc = M(float(c["u_max"])), M(float(c["u_min"])), M(float(c["f_coulomb"]))
+        self.K, self.P = M(float(c["K"])), M(float(c["P"]))
+        self.sR0N = [M(float(v)) for v in c["sigma_R0N"]]
+        Cax = [[M(float(c["ctrl_axes"][3 * i + j])) for j in range(3)] for i in range(3)]
+        D = [[self.I[a][b] - sum(self.js[i] * self.gs[i][a] * self.gs[i][b] for i in range(self.n_rw)) for b in range(3)]
+             for a in range(3)]
+        self.Dinv = inv3(D)
+        if self.n_rw:
+            cgs = [[dot(Cax[a], self.gs[i]) for i in range(self.n_rw)] for a in range(3)]
+            Mi = inv3([[sum(cgs[a][i] * cgs[b][i] for i in range(self.n_rw)) for b in range(3)] for a in range(3)])
+            self.map = []
+            for i in range(self.n_rw):
+                t = [sum(cgs[k][i] * Mi[k][a] for k in range(3)) for a in range(3)]
+                self.map.append([sum(t[k] * Cax[k][b] for k in range(3)) for b in range(3)])
+        self.wheel_limit, self.power_max = M(float(c["wheel_limit"])), M(float(c["power_max"]))
+        self.reward_mult, self.failure_penalty = M(float(c["reward_mult"])), M(float(c["failure_penalty"]))
+        self.r_min, self.max_length = M(float(c["r_min"])), int(c["max_length"])
+
+    def gravity(self, r):
+        rm = norm(r)
+        a = scale(-self.mu / rm ** 3, r)
+        if self.grav == GRAV_PM_J2:
+            z2 = (r[2] / rm) ** 2
+            k = M(3) / 2 * self.j2 * self.mu * self.req ** 2 / rm ** 5
+            a = [a[0] + k * r[0] * (5 * z2 - 1), a[1] + k * r[1] * (5 * z2 - 1), a[2] + k * r[2] * (5 * z2 - 3)]
+        return a
+
+    def eom(self, x, u, lext):
+        r, v, s, w, Om = x[0:3], x[3:6], x[6:9], x[9:12], x[12:]
+        dv = self.gravity(r)
+        s2, sw, sxw = dot(s, s), dot(s, w), cross(s, w)
+        ds = [((1 - s2) * w[k] + 2 * sxw[k] + 2 * sw * s[k]) / 4 for k in range(3)]
+        rhs = add(scale(-1, cross(w, matvec(self.I, w))), lext)
+        tq = []
+        for i in range(self.n_rw):
+            fr = -self.fc if Om[i] > 0 else (self.fc if Om[i] < 0 else M(0))
+            tq.append(u[i] + fr)
+            wg = cross(w, self.gs[i])
+            rhs = [rhs[k] - self.gs[i][k] * tq[i] - self.js[i] * Om[i] * wg[k] for k in range(3)]
+        dw = matvec(self.Dinv, rhs)
+        dOm = [tq[i] / self.js[i] - dot(self.gs[i], dw) for i in range(self.n_rw)]
+        return list(v) + dv + ds + dw + dOm
+
+    def rk4(self, x, u, lext):
+        h = self.dt
+        ax = lambda a, k, y: [yi + a * ki for yi, ki in zip(y, k)]  # noqa: E731
+        k1 = self.eom(x, u, lext)
+        k2 = self.eom(ax(h / 2, k1, x), u, lext)
+        k3 = self.eom(ax(h / 2, k2, x), u, lext)
+        k4 = self.eom(ax(h, k3, x), u, lext)
+        x = [x[i] + h / 6 * k1[i] + h / 3 * k2[i] + h / 3 * k3[i] + h / 6 * k4[i] for i in range(len(x))]
+        s2 = dot(x[6:9], x[6:9])
+        if s2 > 1:
+            x[6:9] = scale(-1 / s2, x[6:9])
+        return x
+
+    def guidance(self, x, action):
+        r, v, s, w = x[0:3], x[3:6], x[6:9], x[9:12]
+        if action == 0:
+            rm = norm(r)
+            h = cross(r, v)
+            hm = norm(h)
+            e_r, e_h = scale(1 / rm, r), scale(1 / hm, h)
+            e_t = cross(e_h, e_r)
+            sRN = c2mrp([e_r, e_t, e_h])
+            dfdt = hm / rm ** 2
+            ddf = -2 * dot(v, e_r) / rm * dfdt
+            wRN, dwRN = scale(dfdt, e_h), scale(ddf, e_h)
+        else:
+            sRN, wRN, dwRN = list(self.sR0N), [M(0)] * 3, [M(0)] * 3
+        sBR = submrp(s, sRN)
+        BN = mrp2c(s)
+        wRN_B, dwRN_B = matvec(BN, wRN), matvec(BN, dwRN)
+        return sBR, sub(w, wRN_B), wRN_B, dwRN_B
+
+    def control(self, g):
+        sBR, wBR, wRN, dwRN = g
+        wBN = add(wBR, wRN)
+        Lr = add(scale(self.K, sBR), scale(self.P, wBR))
+        Lr = sub(Lr, cross(wRN, matvec(self.I, wBN)))
+        Lr = add(Lr, matvec(self.I, sub(cross(wBN, wRN), dwRN)))
+        Lr = scale(-1, Lr)
+        u = []
+        for i in range(self.n_rw):
+            us = -dot(self.map[i], Lr)
+            if self.u_max > 0:
+                us = min(max(us, -self.u_max), self.u_max)
+            if abs(us) < self.u_min:
+                us = M(0)
+            u.append(us)
+        return u
+
+    def step(self, env, action, substeps):
+        """env: dict(x, u, lext, charge, steps, ticks) — one spacecraft; mutated."""
+        x, u = env["x"], env["u"]
+        for _ in range(substeps):
+            if self.n_rw and env["ticks"] % self.fsw_every == 0:
+                u = self.control(self.guidance(x, action))
+            x = self.rk4(x, u, env["lext"])
+            env["ticks"] += 1
+        env["x"], env["u"] = x, u
+        sBR = self.guidance(x, action)[0]
+        o0, o1 = norm(sBR), norm(x[9:12])
+        o2 = mp.sqrt(sum(v * v for v in x[12:])) / self.wheel_limit if self.n_rw else M(0)
+        o3 = env["charge"] / 3600 / self.power_max
+        why = 0
+        rew = self.reward_mult / (1 + o0 * o0) if action == 0 else M(0)
+        if env["steps"] >= self.max_length:
+            why |= 1
+        if o2 > 1:
+            why |= 2
+            rew -= self.failure_penalty
+        if o3 == 0:
+            why |= 4
+            rew -= self.failure_penalty
+        if norm(x[0:3]) < self.r_min:
+            why |= 8
+        env["steps"] += 1
+        return [o0, o1, o2, o3, M(1)], rew, why
+
+
+def run_case(name, n_rw, grav, n_envs, seed, schedule, cfg_edit=None):
+    cfg = default_config(n_rw=n_rw, gravity_model=grav)
+    if cfg_edit:
+        cfg_edit(cfg)
+    model = Model(cfg)
+    ic = sample_ic_batch(n_envs, n_rw, seed=seed)
+    nf = n_fields(n_rw)
+    t = 12 + n_rw
+    envs = []
+    for e in range(n_envs):
+        envs.append({"x": [M(float(ic[f, e])) for f in range(12 + n_rw)], "u": [M(0)] * n_rw,
+                     "lext": [M(float(ic[t + k, e])) for k in range(3)], "charge": M(float(ic[t + 7, e])),
+                     "steps": 0, "ticks": 0})
+    calls = []
+    for ci, (actions, substeps) in enumerate(schedule):
+        obs, rews, whys = [], [], []
+        for e, env in enumerate(envs):
+            o, r, w = model.step(env, int(actions[e]), substeps)
+            obs.append([float(v) for v in o])
+            rews.append(float(r))
+            whys.append(w)
+        state = np.zeros((nf, n_envs))
+        for e, env in enumerate(envs):
+            state[:12 + n_rw, e] = [float(v) for v in env["x"]]
+            state[t:t + 3, e] = [float(v) for v in env["lext"]]
+            state[t + 3:t + 3 + n_rw, e] = [float(v) for v in env["u"]]
+            state[t + 7, e] = float(env["charge"])
+        calls.append({"actions": [int(a) for a in actions], "substeps": int(substeps), "state": state.tolist(),
+                      "obs": np.array(obs).T.tolist(), "reward": rews, "reason": whys})
+        print("  %s call %d/%d done" % (name, ci + 1, len(schedule)), flush=True)
+    return {"name": name, "n_rw": n_rw, "gravity_model": grav, "n_envs": n_envs, "seed": seed, "ic": ic.tolist(),
+            "calls": calls}
+
+
+def main():
+    n = 8
+    rng = np.random.Generator(np.random.PCG64(99))
+    cases = []
+    # config-2 shape: point mass + MRP attitude, no wheels; checkpoints at 1, 10, 100, 1000 RK4 steps
+    cases.append(run_case("pm_norw", 0, GRAV_PM, n, 11, [(np.zeros(n, int), k) for k in (1, 9, 90, 900)]))
+    # config-3 shape: J2 + 4-wheel pyramid; nadir/sun-point per env; u is held across the calls
+    cases.append(run_case("j2_rw4", 4, GRAV_PM_J2, n, 12, [(np.arange(n) % 2, k) for k in (1, 9, 90, 900)]))
+    # reference wiring: point mass + 3-wheel triad, mode switches between calls, odd call lengths
+    sched = [(rng.integers(0, 3, n), int(k)) for k in (50, 37, 3, 110, 50, 50, 25, 75)]
+    cases.append(run_case("pm_rw3_modes", 3, GRAV_PM, n, 13, sched))
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "trajectories.json")
+    with open(out, "w") as f:
+        json.dump({"dps": mp.mp.dps, "generator": "tests/golden/make_golden.py", "cases": cases}, f)
+    print("wrote", out, os.path.getsize(out), "bytes")
+
+
+if __name__ == "__main__":
+    main()
