@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the batched HIP propagator on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[2], the one the metric is quoted on): 65 536 spacecraft PER GPU,
+J2 gravity + 4 reaction wheels (pyramid) + nadir-pointing reward (action 0), fp64, synthetic
+random-orbit batch, one RK4 sub-step of 0.1 s per env step (the HBM framing
+of the metric).  Envs are independent: ranks shard them with no collective on the step path
+("scaling": "weak"); one RCCL all-gather of the observation shards is exercised and timed
+after the timed region (``gather_ms``).
+
+A "step" = one pass of the hot path over the whole batch (one kernel launch per GPU): mode
+switch, FSW chain when due, RK4, observation, reward, done mask, wave reductions.  Actions and
+state are resident in HBM when the timed region starts.
+
+Besides the contract keys the JSON line carries ``roofline`` (dominant kernel, algorithmic
+bytes = 340 B/env-step), ``cpu_baseline`` (the CPU oracle on this box's host
+cores, rank 0 at N=1 only) and ``extra`` (the reference-faithful 1 800 sub-steps/env-step rate
+and a large-batch roofline point).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_ENV_STEP = 340.0   # config 3/4 algorithmic bytes per env-step
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FLOP_PER_RK4 = 4 * 330 + 110  # SURVEY.md §8(d) algorithmic flops per RK4 sub-step, config 3
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--envs", type=int, default=65536, help="spacecraft per GPU")
+    p.add_argument("--substeps", type=int, default=1, help="RK4 sub-steps per env step")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extra", action="store_true")
+    return p.parse_args()
+
+
+def timed_run(prop, d_act_ptr, substeps, steps, warmup, barrier, torch):
+    for _ in range(warmup):
+        prop.step_device(d_act_ptr, substeps)
+    prop.sync()
+    prop.profile_begin(steps)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        prop.step_device(d_act_ptr, substeps)
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    kernel_ms, n_launch = prop.profile_end()
+    return t1 - t0, kernel_ms, n_launch
+
+
+def cpu_baseline(cfg, n_rw, substeps):
+    """The CPU oracle (plain-C restatement, oracle/bsk_oracle.c) on the host cores of this box:
+    OpenMP over spacecraft, bounded to ~10-20 s.  A reported baseline, not the target."""
+    import numpy as np
+
+    from basilisk_env_amd.simulators.initial_conditions.batch import sample_ic_batch
+    from oracle import oracle
+
+    cores = os.cpu_count() or 1
+    n = 8192
+    st = sample_ic_batch(n, n_rw, seed=0)
+    steps_c, ticks_c = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    act = np.zeros(n, np.int32)
+    oracle.step(cfg, st, steps_c, ticks_c, act, substeps, omp=True)  # warm
+    t0 = time.perf_counter()
+    done_steps = 0
+    while True:
+        oracle.step(cfg, st, steps_c, ticks_c, act, substeps, omp=True)
+        done_steps += 1
+        el = time.perf_counter() - t0
+        if el > 12.0 or done_steps >= 100000:
+            break
+    return {"value": n * done_steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d envs x %d env-steps of %d RK4 sub-step(s), same physics/config, OpenMP over envs, %.1f s"
+                      % (n, done_steps, substeps, el)}
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a MI355X: no HIP device visible (there is no CPU path to measure)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    from basilisk_env_amd._lib import GRAV_PM_J2
+    from basilisk_env_amd.simulators.dynamics import BatchedPropagator, default_config
+    from basilisk_env_amd.simulators.initial_conditions.batch import sample_ic_batch
+
+    n_rw = 4
+    cfg = default_config(n_rw=n_rw, gravity_model=GRAV_PM_J2)
+    n = a.envs
+    ic = sample_ic_batch(n, n_rw, seed=rank)       # rank r owns env indices [r*n, (r+1)*n)
+    prop = BatchedPropagator(cfg, n, device=local)
+    prop.reset(ic)
+    d_act = torch.zeros(n, dtype=torch.int32, device="cuda")  # action 0 = nadir pointing (reward mode)
+    torch.cuda.synchronize()
+
+    el, kernel_ms, n_launch = timed_run(prop, d_act.data_ptr(), a.substeps, a.steps, a.warmup, barrier, torch)
+    el_t = torch.tensor([el], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
+    el = float(el_t.item())
+    obs, rew, done, why = prop.get_obs()
+    assert np.isfinite(obs).all() and np.isfinite(rew).all()
+    info = prop.kernel_info()
+
+    # the one exchange step of the path: all-gather of the observation shards over RCCL/xGMI
+    gather_ms = None
+    if dist is not None:
+        from basilisk_env_amd.parallel import gather_observations
+        gather_observations(prop, dist)  # warm
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        full = gather_observations(prop, dist)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - t0) * 1e3
+        assert full.shape == (world, 5, n)
+
+    value = n * world * a.steps / el
+    kernel_s = kernel_ms * 1e-3
+    achieved = BYTES_PER_ENV_STEP * n / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    out = {
+        "metric": "env steps/sec at 65k parallel spacecraft per GPU",
+        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: %d envs/GPU, J2 gravity + 4 reaction wheels (pyramid) + "
+                               "nadir-pointing reward, fp64, dt 0.1 s, %d RK4 sub-step(s) per env step, fsw every 10 "
+                               "sub-steps, synthetic random-orbit batch PCG64(rank)" % (n, a.substeps),
+                   "envs_per_gpu": n, "substeps": a.substeps, "sharding": "env ranges, no step-path collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": info["name"], "kernel_us": kernel_ms * 1e3, "launches_timed": n_launch,
+                     "bytes_per_env_step": BYTES_PER_ENV_STEP, "vgprs": info["vgprs"], "block": info["block"],
+                     "grid": info["grid"]},
+        "rk4_substeps_per_s": value * a.substeps,
+    }
+    if gather_ms is not None:
+        out["gather_ms"] = gather_ms
+
+    if rank == 0 and world == 1 and not a.no_extra:
+        extra = {}
+        # reference-faithful env step: 180 s of sim time = 1 800 RK4 sub-steps, 180 FSW updates
+        ksteps = 5
+        el2, km2, _ = timed_run(prop, d_act.data_ptr(), 1800, ksteps, 1, barrier, torch)
+        extra["k1800"] = {"env_steps_per_s": n * ksteps / el2, "rk4_substeps_per_s": n * ksteps * 1800 / el2,
+                          "fp64_tflops_algorithmic": n * ksteps * 1800 * FLOP_PER_RK4 / el2 / 1e12,
+                          "kernel_ms": km2, "ms_per_step": el2 / ksteps * 1e3}
+        # large-batch point where the HBM roofline is the binding limit (4 Mi envs = 1.4 GB/launch)
+        nl = 1 << 22
+        big = BatchedPropagator(cfg, nl, device=local)
+        big.reset(sample_ic_batch(nl, n_rw, seed=1))
+        d_act_big = torch.zeros(nl, dtype=torch.int32, device="cuda")
+        el3, km3, _ = timed_run(big, d_act_big.data_ptr(), 1, 50, 5, barrier, torch)
+        extra["large_n"] = {"envs": nl, "env_steps_per_s": nl * 50 / el3, "kernel_us": km3 * 1e3,
+                            "achieved_gbs": BYTES_PER_ENV_STEP * nl / (km3 * 1e-3) / 1e9,
+                            "frac_of_8TBs": BYTES_PER_ENV_STEP * nl / (km3 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        big.close()
+        out["extra"] = extra
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, n_rw, a.substeps)
+    prop.close()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

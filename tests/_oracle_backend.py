@@ -1,0 +1,59 @@
+"""Oracle-backed stand-in for ``BatchedPropagator`` with the same Python interface.
+
+TEST INFRASTRUCTURE: lets the CPU suite exercise the host logic (simulator mirror, gym env, vec
+env, sharding) without a GPU, and gives the GPU suite a like-for-like checker.  It lives under
+tests/ and is injected through ``propagator_factory``; the product never imports it.
+"""
+import numpy as np
+
+from basilisk_env_amd._lib import n_fields
+from oracle import oracle
+
+
+class OraclePropagator(object):
+    def __init__(self, cfg, n_envs, device=0, stream=None):
+        self.cfg = cfg.copy()
+        self.n_envs = int(n_envs)
+        self.n_rw = int(cfg.n_rw)
+        self.n_fields = n_fields(self.n_rw)
+        self.state = np.zeros((self.n_fields, self.n_envs))
+        self.steps = np.zeros(self.n_envs, np.int32)
+        self.ticks = np.zeros(self.n_envs, np.int32)
+        self._out = None
+
+    def close(self):
+        pass
+
+    def reset(self, ic, mask=None):
+        ic = np.asarray(ic, dtype=np.float64)
+        assert ic.shape == self.state.shape
+        if mask is None:
+            self.state[:] = ic
+            self.steps[:] = 0
+            self.ticks[:] = 0
+        else:
+            m = np.asarray(mask).astype(bool)
+            self.state[:, m] = ic[:, m]
+            self.steps[m] = 0
+            self.ticks[m] = 0
+
+    def get_state(self):
+        return self.state.copy()
+
+    def set_state(self, state):
+        self.state[:] = state
+
+    def get_counters(self):
+        return self.steps.copy(), self.ticks.copy()
+
+    def step(self, actions, substeps):
+        self._out = oracle.step(self.cfg, self.state, self.steps, self.ticks, np.asarray(actions, np.int32), substeps)
+
+    def get_obs(self):
+        return self._out
+
+    def batch_stats(self):
+        return float(self._out[1].sum()), int(self._out[2].sum())
+
+    def sync(self):
+        pass
