@@ -55,13 +55,14 @@ void sun_position(double jd, double out[3]) {
     out[2] = R * std::sin(eps) * std::sin(lam);
 }
 
-int build_devcfg(const bsk_config& c, bsk::DevCfg& d) {
-    std::memset(&d, 0, sizeof d);
-    d.dt = c.dt;
-    d.mu = c.mu;
-    d.req = c.req;
-    d.j2k = 1.5 * c.j2 * c.mu * c.req * c.req;
-    std::memcpy(d.inertia, c.inertia, sizeof d.inertia);
+int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool& diag) {
+    std::memset(&p, 0, sizeof p);
+    std::memset(&k, 0, sizeof k);
+    p.dt = c.dt;
+    p.mu = c.mu;
+    p.j2k = 1.5 * c.j2 * c.mu * c.req * c.req;
+    std::memcpy(p.inertia, c.inertia, sizeof p.inertia);
+    std::memcpy(k.inertia, c.inertia, sizeof k.inertia);
     double D[9];
     std::memcpy(D, c.inertia, sizeof D);
     for (int i = 0; i < c.n_rw; ++i) {
@@ -69,13 +70,18 @@ int build_devcfg(const bsk_config& c, bsk::DevCfg& d) {
         if (!(std::fabs(nrm - 1.0) < 1e-9)) return fail(BSK_EINVAL, "wheel spin axis is not a unit vector");
         if (!(c.js[i] > 0.0)) return fail(BSK_EINVAL, "wheel inertia js must be positive");
         for (int a = 0; a < 3; ++a) {
-            d.gs[i][a] = c.gs[i][a];
+            p.gs[i][a] = c.gs[i][a];
             for (int b = 0; b < 3; ++b) D[3 * a + b] -= c.js[i] * c.gs[i][a] * c.gs[i][b];
         }
-        d.js[i] = c.js[i];
-        d.inv_js[i] = 1.0 / c.js[i];
+        p.js[i] = c.js[i];
     }
-    if (!inv3(D, d.dinv)) return fail(BSK_EINVAL, "hub inertia minus wheel inertia is singular");
+    if (!inv3(D, p.dinv)) return fail(BSK_EINVAL, "hub inertia minus wheel inertia is singular");
+    // Diagonal fast path: only when every off-diagonal of I_sc and of (I_sc - sum Js g g^T) is
+    // EXACTLY zero (true for the reference's cuboid hub with the triad or the symmetric pyramid).
+    diag = true;
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b)
+            if (a != b && (c.inertia[3 * a + b] != 0.0 || D[3 * a + b] != 0.0)) diag = false;
     if (c.n_rw > 0) {
         // rwMotorTorque: map = CGs^T (CGs CGs^T)^-1 C,  CGs = C Gs
         double cgs[3][BSK_MAX_RW], M[9] = {0}, Mi[9];
@@ -91,22 +97,22 @@ int build_devcfg(const bsk_config& c, bsk::DevCfg& d) {
             double t[3];
             for (int a = 0; a < 3; ++a) t[a] = cgs[0][i] * Mi[a] + cgs[1][i] * Mi[3 + a] + cgs[2][i] * Mi[6 + a];
             for (int b = 0; b < 3; ++b)
-                d.map[i][b] = t[0] * c.ctrl_axes[b] + t[1] * c.ctrl_axes[3 + b] + t[2] * c.ctrl_axes[6 + b];
+                k.map[i][b] = t[0] * c.ctrl_axes[b] + t[1] * c.ctrl_axes[3 + b] + t[2] * c.ctrl_axes[6 + b];
         }
     }
-    d.u_max = c.u_max;
-    d.u_min = c.u_min;
-    d.f_coulomb = c.f_coulomb;
-    d.K = c.K;
-    d.P = c.P;
-    std::memcpy(d.sigma_R0N, c.sigma_R0N, sizeof d.sigma_R0N);
-    d.inv_wheel_limit = 1.0 / c.wheel_limit;
-    d.charge_scale = 1.0 / 3600.0 / c.power_max;
-    d.reward_mult = c.reward_mult;
-    d.failure_penalty = c.failure_penalty;
-    d.r_min2 = c.r_min * c.r_min;
-    d.fsw_every = c.fsw_every;
-    d.max_length = c.max_length;
+    p.f_coulomb = c.f_coulomb;
+    p.fsw_every = c.fsw_every;
+    k.u_max = c.u_max;
+    k.u_min = c.u_min;
+    k.K = c.K;
+    k.P = c.P;
+    std::memcpy(k.sigma_R0N, c.sigma_R0N, sizeof k.sigma_R0N);
+    k.inv_wheel_limit = 1.0 / c.wheel_limit;
+    k.charge_scale = 1.0 / 3600.0 / c.power_max;
+    k.reward_mult = c.reward_mult;
+    k.failure_penalty = c.failure_penalty;
+    k.r_min2 = c.r_min * c.r_min;
+    k.max_length = c.max_length;
     return BSK_OK;
 }
 
@@ -114,7 +120,10 @@ int build_devcfg(const bsk_config& c, bsk::DevCfg& d) {
 
 struct bsk_handle {
     bsk_config cfg;
-    bsk::DevCfg dc;
+    bsk::StepParams sp;
+    bsk::ColdCfg cold;
+    bool diag = false;
+    bsk::ColdCfg* d_cold = nullptr;
     int n = 0, nf = 0, device = 0, block = 64;
     int64_t stride = 0;
     hipStream_t stream = nullptr;
@@ -186,26 +195,26 @@ int ensure_stage(bsk_handle* h, size_t m) {
 }
 
 int do_step(bsk_handle* h, const int* d_actions, int substeps) {
-    bsk::StepArgs a;
-    a.c = h->dc;
-    a.st = h->d_state;
-    a.cnt = h->d_cnt;
-    a.act = d_actions;
-    a.obs = h->d_obs;
-    a.reward = h->d_reward;
-    a.done_mask = h->d_done_mask;
-    a.reason = h->d_reason;
-    a.wave_reward = h->d_wave_reward;
-    a.stride = h->stride;
-    a.n = h->n;
-    a.substeps = substeps;
-    const bool timed = h->prof && h->ev_used + 2 <= (int)h->ev.size();
-    if (timed) HIP_TRY(hipEventRecord(h->ev[h->ev_used], h->stream));
-    HIP_TRY(bsk::launch_step(h->cfg.gravity_model, h->cfg.n_rw, a, h->block, h->stream));
-    if (timed) {
-        HIP_TRY(hipEventRecord(h->ev[h->ev_used + 1], h->stream));
+    bsk::StepBuffers b;
+    b.cold = h->d_cold;
+    b.st = h->d_state;
+    b.cnt = h->d_cnt;
+    b.act = d_actions;
+    b.obs = h->d_obs;
+    b.reward = h->d_reward;
+    b.done_mask = h->d_done_mask;
+    b.reason = h->d_reason;
+    b.wave_reward = h->d_wave_reward;
+    b.stride = h->stride;
+    b.n = h->n;
+    b.substeps = substeps;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->prof && h->ev_used + 2 <= (int)h->ev.size()) {
+        e0 = h->ev[h->ev_used];
+        e1 = h->ev[h->ev_used + 1];
         h->ev_used += 2;
     }
+    HIP_TRY(bsk::launch_step(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp, b, h->block, h->stream, e0, e1));
     h->sim_time += substeps * h->cfg.dt;
     return BSK_OK;
 }
@@ -243,11 +252,17 @@ int bsk_default_config(bsk_config* c, int n_rw, int gravity_model) {
     if (n_rw == 3) {
         for (int i = 0; i < 3; ++i) c->gs[i][i] = 1.0;
     } else if (n_rw == 4) {
-        const double el = 40.0 * D2R, az[4] = {45.0 * D2R, 135.0 * D2R, 225.0 * D2R, 315.0 * D2R};
+        // one quadrant's components with explicit signs: exactly symmetric set (see
+        // actuatorPrimatives.balancedHR16Pyramid), so sum(g g^T) is exactly diagonal
+        const double el = 40.0 * D2R, az = 45.0 * D2R;
+        double cx = std::cos(az) * std::cos(el), cy = std::sin(az) * std::cos(el), cz = std::sin(el);
+        const double nn = std::sqrt(cx * cx + cy * cy + cz * cz);
+        cx /= nn; cy /= nn; cz /= nn;
+        const int sx[4] = {1, -1, -1, 1}, sy[4] = {1, 1, -1, -1};
         for (int i = 0; i < 4; ++i) {
-            c->gs[i][0] = std::cos(az[i]) * std::cos(el);
-            c->gs[i][1] = std::sin(az[i]) * std::cos(el);
-            c->gs[i][2] = std::sin(el);
+            c->gs[i][0] = sx[i] * cx;
+            c->gs[i][1] = sy[i] * cy;
+            c->gs[i][2] = cz;
         }
     }
     for (int i = 0; i < n_rw; ++i) c->js[i] = 50.0 / (6000.0 * M_PI * 2.0 / 60.0);
@@ -305,7 +320,7 @@ int bsk_create(const bsk_config* cfg, int n_envs, int device_id, void* stream, b
 
     bsk_handle* h = new bsk_handle();
     h->cfg = *cfg;
-    rc = build_devcfg(*cfg, h->dc);
+    rc = build_params(*cfg, h->sp, h->cold, h->diag);
     if (rc) { delete h; return rc; }
     h->n = n_envs;
     h->nf = BSK_NF_BASE + cfg->n_rw + BSK_NF_TAIL;
@@ -337,6 +352,8 @@ int bsk_create(const bsk_config* cfg, int n_envs, int device_id, void* stream, b
     if (e == hipSuccess) e = alloc((void**)&h->d_wave_reward, (size_t)(S / 64) * sizeof(double));
     if (e == hipSuccess) e = alloc((void**)&h->d_stat_sum, sizeof(double));
     if (e == hipSuccess) e = alloc((void**)&h->d_stat_done, sizeof(long long));
+    if (e == hipSuccess) e = alloc((void**)&h->d_cold, sizeof(bsk::ColdCfg));
+    if (e == hipSuccess) e = hipMemcpyAsync(h->d_cold, &h->cold, sizeof(bsk::ColdCfg), hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
         int code = fail(e == hipErrorOutOfMemory ? BSK_ENOMEM : BSK_EHIP, std::string("device allocation: ") + hipGetErrorString(e));
@@ -353,7 +370,7 @@ void bsk_destroy(bsk_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (hipEvent_t ev : h->ev) (void)hipEventDestroy(ev);
     void* bufs[] = {h->d_state, h->d_cnt, h->d_act, h->d_obs, h->d_reward, h->d_done_mask, h->d_reason,
-                    h->d_wave_reward, h->d_stat_sum, h->d_stat_done, h->d_ic_stage, h->d_idx_stage};
+                    h->d_wave_reward, h->d_stat_sum, h->d_stat_done, h->d_ic_stage, h->d_idx_stage, h->d_cold};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -536,12 +553,13 @@ int bsk_profile_end(bsk_handle* h, double* mean_kernel_ms, int* n_launches) {
 int bsk_kernel_info(bsk_handle* h, char* name, int name_cap, int* vgprs, int* lds_bytes, int* block, int* grid) {
     if (!h) return fail(BSK_EINVAL, "handle is NULL");
     DeviceGuard guard(h->device);
-    const void* fp = bsk::step_kernel_ptr(h->cfg.gravity_model, h->cfg.n_rw);
+    const void* fp = bsk::step_kernel_ptr(h->cfg.gravity_model, h->cfg.n_rw, h->diag);
     if (!fp) return fail(BSK_EINVAL, "no kernel variant for this config");
     hipFuncAttributes at;
     HIP_TRY(hipFuncGetAttributes(&at, fp));
     if (name && name_cap > 0)
-        std::snprintf(name, name_cap, "step_kernel<%s,%d>", h->cfg.gravity_model == BSK_GRAV_PM ? "PM" : "PM_J2", h->cfg.n_rw);
+        std::snprintf(name, name_cap, "step_kernel<%s,%d,%s>", h->cfg.gravity_model == BSK_GRAV_PM ? "PM" : "PM_J2", h->cfg.n_rw,
+                      h->diag ? "diag" : "full");
     if (vgprs) *vgprs = at.numRegs;
     if (lds_bytes) *lds_bytes = (int)at.sharedSizeBytes;
     if (block) *block = h->block;

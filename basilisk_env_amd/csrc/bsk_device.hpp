@@ -1,9 +1,14 @@
 // bsk_device.hpp — per-spacecraft fp64 physics for gfx950 (CDNA4), one spacecraft per lane.
 //
-// Everything a lane needs that is the same for every spacecraft (inertia, wheel geometry, gains,
-// gravity constants) travels in DevCfg, passed BY VALUE as a kernel argument: the compiler keeps
-// it in SGPRs (s_load from the kernarg segment), so the fp64 VALU stream carries no loads for it.
-// Per-spacecraft state lives in VGPRs as named scalars (no runtime-indexed arrays -> no scratch).
+// The step kernel is fp64-VALU-issue bound (measured: one wave per SIMD already reaches ~80 % of
+// the saturated issue rate), so this file is written for minimum VALU instruction count:
+//   * constants the RK4 loop needs (HotCfg) travel BY VALUE in the kernarg segment and stay in
+//     SGPRs; HotCfg is specialised on <NRW, DIAG> so it fits the 102-SGPR budget (an overflow
+//     turns into v_readlane/v_writelane spill traffic on the VALU, the bottleneck);
+//   * constants only the 1 Hz FSW chain / the observation need (ColdCfg) sit behind a pointer and
+//     are s_load-ed where used, so they hold no SGPRs across the loop;
+//   * 1/|r| is one v_rsq_f64 + one cubic Newton step (6 ops) instead of IEEE sqrt + IEEE divide;
+//   * cross products are folded into FMA chains; wheel friction is branch-free.
 //
 // What this replaces: the Basilisk modules wired by the reference scenario
 //   spacecraftPlus + RK4        basilisk_env/simulators/leoPowerAttitudeSimulator.py:213-259,356
@@ -28,7 +33,11 @@ __device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y -
 __device__ __forceinline__ V3 operator*(double s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
 __device__ __forceinline__ double dot(V3 a, V3 b) { return fma(a.x, b.x, fma(a.y, b.y, a.z * b.z)); }
 __device__ __forceinline__ V3 cross(V3 a, V3 b) {
-    return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+    return V3{fma(a.y, b.z, -(a.z * b.y)), fma(a.z, b.x, -(a.x * b.z)), fma(a.x, b.y, -(a.y * b.x))};
+}
+// c - a x b, folded into FMA chains (6 ops)
+__device__ __forceinline__ V3 sub_cross(V3 c, V3 a, V3 b) {
+    return V3{fma(-a.y, b.z, fma(a.z, b.y, c.x)), fma(-a.z, b.x, fma(a.x, b.z, c.y)), fma(-a.x, b.y, fma(a.y, b.x, c.z))};
 }
 // y = a*x + y
 __device__ __forceinline__ V3 axpy(double a, V3 x, V3 y) { return V3{fma(a, x.x, y.x), fma(a, x.y, y.y), fma(a, x.z, y.z)}; }
@@ -37,79 +46,109 @@ __device__ __forceinline__ V3 mv(const double* m, V3 v) {
               fma(m[6], v.x, fma(m[7], v.y, m[8] * v.z))};
 }
 
-// Uniform (per-handle) constants.  Built on the host in bsk_capi.hip from bsk_config.
-struct DevCfg {
-    double dt;
-    double mu, req, j2k;  // j2k = 1.5 * J2 * mu * req^2
+// 1/sqrt(x) for normal positive x: hardware estimate (v_rsq_f64, ~2^-23 relative) + one cubic
+// Newton step y (1 + e/2 + 3e^2/8), e = 1 - x y^2  ->  error ~e^3, i.e. rounding-limited (~1 ulp).
+__device__ __forceinline__ double rsqrt_nr(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double t = x * y;
+    double e = fma(-t, y, 1.0);
+    double p = fma(0.375, e, 0.5);
+    return fma(y * e, p, y);
+}
+
+// --------------------------------------------------------------------------------------------
+// Hot constants (SGPR-resident).  M3 = 3 (diagonal) or 9 (full, row-major) doubles per matrix.
+template <int NRW, bool DIAG>
+struct HotCfg {
+    double h, h2, h3, h6;  // dt, dt/2, dt/3, dt/6
+    double nmu, j2k;       // -mu,  1.5 * J2 * mu * req^2
+    double I[DIAG ? 3 : 9];
+    double Di[DIAG ? 3 : 9];  // (I_sc - sum Js g g^T)^-1
+    double g[NRW > 0 ? NRW : 1][3];
+    double js[NRW > 0 ? NRW : 1], ijs[NRW > 0 ? NRW : 1];
+    double fc;
+    int32_t fsw_every, pad_;
+};
+
+// Cold constants (device memory, loaded on demand by the FSW chain and the observation).
+struct ColdCfg {
     double inertia[9];
-    double dinv[9];  // (I_sc - sum Js g g^T)^-1
-    double gs[BSK_MAX_RW][3];
-    double js[BSK_MAX_RW], inv_js[BSK_MAX_RW];
     double map[BSK_MAX_RW][3];  // rwMotorTorque pseudo-inverse rows
-    double u_max, u_min, f_coulomb;
+    double u_max, u_min;
     double K, P;
     double sigma_R0N[3];
     double inv_wheel_limit, charge_scale, reward_mult, failure_penalty, r_min2;
-    int32_t fsw_every, max_length;
+    int32_t max_length, pad_;
 };
+
+template <bool DIAG>
+__device__ __forceinline__ V3 mv3(const double* m, V3 v) {
+    if constexpr (DIAG) return V3{m[0] * v.x, m[1] * v.y, m[2] * v.z};
+    else return mv(m, v);
+}
 
 template <int NRW>
 struct State {
-    V3 r, v, s, w;    // position, velocity, sigma_BN, omega_BN_B
+    V3 r, v, s, w;  // position, velocity, sigma_BN, omega_BN_B
     double Om[NRW > 0 ? NRW : 1];
 };
 
-// ---------------------------------------------------------------------------------------------
-// gravity: point mass (+ closed-form J2).  One rsqrt-shaped chain: r2 -> 1/r -> 1/r^2, 1/r^3.
-template <int GRAV>
-__device__ __forceinline__ V3 gravity(const DevCfg& c, V3 r) {
-    double r2 = dot(r, r);
-    double ir = 1.0 / sqrt(r2);
+// --------------------------------------------------------------------------------------------
+// gravity: point mass (+ closed-form J2): 15 / 22 fp64 ops.
+template <int GRAV, class Hot>
+__device__ __forceinline__ V3 gravity(const Hot& c, V3 r) {
+    double zz = r.z * r.z;
+    double r2 = fma(r.x, r.x, fma(r.y, r.y, zz));
+    double ir = rsqrt_nr(r2);
     double ir2 = ir * ir;
     double ir3 = ir * ir2;
-    double k0 = -c.mu * ir3;
+    double k0 = c.nmu * ir3;
     if constexpr (GRAV == BSK_GRAV_PM_J2) {
-        double z2 = r.z * r.z * ir2;          // (z/r)^2
-        double kj = c.j2k * ir3 * ir2;        // 1.5 J2 mu Re^2 / r^5
+        double z2 = zz * ir2;               // (z/r)^2
+        double kj = c.j2k * (ir3 * ir2);    // 1.5 J2 mu Re^2 / r^5
         double kxy = fma(kj, fma(5.0, z2, -1.0), k0);
-        double kz = fma(kj, fma(5.0, z2, -3.0), k0);
+        double kz = fma(-2.0, kj, kxy);     // k0 + kj (5 z2 - 3)
         return V3{kxy * r.x, kxy * r.y, kz * r.z};
     } else {
         return k0 * r;
     }
 }
 
-// ---------------------------------------------------------------------------------------------
+// --------------------------------------------------------------------------------------------
 // equations of motion.  u = held wheel motor torques, lext = external body torque.
-template <int GRAV, int NRW>
-__device__ __forceinline__ void eom(const DevCfg& c, const State<NRW>& x, const double* u, V3 lext, State<NRW>& d) {
+template <int GRAV, int NRW, bool DIAG>
+__device__ __forceinline__ void eom(const HotCfg<NRW, DIAG>& c, const State<NRW>& x, const double* u, V3 lext,
+                                    State<NRW>& d) {
     d.r = x.v;
     d.v = gravity<GRAV>(c, x.r);
-    // sigma' = 1/4 [(1 - s^2) w + 2 s x w + 2 (s.w) s]
-    double s2 = dot(x.s, x.s), sw = dot(x.s, x.w);
-    V3 sxw = cross(x.s, x.w);
-    double a = 0.25 * (1.0 - s2), b = 0.5 * sw;
-    d.s = V3{fma(a, x.w.x, fma(0.5, sxw.x, b * x.s.x)), fma(a, x.w.y, fma(0.5, sxw.y, b * x.s.y)),
-             fma(a, x.w.z, fma(0.5, sxw.z, b * x.s.z))};
-    // [I - sum Js g g^T] w' = -w x (I w + h_w) + L_ext - Gs (u + tau_f),  h_w = sum Js Om g
-    V3 H = mv(c.inertia, x.w);
+    // sigma' = 1/4 [(1 - s^2) w + 2 s x w + 2 (s.w) s],  with hw = w/2:
+    //        = (1 - s^2)/2 hw + s x hw + (s.hw) s
+    V3 hw = 0.5 * x.w;
+    double s2 = dot(x.s, x.s);
+    double b = dot(x.s, hw);
+    double a = fma(-0.5, s2, 0.5);
+    d.s = V3{fma(a, hw.x, fma(b, x.s.x, fma(x.s.y, hw.z, -(x.s.z * hw.y)))),
+             fma(a, hw.y, fma(b, x.s.y, fma(x.s.z, hw.x, -(x.s.x * hw.z)))),
+             fma(a, hw.z, fma(b, x.s.z, fma(x.s.x, hw.y, -(x.s.y * hw.x))))};
+    // [I - sum Js g g^T] w' = L_ext - Gs (u + tau_f) - w x (I w + sum Js Om g)
+    V3 H = mv3<DIAG>(c.I, x.w);
     V3 rhs = lext;
     double tq[NRW > 0 ? NRW : 1];
 #pragma unroll
     for (int i = 0; i < NRW; ++i) {
-        double fr = x.Om[i] > 0.0 ? -c.f_coulomb : (x.Om[i] < 0.0 ? c.f_coulomb : 0.0);
+        // Coulomb friction -fc sign(Om), 0 at rest; branch-free
+        double fr = __builtin_copysign(c.fc, -x.Om[i]);
+        fr = (x.Om[i] == 0.0) ? 0.0 : fr;
         tq[i] = u[i] + fr;
-        V3 g = mk(c.gs[i][0], c.gs[i][1], c.gs[i][2]);
+        V3 g = mk(c.g[i][0], c.g[i][1], c.g[i][2]);
         H = axpy(c.js[i] * x.Om[i], g, H);
         rhs = axpy(-tq[i], g, rhs);
     }
-    rhs = rhs - cross(x.w, H);
-    d.w = mv(c.dinv, rhs);
+    rhs = sub_cross(rhs, x.w, H);
+    d.w = mv3<DIAG>(c.Di, rhs);
 #pragma unroll
-    for (int i = 0; i < NRW; ++i) {
-        V3 g = mk(c.gs[i][0], c.gs[i][1], c.gs[i][2]);
-        d.Om[i] = fma(tq[i], c.inv_js[i], -dot(g, d.w));
-    }
+    for (int i = 0; i < NRW; ++i)
+        d.Om[i] = fma(-c.g[i][0], d.w.x, fma(-c.g[i][1], d.w.y, fma(-c.g[i][2], d.w.z, tq[i] * c.ijs[i])));
 }
 
 template <int NRW>
@@ -124,27 +163,26 @@ __device__ __forceinline__ void st_axpy(double a, const State<NRW>& k, const Sta
 
 // classic RK4, sequential accumulation x0 + h/6 k1 + h/3 k2 + h/3 k3 + h/6 k4, then the MRP
 // shadow-set switch once per completed step.
-template <int GRAV, int NRW>
-__device__ __forceinline__ void rk4_step(const DevCfg& c, State<NRW>& x, const double* u, V3 lext) {
-    const double h = c.dt, h2 = 0.5 * h, h6 = h / 6.0, h3 = h / 3.0;
+template <int GRAV, int NRW, bool DIAG>
+__device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, State<NRW>& x, const double* u, V3 lext) {
     State<NRW> k, xt, acc;
-    eom<GRAV, NRW>(c, x, u, lext, k);
-    st_axpy<NRW>(h6, k, x, acc);
-    st_axpy<NRW>(h2, k, x, xt);
-    eom<GRAV, NRW>(c, xt, u, lext, k);
-    st_axpy<NRW>(h3, k, acc, acc);
-    st_axpy<NRW>(h2, k, x, xt);
-    eom<GRAV, NRW>(c, xt, u, lext, k);
-    st_axpy<NRW>(h3, k, acc, acc);
-    st_axpy<NRW>(h, k, x, xt);
-    eom<GRAV, NRW>(c, xt, u, lext, k);
-    st_axpy<NRW>(h6, k, acc, x);
+    eom<GRAV, NRW, DIAG>(c, x, u, lext, k);
+    st_axpy<NRW>(c.h6, k, x, acc);
+    st_axpy<NRW>(c.h2, k, x, xt);
+    eom<GRAV, NRW, DIAG>(c, xt, u, lext, k);
+    st_axpy<NRW>(c.h3, k, acc, acc);
+    st_axpy<NRW>(c.h2, k, x, xt);
+    eom<GRAV, NRW, DIAG>(c, xt, u, lext, k);
+    st_axpy<NRW>(c.h3, k, acc, acc);
+    st_axpy<NRW>(c.h, k, x, xt);
+    eom<GRAV, NRW, DIAG>(c, xt, u, lext, k);
+    st_axpy<NRW>(c.h6, k, acc, x);
     double s2 = dot(x.s, x.s);
     if (s2 > 1.0) x.s = (-1.0 / s2) * x.s;
 }
 
-// ---------------------------------------------------------------------------------------------
-// attitude kinematics helpers
+// --------------------------------------------------------------------------------------------
+// attitude kinematics helpers (FSW chain / observation; run at 1/10 of the RK4 rate)
 __device__ __forceinline__ void mrp2c(V3 q, double* C) {
     double q2 = dot(q, q), op = 1.0 + q2, id = 1.0 / (op * op);
     double a = 8.0 * id, b = 4.0 * (1.0 - q2) * id;
@@ -172,16 +210,13 @@ __device__ __forceinline__ V3 c2mrp(const double* C) {
     if (b22 > mx) { mx = b22; i = 2; }
     if (b23 > mx) { mx = b23; i = 3; }
     double p = sqrt(mx), q4 = 0.25 / p;
-    double b0, b1, b2, b3;
-    if (i == 0) {
-        b0 = p; b1 = (C[5] - C[7]) * q4; b2 = (C[6] - C[2]) * q4; b3 = (C[1] - C[3]) * q4;
-    } else if (i == 1) {
-        b1 = p; b0 = (C[5] - C[7]) * q4; b2 = (C[1] + C[3]) * q4; b3 = (C[6] + C[2]) * q4;
-    } else if (i == 2) {
-        b2 = p; b0 = (C[6] - C[2]) * q4; b1 = (C[1] + C[3]) * q4; b3 = (C[5] + C[7]) * q4;
-    } else {
-        b3 = p; b0 = (C[1] - C[3]) * q4; b1 = (C[6] + C[2]) * q4; b2 = (C[5] + C[7]) * q4;
-    }
+    // numerators of the four Sheppard cases, selected without divergent control flow
+    double d0 = C[5] - C[7], d1 = C[6] - C[2], d2 = C[1] - C[3];
+    double s0 = C[1] + C[3], s1 = C[6] + C[2], s2 = C[5] + C[7];
+    double b0 = (i == 0) ? p : q4 * ((i == 1) ? d0 : (i == 2) ? d1 : d2);
+    double b1 = (i == 1) ? p : q4 * ((i == 0) ? d0 : (i == 2) ? s0 : s1);
+    double b2 = (i == 2) ? p : q4 * ((i == 0) ? d1 : (i == 1) ? s0 : s2);
+    double b3 = (i == 3) ? p : q4 * ((i == 0) ? d2 : (i == 1) ? s1 : s2);
     if (b0 < 0.0) { b0 = -b0; b1 = -b1; b2 = -b2; b3 = -b3; }
     double id = 1.0 / (1.0 + b0);
     return V3{b1 * id, b2 * id, b3 * id};
@@ -210,7 +245,7 @@ struct Guid {
 
 // hillPoint | inertial3D  ->  attTrackingError
 template <int NRW>
-__device__ __forceinline__ Guid guidance(const DevCfg& c, const State<NRW>& x, int action) {
+__device__ __forceinline__ Guid guidance(const ColdCfg* __restrict__ c, const State<NRW>& x, int action) {
     V3 sRN, wRN_N, dwRN_N;
     if (action == 0) {
         double ir = 1.0 / sqrt(dot(x.r, x.r));
@@ -224,7 +259,7 @@ __device__ __forceinline__ Guid guidance(const DevCfg& c, const State<NRW>& x, i
         wRN_N = dfdt * e_h;
         dwRN_N = ddfdt2 * e_h;
     } else {
-        sRN = mk(c.sigma_R0N[0], c.sigma_R0N[1], c.sigma_R0N[2]);
+        sRN = mk(c->sigma_R0N[0], c->sigma_R0N[1], c->sigma_R0N[2]);
         wRN_N = mk(0, 0, 0);
         dwRN_N = mk(0, 0, 0);
     }
@@ -240,17 +275,18 @@ __device__ __forceinline__ Guid guidance(const DevCfg& c, const State<NRW>& x, i
 
 // MRP_Feedback -> rwMotorTorque -> wheel saturation / dead-band
 template <int NRW>
-__device__ __forceinline__ void control(const DevCfg& c, const Guid& g, double* u) {
+__device__ __forceinline__ void control(const ColdCfg* __restrict__ c, const Guid& g, double* u) {
     V3 wBN = g.omega_BR_B + g.omega_RN_B;
-    V3 Lr = c.K * g.sigma_BR + c.P * g.omega_BR_B;
-    Lr = Lr - cross(g.omega_RN_B, mv(c.inertia, wBN));
-    Lr = Lr + mv(c.inertia, cross(wBN, g.omega_RN_B) - g.domega_RN_B);
+    V3 Lr = c->K * g.sigma_BR + c->P * g.omega_BR_B;
+    Lr = Lr - cross(g.omega_RN_B, mv(c->inertia, wBN));
+    Lr = Lr + mv(c->inertia, cross(wBN, g.omega_RN_B) - g.domega_RN_B);
     // module output is -Lr (torque on the body); wheels need u_s = -map * (-Lr) = map * Lr
+    const double u_max = c->u_max, u_min = c->u_min;
 #pragma unroll
     for (int i = 0; i < NRW; ++i) {
-        double us = fma(c.map[i][0], Lr.x, fma(c.map[i][1], Lr.y, c.map[i][2] * Lr.z));
-        if (c.u_max > 0.0) us = fmin(fmax(us, -c.u_max), c.u_max);
-        if (fabs(us) < c.u_min) us = 0.0;
+        double us = fma(c->map[i][0], Lr.x, fma(c->map[i][1], Lr.y, c->map[i][2] * Lr.z));
+        if (u_max > 0.0) us = fmin(fmax(us, -u_max), u_max);
+        if (fabs(us) < u_min) us = 0.0;
         u[i] = us;
     }
 }

@@ -21,9 +21,10 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-template <int GRAV, int NRW>
-__global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
-    const DevCfg& c = a.c;
+template <int GRAV, int NRW, bool DIAG>
+__global__ __launch_bounds__(256) void step_kernel(const StepArgs<NRW, DIAG> a) {
+    const HotCfg<NRW, DIAG>& c = a.hot;
+    const ColdCfg* __restrict__ cold = a.cold;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = gid < a.n;
     const int i = valid ? gid : a.n - 1;  // tail lanes shadow the last env; their stores are masked
@@ -58,36 +59,43 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
     }
     bool fsw_ran = false;
 
-    for (int j = 0; j < a.substeps; ++j) {
+    // Outer loop over FSW periods, inner loop of pure RK4 steps: the 1 Hz FSW chain (and the
+    // SGPRs its constants need) stays out of the inner loop, which holds only HotCfg.
+    const int fsw_every = c.fsw_every;
+    int j = 0;
+    while (j < a.substeps) {
+        int m = a.substeps - j;
         if constexpr (NRW > 0) {
             if (phase == 0) {
-                Guid g = guidance<NRW>(c, x, action);
-                control<NRW>(c, g, u);
+                Guid g = guidance<NRW>(cold, x, action);
+                control<NRW>(cold, g, u);
                 fsw_ran = true;
             }
-            phase = (phase + 1 == c.fsw_every) ? 0 : phase + 1;
+            m = min(m, fsw_every - phase);
+            phase = (phase + m == fsw_every) ? 0 : phase + m;
         }
-        rk4_step<GRAV, NRW>(c, x, u, lext);
+        j += m;
+        for (int t = 0; t < m; ++t) rk4_step<GRAV, NRW, DIAG>(c, x, u, lext);
     }
 
     // observation: [|sigma_BR|, |omega_BN|, |Omega|/limit, charge/3600/power_max, shadow]
-    const Guid g = guidance<NRW>(c, x, action);
+    const Guid g = guidance<NRW>(cold, x, action);
     const double o0 = sqrt(dot(g.sigma_BR, g.sigma_BR));
     const double o1 = sqrt(dot(x.w, x.w));
     double om2 = 0.0;
 #pragma unroll
     for (int k = 0; k < NRW; ++k) om2 = fma(x.Om[k], x.Om[k], om2);
-    const double o2 = sqrt(om2) * c.inv_wheel_limit;
-    const double o3 = charge * c.charge_scale;
+    const double o2 = sqrt(om2) * cold->inv_wheel_limit;
+    const double o3 = charge * cold->charge_scale;
     const double o4 = 1.0;
 
     // reward and termination
     int why = 0;
-    double rew = (action == 0) ? c.reward_mult / fma(o0, o0, 1.0) : 0.0;
-    if (cnt.x >= c.max_length) why |= BSK_DONE_LENGTH;
-    if (o2 > 1.0) { why |= BSK_DONE_WHEELS; rew -= c.failure_penalty; }
-    if (o3 == 0.0) { why |= BSK_DONE_BATTERY; rew -= c.failure_penalty; }
-    if (dot(x.r, x.r) < c.r_min2) why |= BSK_DONE_ORBIT;
+    double rew = (action == 0) ? cold->reward_mult / fma(o0, o0, 1.0) : 0.0;
+    if (cnt.x >= cold->max_length) why |= BSK_DONE_LENGTH;
+    if (o2 > 1.0) { why |= BSK_DONE_WHEELS; rew -= cold->failure_penalty; }
+    if (o3 == 0.0) { why |= BSK_DONE_BATTERY; rew -= cold->failure_penalty; }
+    if (dot(x.r, x.r) < cold->r_min2) why |= BSK_DONE_ORBIT;
 
     // wavefront reductions (every lane of the wave participates; tail lanes contribute nothing)
     const unsigned long long dmask = __ballot(valid && why != 0);
@@ -154,27 +162,58 @@ __global__ void scatter_reset_kernel(double* __restrict__ st, int64_t stride, in
     cnt[e] = make_int2(0, 0);
 }
 
-template <int GRAV, int NRW>
-static hipError_t launch_t(const StepArgs& a, int block, hipStream_t s) {
-    const int grid = (a.n + block - 1) / block;
-    hipLaunchKernelGGL((step_kernel<GRAV, NRW>), dim3(grid), dim3(block), 0, s, a);
+template <int GRAV, int NRW, bool DIAG>
+static void fill_hot(const StepParams& p, HotCfg<NRW, DIAG>& h) {
+    h.h = p.dt; h.h2 = 0.5 * p.dt; h.h3 = p.dt / 3.0; h.h6 = p.dt / 6.0;
+    h.nmu = -p.mu; h.j2k = p.j2k;
+    for (int i = 0; i < (DIAG ? 3 : 9); ++i) {
+        h.I[i] = DIAG ? p.inertia[4 * i] : p.inertia[i];
+        h.Di[i] = DIAG ? p.dinv[4 * i] : p.dinv[i];
+    }
+    for (int i = 0; i < NRW; ++i) {
+        for (int k = 0; k < 3; ++k) h.g[i][k] = p.gs[i][k];
+        h.js[i] = p.js[i];
+        h.ijs[i] = 1.0 / p.js[i];
+    }
+    h.fc = p.f_coulomb;
+    h.fsw_every = p.fsw_every;
+    h.pad_ = 0;
+}
+
+template <int GRAV, int NRW, bool DIAG>
+static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block, hipStream_t s, hipEvent_t ev0,
+                           hipEvent_t ev1) {
+    StepArgs<NRW, DIAG> a;
+    fill_hot<GRAV, NRW, DIAG>(p, a.hot);
+    a.cold = b.cold; a.st = b.st; a.cnt = b.cnt; a.act = b.act; a.obs = b.obs; a.reward = b.reward;
+    a.done_mask = b.done_mask; a.reason = b.reason; a.wave_reward = b.wave_reward;
+    a.stride = b.stride; a.n = b.n; a.substeps = b.substeps;
+    const int grid = (b.n + block - 1) / block;
+    // hipExtLaunchKernelGGL stamps ev0/ev1 from the dispatch packet itself (no marker packets), so
+    // their difference is the kernel's own duration, as rocprofv3 --kernel-trace reports it.
+    hipExtLaunchKernelGGL((step_kernel<GRAV, NRW, DIAG>), dim3(grid), dim3(block), 0, s, ev0, ev1, 0, a);
     return hipGetLastError();
 }
 
-hipError_t launch_step(int grav, int nrw, const StepArgs& a, int block, hipStream_t s) {
-#define CASE(G, R) \
-    if (grav == G && nrw == R) return launch_t<G, R>(a, block, s);
-    CASE(BSK_GRAV_PM, 0) CASE(BSK_GRAV_PM, 3) CASE(BSK_GRAV_PM, 4)
-    CASE(BSK_GRAV_PM_J2, 0) CASE(BSK_GRAV_PM_J2, 3) CASE(BSK_GRAV_PM_J2, 4)
+#define BSK_VARIANTS(X)                                                                                     \
+    X(BSK_GRAV_PM, 0, true) X(BSK_GRAV_PM, 3, true) X(BSK_GRAV_PM, 4, true)                                  \
+    X(BSK_GRAV_PM_J2, 0, true) X(BSK_GRAV_PM_J2, 3, true) X(BSK_GRAV_PM_J2, 4, true)                         \
+    X(BSK_GRAV_PM, 0, false) X(BSK_GRAV_PM, 3, false) X(BSK_GRAV_PM, 4, false)                               \
+    X(BSK_GRAV_PM_J2, 0, false) X(BSK_GRAV_PM_J2, 3, false) X(BSK_GRAV_PM_J2, 4, false)
+
+hipError_t launch_step(int grav, int nrw, bool diag, const StepParams& p, const StepBuffers& b, int block,
+                       hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+#define CASE(G, R, D) \
+    if (grav == G && nrw == R && diag == D) return launch_t<G, R, D>(p, b, block, s, ev0, ev1);
+    BSK_VARIANTS(CASE)
 #undef CASE
     return hipErrorInvalidValue;
 }
 
-const void* step_kernel_ptr(int grav, int nrw) {
-#define CASE(G, R) \
-    if (grav == G && nrw == R) return (const void*)&step_kernel<G, R>;
-    CASE(BSK_GRAV_PM, 0) CASE(BSK_GRAV_PM, 3) CASE(BSK_GRAV_PM, 4)
-    CASE(BSK_GRAV_PM_J2, 0) CASE(BSK_GRAV_PM_J2, 3) CASE(BSK_GRAV_PM_J2, 4)
+const void* step_kernel_ptr(int grav, int nrw, bool diag) {
+#define CASE(G, R, D) \
+    if (grav == G && nrw == R && diag == D) return (const void*)&step_kernel<G, R, D>;
+    BSK_VARIANTS(CASE)
 #undef CASE
     return nullptr;
 }

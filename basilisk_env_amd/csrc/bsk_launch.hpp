@@ -1,6 +1,7 @@
-// bsk_launch.hpp — kernel argument block and host-side launch entry points (internal).
+// bsk_launch.hpp — kernel argument blocks and host-side launch entry points (internal).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "bsk_device.hpp"
@@ -8,8 +9,10 @@
 namespace bsk {
 
 // Passed by value to step_kernel (kernarg segment -> SGPRs).
+template <int NRW, bool DIAG>
 struct StepArgs {
-    DevCfg c;
+    HotCfg<NRW, DIAG> hot;
+    const ColdCfg* cold;           // device memory
     double* st;                    // state slab [n_fields][stride]
     int2* cnt;                     // per env {env steps, RK4 ticks} since reset
     const int* act;                // actions, device
@@ -23,8 +26,33 @@ struct StepArgs {
     int substeps;
 };
 
-hipError_t launch_step(int grav, int nrw, const StepArgs& a, int block, hipStream_t s);
-const void* step_kernel_ptr(int grav, int nrw);
+// Host-side, variant-independent description of the hot constants (built once per handle).
+struct StepParams {
+    double dt, mu, j2k;
+    double inertia[9], dinv[9];
+    double gs[BSK_MAX_RW][3], js[BSK_MAX_RW];
+    double f_coulomb;
+    int32_t fsw_every;
+};
+
+struct StepBuffers {
+    const ColdCfg* cold;
+    double* st;
+    int2* cnt;
+    const int* act;
+    double* obs;
+    double* reward;
+    unsigned long long* done_mask;
+    unsigned char* reason;
+    double* wave_reward;
+    int64_t stride;
+    int n;
+    int substeps;
+};
+
+hipError_t launch_step(int grav, int nrw, bool diag, const StepParams& p, const StepBuffers& b, int block,
+                       hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+const void* step_kernel_ptr(int grav, int nrw, bool diag);
 hipError_t launch_stats(const double* wave_reward, const unsigned long long* done_mask, int n_waves, double* out_sum,
                         long long* out_done, hipStream_t s);
 hipError_t launch_scatter_reset(double* st, int64_t stride, int nf, const double* ic, const int* idx, int m, int2* cnt,

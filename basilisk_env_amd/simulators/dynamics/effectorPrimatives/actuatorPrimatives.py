@@ -30,7 +30,6 @@ Wheel = namedtuple("Wheel", "gsHat_B Js Omega u_max u_min fCoulomb")
 
 def _wheel(gs, omega_rpm):
     gs = np.asarray(gs, dtype=float)
-    gs = gs / np.linalg.norm(gs)
     p = HONEYWELL_HR16
     return Wheel(gs, p["maxMomentum"] / p["Omega_max"], omega_rpm * RPM, p["u_max"], p["u_min"], p["fCoulomb"])
 
@@ -46,10 +45,16 @@ def balancedHR16Triad(useRandom=False, randomBounds=(-400, 400)):
 
 
 def balancedHR16Pyramid(wheelSpeedsRPM=(0.0, 0.0, 0.0, 0.0)):
-    """Four-wheel pyramid, gsHat = M3(-az) M2(el) [1,0,0] (reference BSK_OpNavDynamics.py:278-291)."""
-    el = 40.0 * math.pi / 180.0
-    out = []
-    for az_deg, s in zip((45.0, 135.0, 225.0, 315.0), wheelSpeedsRPM):
-        az = az_deg * math.pi / 180.0
-        out.append(_wheel([math.cos(az) * math.cos(el), math.sin(az) * math.cos(el), math.sin(el)], s))
-    return out
+    """Four-wheel pyramid, gsHat = M3(-az) M2(el) [1,0,0] = [cos az cos el, sin az cos el, sin el]
+    with el = 40 deg, az = 45/135/225/315 deg (reference BSK_OpNavDynamics.py:278-291).
+
+    The four axes are built from ONE quadrant's components with explicit signs, so the set is
+    exactly symmetric in floating point and sum(g g^T) is exactly diagonal (this is what lets the
+    propagator pick its diagonal-inertia kernel); each component equals the per-angle cos/sin
+    value to 1 ulp."""
+    el, az = 40.0 * math.pi / 180.0, 45.0 * math.pi / 180.0
+    cx, cy, cz = math.cos(az) * math.cos(el), math.sin(az) * math.cos(el), math.sin(el)
+    n = math.sqrt(cx * cx + cy * cy + cz * cz)
+    cx, cy, cz = cx / n, cy / n, cz / n
+    signs = ((1, 1), (-1, 1), (-1, -1), (1, -1))
+    return [_wheel([sx * cx, sy * cy, cz], s) for (sx, sy), s in zip(signs, wheelSpeedsRPM)]

@@ -71,7 +71,7 @@ def cpu_baseline(cfg, n_rw, substeps):
     from basilisk_env_amd.simulators.initial_conditions.batch import sample_ic_batch
     from oracle import oracle
 
-    cores = os.cpu_count() or 1
+    cores = oracle.set_threads(oracle.usable_cpus())
     n = 8192
     st = sample_ic_batch(n, n_rw, seed=0)
     steps_c, ticks_c = np.zeros(n, np.int32), np.zeros(n, np.int32)

@@ -509,6 +509,15 @@ int orc_step(const bsk_config* c, int n, double* state, int32_t* steps, int32_t*
     return 0;
 }
 
+#ifdef ORC_OMP
+#include <omp.h>
+void orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int orc_get_threads(void) { return omp_get_max_threads(); }
+#else
+void orc_set_threads(int n) { (void)n; }
+int orc_get_threads(void) { return 1; }
+#endif
+
 /* Single-function probes used by the known-answer tests. */
 int orc_gravity(const bsk_config* c, const double* cbar, const double* sbar, const double r[3], double t, double a[3]) {
     orc_ctx ctx;

@@ -42,6 +42,25 @@ def load(omp=False):
     return lib
 
 
+def usable_cpus():
+    """CPUs this process may actually use: min(affinity, cgroup quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def set_threads(n):
+    lib = load(omp=True)
+    lib.orc_set_threads(int(n))
+    return lib.orc_get_threads()
+
+
 def _p(a):
     return a.ctypes.data if a is not None else None
 

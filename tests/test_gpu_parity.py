@@ -201,7 +201,7 @@ def test_full_size_invariants_65536():
         I = np.array(cfg.inertia).reshape(3, 3)
         gs = np.array([list(g) for g in cfg.gs])[:n_rw]
         js = np.array(cfg.js)[:n_rw]
-        HB = I @ w + gs.T @ (js[:, None] * (Om + gs @ w))
+        HB = I @ w + gs.T @ (js[:, None] * Om)  # I_sc already holds the wheels' inertia (balanced model)
         # BN from MRP
         s2 = (sg * sg).sum(0)
         HN = np.empty_like(HB)
