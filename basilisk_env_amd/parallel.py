@@ -53,9 +53,10 @@ def gather_observations(prop, dist, dst=None, group=None):
     dist.all_gather_object(sizes, n_local, group=group)
     if len(set(sizes)) == 1:
         if dst is None:
-            out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+            # concatenation along dim 0 is the layout both RCCL and gloo accept; view as (world, 5, n)
+            out = torch.empty((world * local.shape[0], n_local), dtype=local.dtype, device=local.device)
             dist.all_gather_into_tensor(out, local, group=group)
-            return out
+            return out.view(world, local.shape[0], n_local)
         bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
         dist.gather(local, bufs, dst=dst, group=group)
         return torch.stack(bufs) if rank == dst else None

@@ -1,0 +1,71 @@
+"""CPU: initial-condition samplers.  ``random_tumble`` is pinned bit-for-bit by a fixture produced
+with the reference's own sc_attitudes.py (tests/golden/make_ic_fixture.py); the orbit sampler and
+``set_ICs`` are checked for the reference's distributions and legacy-RNG draw order."""
+import json
+import os
+
+import numpy as np
+
+from basilisk_env_amd.simulators.initial_conditions import leo_orbit, sc_attitudes
+from basilisk_env_amd.simulators.initial_conditions.batch import sample_ic_batch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_random_tumble_matches_reference_fixture():
+    with open(os.path.join(HERE, "golden", "ic_random_tumble.json")) as f:
+        fx = json.load(f)
+    for c in fx["random_tumble"]:
+        np.random.seed(c["seed"])
+        s, w = sc_attitudes.random_tumble(maxSpinRate=c["maxSpinRate"])
+        s2, w2 = sc_attitudes.random_tumble(maxSpinRate=c["maxSpinRate"])
+        assert s.tolist() == c["sigma"] and w.tolist() == c["omega"]
+        assert s2.tolist() == c["sigma_2"] and w2.tolist() == c["omega_2"]
+    s, w = sc_attitudes.static_inertial()
+    assert s.tolist() == fx["static_inertial"]["sigma"] and w.tolist() == fx["static_inertial"]["omega"]
+
+
+def test_sampled_400km_distribution_and_draw_order():
+    np.random.seed(3)
+    oe, rN, vN = leo_orbit.sampled_400km()
+    # same five size-1 draws, in the reference's order (leo_orbit.py:33-37)
+    np.random.seed(3)
+    e = np.random.uniform(0, 0.05, 1)
+    i = np.random.uniform(-np.pi / 2, np.pi / 2, 1)
+    Om, om, f = (np.random.uniform(0, 2 * np.pi, 1) for _ in range(3))
+    assert oe.a == 6371e3 + 500e3
+    assert oe.e[0] == e[0] and oe.i[0] == i[0] and oe.Omega[0] == Om[0] and oe.omega[0] == om[0] and oe.f[0] == f[0]
+    assert rN.shape == (3,) and vN.shape == (3,)
+    # vis-viva and the radius equation
+    r, v = np.linalg.norm(rN), np.linalg.norm(vN)
+    assert abs(v * v - leo_orbit.MU_EARTH * (2 / r - 1 / oe.a)) / (v * v) < 1e-13
+    assert abs(r - oe.a * (1 - e[0] ** 2) / (1 + e[0] * np.cos(f[0]))) / r < 1e-13
+
+
+def test_elem2rv_known_values():
+    oe = leo_orbit.ClassicElements()
+    oe.a, oe.e, oe.i, oe.Omega, oe.omega, oe.f = 7000e3, 0.0, 0.0, 0.0, 0.0, 0.0
+    r, v = leo_orbit.elem2rv(leo_orbit.MU_EARTH, oe)
+    assert np.allclose(r, [7000e3, 0, 0], atol=1e-6) and np.allclose(v, [0, np.sqrt(leo_orbit.MU_EARTH / 7000e3), 0], atol=1e-9)
+    oe, r, v = leo_orbit.inclined_circular_300km()
+    assert np.allclose(r, [6671e3, 0, 0], atol=1e-6)
+    assert abs(v[2] / v[1] - 1.0) < 1e-12          # 45 deg inclination
+
+
+def test_batch_sampler_ranges_and_reproducibility():
+    n, n_rw = 4096, 4
+    a = sample_ic_batch(n, n_rw, seed=0)
+    b = sample_ic_batch(n, n_rw, seed=0)
+    c = sample_ic_batch(n, n_rw, seed=1)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    assert a.shape == (12 + n_rw + 8, n)
+    r = np.linalg.norm(a[0:3], axis=0)
+    assert r.min() > 6871e3 * 0.95 - 1 and r.max() < 6871e3 * 1.05 + 1
+    assert a[6:9].min() >= 0 and a[6:9].max() < 1
+    assert np.abs(a[9:12]).max() <= 1e-5
+    rpm = a[12:16] / (2 * np.pi / 60)
+    assert np.abs(rpm).max() <= 800 and np.abs(rpm).max() > 700
+    t = 12 + n_rw
+    assert 1.5e-4 < a[t:t + 3].std() < 2.5e-4
+    assert (a[t + 3:t + 7] == 0).all()
+    assert a[t + 7].min() >= 8 * 3600 and a[t + 7].max() <= 20 * 3600
