@@ -76,6 +76,27 @@ def lib_path():
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbskgpu.so")
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own ``libamdhip64.so``
+    (SONAME libamdhip64.so.7, the SONAME libbskgpu.so asks for).  If libbskgpu.so were loaded
+    first it would bind /opt/rocm's copy and a later ``import torch`` would bring a second runtime
+    into the process: torch then sees no GPU and device pointers cannot be shared with RCCL.
+    Preloading torch's copy (without importing torch) makes every import order end with one
+    runtime; without torch installed the system ROCm runtime is used."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return None
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            return cand
+    except Exception:
+        return None
+    return None
+
+
 def load():
     """Load libbskgpu.so (built in-tree by ``__graft_entry__.build()`` / csrc/Makefile)."""
     global _LIB
@@ -86,6 +107,7 @@ def load():
         raise BskGpuUnavailable(
             "%s is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` (or `make -C "
             "basilisk_env_amd/csrc`). There is no CPU fallback for the propagator." % path)
+    _share_hip_runtime_with_torch()
     try:
         lib = C.CDLL(path)
     except OSError as e:  # pragma: no cover - depends on the host
