@@ -73,7 +73,8 @@ _LIB = None
 
 
 def lib_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbskgpu.so")
+    """In-tree library; ``BSKGPU_LIB`` overrides it (kernel A/B experiments only)."""
+    return os.environ.get("BSKGPU_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbskgpu.so")
 
 
 def _share_hip_runtime_with_torch():

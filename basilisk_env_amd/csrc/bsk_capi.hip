@@ -106,13 +106,15 @@ int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool&
     k.u_min = c.u_min;
     k.K = c.K;
     k.P = c.P;
+    std::memcpy(p.obs.sigma_R0N, c.sigma_R0N, sizeof p.obs.sigma_R0N);
     std::memcpy(k.sigma_R0N, c.sigma_R0N, sizeof k.sigma_R0N);
-    k.inv_wheel_limit = 1.0 / c.wheel_limit;
-    k.charge_scale = 1.0 / 3600.0 / c.power_max;
-    k.reward_mult = c.reward_mult;
-    k.failure_penalty = c.failure_penalty;
-    k.r_min2 = c.r_min * c.r_min;
-    k.max_length = c.max_length;
+    p.obs.inv_wheel_limit = 1.0 / c.wheel_limit;
+    p.obs.charge_scale = 1.0 / 3600.0 / c.power_max;
+    p.obs.reward_mult = c.reward_mult;
+    p.obs.failure_penalty = c.failure_penalty;
+    p.obs.r_min2 = c.r_min * c.r_min;
+    p.obs.max_length = c.max_length;
+    p.obs.pad_ = 0;
     return BSK_OK;
 }
 
@@ -168,7 +170,8 @@ int validate(const bsk_config& c) {
         return fail(BSK_EABI, "bsk_config abi_version/struct_size mismatch (header " + std::to_string(BSK_ABI_VERSION) +
                                   "/" + std::to_string(sizeof(bsk_config)) + ")");
     if (!(c.dt > 0.0)) return fail(BSK_EINVAL, "dt must be positive");
-    if (c.fsw_every < 1) return fail(BSK_EINVAL, "fsw_every must be >= 1");
+    if (c.fsw_every < 1 || c.fsw_every > 2047) return fail(BSK_EINVAL, "fsw_every must be in 1..2047");
+    if (c.max_length < 0 || c.max_length > 1000000) return fail(BSK_EINVAL, "max_length must be in 0..1000000");
     if (c.n_rw != 0 && c.n_rw != 3 && c.n_rw != 4) return fail(BSK_EINVAL, "n_rw must be 0, 3 or 4");
     if (c.gravity_model != BSK_GRAV_PM && c.gravity_model != BSK_GRAV_PM_J2 && c.gravity_model != BSK_GRAV_SH)
         return fail(BSK_EINVAL, "unknown gravity_model");
@@ -495,7 +498,7 @@ int bsk_get_counters(bsk_handle* h, int32_t* steps, int32_t* ticks) {
     HIP_TRY(hipMemcpyAsync(tmp.data(), h->d_cnt, (size_t)h->n * sizeof(int2), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     for (int i = 0; i < h->n; ++i) {
-        if (steps) steps[i] = tmp[i].x;
+        if (steps) steps[i] = tmp[i].x & 0xFFFFF;  // high bits carry the FSW phase
         if (ticks) ticks[i] = tmp[i].y;
     }
     return BSK_OK;

@@ -70,15 +70,44 @@ struct HotCfg {
     int32_t fsw_every, pad_;
 };
 
-// Cold constants (device memory, loaded on demand by the FSW chain and the observation).
+// Cold constants of the 1 Hz control law (device memory, s_load-ed inside the FSW block only).
 struct ColdCfg {
     double inertia[9];
     double map[BSK_MAX_RW][3];  // rwMotorTorque pseudo-inverse rows
     double u_max, u_min;
     double K, P;
     double sigma_R0N[3];
+};
+
+// Guidance / observation / reward constants: by value in the kernarg (used once per launch, outside
+// the RK4 loop, so they may be parked in VGPR lanes across it at no cost to the loop).
+struct ObsCfg {
+    double sigma_R0N[3];
     double inv_wheel_limit, charge_scale, reward_mult, failure_penalty, r_min2;
     int32_t max_length, pad_;
+};
+
+// Wheel geometry lives in VGPRs (same value in every lane): g, js, 1/js are 20 doubles for four
+// wheels, and together with the rest of HotCfg they overflow the SGPR file; a VGPR operand costs
+// a VALU instruction nothing, an SGPR spill costs a v_readlane per use.
+__device__ __forceinline__ double to_vgpr(double x) {
+#ifndef BSK_WHEEL_SGPR
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+}
+template <int NRW>
+struct WheelV {
+    double g[NRW > 0 ? NRW : 1][3];
+    double js[NRW > 0 ? NRW : 1], ijs[NRW > 0 ? NRW : 1];
+    template <class Hot>
+    __device__ __forceinline__ void load(const Hot& c) {
+#pragma unroll
+        for (int i = 0; i < NRW; ++i) {
+            g[i][0] = to_vgpr(c.g[i][0]); g[i][1] = to_vgpr(c.g[i][1]); g[i][2] = to_vgpr(c.g[i][2]);
+            js[i] = to_vgpr(c.js[i]); ijs[i] = to_vgpr(c.ijs[i]);
+        }
+    }
 };
 
 template <bool DIAG>
@@ -115,10 +144,14 @@ __device__ __forceinline__ V3 gravity(const Hot& c, V3 r) {
 }
 
 // --------------------------------------------------------------------------------------------
-// equations of motion.  u = held wheel motor torques, lext = external body torque.
+// equations of motion.
+//   [I - sum Js g g^T] w' = L_ext - Gs (u + tau_f) - w x (I w + sum Js Om g)
+//   Om_i' = (u_i + tau_f,i)/Js_i - g_i . w'
+// The wheel torque tq_i = u_i + tau_f,i depends on the state only through sign(Om_i) (Coulomb
+// friction), so the caller passes rhs0 = L_ext - sum tq_i g_i and tqj_i = tq_i / Js_i.
 template <int GRAV, int NRW, bool DIAG>
-__device__ __forceinline__ void eom(const HotCfg<NRW, DIAG>& c, const State<NRW>& x, const double* u, V3 lext,
-                                    State<NRW>& d) {
+__device__ __forceinline__ void eom(const HotCfg<NRW, DIAG>& c, const WheelV<NRW>& wv, const State<NRW>& x, V3 rhs0,
+                                    const double* tqj, State<NRW>& d) {
     d.r = x.v;
     d.v = gravity<GRAV>(c, x.r);
     // sigma' = 1/4 [(1 - s^2) w + 2 s x w + 2 (s.w) s],  with hw = w/2:
@@ -130,25 +163,31 @@ __device__ __forceinline__ void eom(const HotCfg<NRW, DIAG>& c, const State<NRW>
     d.s = V3{fma(a, hw.x, fma(b, x.s.x, fma(x.s.y, hw.z, -(x.s.z * hw.y)))),
              fma(a, hw.y, fma(b, x.s.y, fma(x.s.z, hw.x, -(x.s.x * hw.z)))),
              fma(a, hw.z, fma(b, x.s.z, fma(x.s.x, hw.y, -(x.s.y * hw.x))))};
-    // [I - sum Js g g^T] w' = L_ext - Gs (u + tau_f) - w x (I w + sum Js Om g)
     V3 H = mv3<DIAG>(c.I, x.w);
-    V3 rhs = lext;
-    double tq[NRW > 0 ? NRW : 1];
 #pragma unroll
-    for (int i = 0; i < NRW; ++i) {
-        // Coulomb friction -fc sign(Om), 0 at rest; branch-free
-        double fr = __builtin_copysign(c.fc, -x.Om[i]);
-        fr = (x.Om[i] == 0.0) ? 0.0 : fr;
-        tq[i] = u[i] + fr;
-        V3 g = mk(c.g[i][0], c.g[i][1], c.g[i][2]);
-        H = axpy(c.js[i] * x.Om[i], g, H);
-        rhs = axpy(-tq[i], g, rhs);
-    }
-    rhs = sub_cross(rhs, x.w, H);
+    for (int i = 0; i < NRW; ++i) H = axpy(wv.js[i] * x.Om[i], mk(wv.g[i][0], wv.g[i][1], wv.g[i][2]), H);
+    V3 rhs = sub_cross(rhs0, x.w, H);
     d.w = mv3<DIAG>(c.Di, rhs);
 #pragma unroll
     for (int i = 0; i < NRW; ++i)
-        d.Om[i] = fma(-c.g[i][0], d.w.x, fma(-c.g[i][1], d.w.y, fma(-c.g[i][2], d.w.z, tq[i] * c.ijs[i])));
+        d.Om[i] = fma(-wv.g[i][0], d.w.x, fma(-wv.g[i][1], d.w.y, fma(-wv.g[i][2], d.w.z, tqj[i])));
+}
+
+// wheel torque terms for the sign pattern of Om: rhs0 = L_ext - sum tq_i g_i, tqj_i = tq_i / Js_i
+template <int NRW, bool DIAG>
+__device__ __forceinline__ V3 wheel_torque(const HotCfg<NRW, DIAG>& c, const WheelV<NRW>& wv, const double* Om,
+                                           const double* u, V3 lext, double* tqj) {
+    V3 rhs0 = lext;
+#pragma unroll
+    for (int i = 0; i < NRW; ++i) {
+        // Coulomb friction -fc sign(Om), 0 at rest; branch-free
+        double fr = __builtin_copysign(c.fc, -Om[i]);
+        fr = (Om[i] == 0.0) ? 0.0 : fr;
+        double tq = u[i] + fr;
+        rhs0 = axpy(-tq, mk(wv.g[i][0], wv.g[i][1], wv.g[i][2]), rhs0);
+        tqj[i] = tq * wv.ijs[i];
+    }
+    return rhs0;
 }
 
 template <int NRW>
@@ -162,20 +201,25 @@ __device__ __forceinline__ void st_axpy(double a, const State<NRW>& k, const Sta
 }
 
 // classic RK4, sequential accumulation x0 + h/6 k1 + h/3 k2 + h/3 k3 + h/6 k4, then the MRP
-// shadow-set switch once per completed step.
+// shadow-set switch once per completed step.  Motor torque and Coulomb friction are evaluated
+// from the wheel speeds at the start of the step and held through its four stages (the RW
+// effector updates both once per dyn tick, outside the equations of motion).
 template <int GRAV, int NRW, bool DIAG>
-__device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, State<NRW>& x, const double* u, V3 lext) {
+__device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, const WheelV<NRW>& wv, State<NRW>& x,
+                                         const double* u, V3 lext) {
     State<NRW> k, xt, acc;
-    eom<GRAV, NRW, DIAG>(c, x, u, lext, k);
+    double tqj[NRW > 0 ? NRW : 1];
+    const V3 rhs0 = wheel_torque<NRW, DIAG>(c, wv, x.Om, u, lext, tqj);
+    eom<GRAV, NRW, DIAG>(c, wv, x, rhs0, tqj, k);
     st_axpy<NRW>(c.h6, k, x, acc);
     st_axpy<NRW>(c.h2, k, x, xt);
-    eom<GRAV, NRW, DIAG>(c, xt, u, lext, k);
+    eom<GRAV, NRW, DIAG>(c, wv, xt, rhs0, tqj, k);
     st_axpy<NRW>(c.h3, k, acc, acc);
     st_axpy<NRW>(c.h2, k, x, xt);
-    eom<GRAV, NRW, DIAG>(c, xt, u, lext, k);
+    eom<GRAV, NRW, DIAG>(c, wv, xt, rhs0, tqj, k);
     st_axpy<NRW>(c.h3, k, acc, acc);
     st_axpy<NRW>(c.h, k, x, xt);
-    eom<GRAV, NRW, DIAG>(c, xt, u, lext, k);
+    eom<GRAV, NRW, DIAG>(c, wv, xt, rhs0, tqj, k);
     st_axpy<NRW>(c.h6, k, acc, x);
     double s2 = dot(x.s, x.s);
     if (s2 > 1.0) x.s = (-1.0 / s2) * x.s;
@@ -245,7 +289,7 @@ struct Guid {
 
 // hillPoint | inertial3D  ->  attTrackingError
 template <int NRW>
-__device__ __forceinline__ Guid guidance(const ColdCfg* __restrict__ c, const State<NRW>& x, int action) {
+__device__ __forceinline__ Guid guidance(const double* __restrict__ sigma_R0N, const State<NRW>& x, int action) {
     V3 sRN, wRN_N, dwRN_N;
     if (action == 0) {
         double ir = 1.0 / sqrt(dot(x.r, x.r));
@@ -259,7 +303,7 @@ __device__ __forceinline__ Guid guidance(const ColdCfg* __restrict__ c, const St
         wRN_N = dfdt * e_h;
         dwRN_N = ddfdt2 * e_h;
     } else {
-        sRN = mk(c->sigma_R0N[0], c->sigma_R0N[1], c->sigma_R0N[2]);
+        sRN = mk(sigma_R0N[0], sigma_R0N[1], sigma_R0N[2]);
         wRN_N = mk(0, 0, 0);
         dwRN_N = mk(0, 0, 0);
     }

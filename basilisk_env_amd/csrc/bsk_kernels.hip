@@ -13,6 +13,9 @@
 #include "bsk_device.hpp"
 #include "bsk_launch.hpp"
 
+#include <cstddef>
+#define __COMMA__ ,
+
 namespace bsk {
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -29,8 +32,9 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs<NRW, DIAG> a) 
     const bool valid = gid < a.n;
     const int i = valid ? gid : a.n - 1;  // tail lanes shadow the last env; their stores are masked
     const int64_t S = a.stride;
-    double* __restrict__ st = a.st;
+    const double* __restrict__ st = a.st;
 
+    // every load of the launch is issued here, before any use
     State<NRW> x;
     x.r = mk(st[(BSK_F_R + 0) * S + i], st[(BSK_F_R + 1) * S + i], st[(BSK_F_R + 2) * S + i]);
     x.v = mk(st[(BSK_F_V + 0) * S + i], st[(BSK_F_V + 1) * S + i], st[(BSK_F_V + 2) * S + i]);
@@ -42,32 +46,30 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs<NRW, DIAG> a) 
     const V3 lext = mk(st[(TAIL + BSK_T_LEXT + 0) * S + i], st[(TAIL + BSK_T_LEXT + 1) * S + i],
                        st[(TAIL + BSK_T_LEXT + 2) * S + i]);
     const double charge = st[(TAIL + BSK_T_CHARGE) * S + i];
-    const int2 cnt = a.cnt[i];
+    const int2 cnt = a.cnt[i];   // {env steps | FSW phase << 20, RK4 ticks}
     const int action = a.act[i];
-
-    int phase = cnt.y % c.fsw_every;
     double u[NRW > 0 ? NRW : 1];
-    if constexpr (NRW > 0) {
-        // the held motor torque only matters when this launch starts between two FSW ticks
-        if (phase != 0) {
+    // the held motor torque only matters when this launch starts between two FSW ticks; it is
+    // loaded unconditionally so that all loads are in flight at once
 #pragma unroll
-            for (int k = 0; k < NRW; ++k) u[k] = st[(TAIL + BSK_T_UCMD + k) * S + i];
-        } else {
-#pragma unroll
-            for (int k = 0; k < NRW; ++k) u[k] = 0.0;
-        }
-    }
+    for (int k = 0; k < NRW; ++k) u[k] = st[(TAIL + BSK_T_UCMD + k) * S + i];
+
+    const int steps0 = cnt.x & 0xFFFFF;
+    int phase = cnt.x >> 20;
     bool fsw_ran = false;
 
     // Outer loop over FSW periods, inner loop of pure RK4 steps: the 1 Hz FSW chain (and the
     // SGPRs its constants need) stays out of the inner loop, which holds only HotCfg.
     const int fsw_every = c.fsw_every;
+    const int substeps = a.substeps;
+    WheelV<NRW> wv;
+    wv.load(c);
     int j = 0;
-    while (j < a.substeps) {
-        int m = a.substeps - j;
+    while (j < substeps) {
+        int m = substeps - j;
         if constexpr (NRW > 0) {
             if (phase == 0) {
-                Guid g = guidance<NRW>(cold, x, action);
+                Guid g = guidance<NRW>(cold->sigma_R0N, x, action);
                 control<NRW>(cold, g, u);
                 fsw_ran = true;
             }
@@ -75,53 +77,66 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs<NRW, DIAG> a) 
             phase = (phase + m == fsw_every) ? 0 : phase + m;
         }
         j += m;
-        for (int t = 0; t < m; ++t) rk4_step<GRAV, NRW, DIAG>(c, x, u, lext);
+        for (int t = 0; t < m; ++t) rk4_step<GRAV, NRW, DIAG>(c, wv, x, u, lext);
     }
 
+    // Re-read the post-loop arguments from the kernarg segment through an opaque pointer: the
+    // compiler cannot hoist these scalar loads above the loop, so they cost it no SGPRs.
+    typedef const TailArgs __attribute__((address_space(4))) * TailPtr;
+    TailPtr tp = (TailPtr)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() +
+                           offsetof(StepArgs<NRW __COMMA__ DIAG>, tail));
+    asm volatile("" : "+s"(tp));
+    const int64_t S2 = tp->stride;
+    const int n2 = tp->n;
+    const bool valid2 = gid < n2;
+
     // observation: [|sigma_BR|, |omega_BN|, |Omega|/limit, charge/3600/power_max, shadow]
-    const Guid g = guidance<NRW>(cold, x, action);
+    double sR0N[3] = {tp->obs_cfg.sigma_R0N[0], tp->obs_cfg.sigma_R0N[1], tp->obs_cfg.sigma_R0N[2]};
+    const Guid g = guidance<NRW>(sR0N, x, action);
     const double o0 = sqrt(dot(g.sigma_BR, g.sigma_BR));
     const double o1 = sqrt(dot(x.w, x.w));
     double om2 = 0.0;
 #pragma unroll
     for (int k = 0; k < NRW; ++k) om2 = fma(x.Om[k], x.Om[k], om2);
-    const double o2 = sqrt(om2) * cold->inv_wheel_limit;
-    const double o3 = charge * cold->charge_scale;
+    const double o2 = sqrt(om2) * tp->obs_cfg.inv_wheel_limit;
+    const double o3 = charge * tp->obs_cfg.charge_scale;
     const double o4 = 1.0;
 
     // reward and termination
     int why = 0;
-    double rew = (action == 0) ? cold->reward_mult / fma(o0, o0, 1.0) : 0.0;
-    if (cnt.x >= cold->max_length) why |= BSK_DONE_LENGTH;
-    if (o2 > 1.0) { why |= BSK_DONE_WHEELS; rew -= cold->failure_penalty; }
-    if (o3 == 0.0) { why |= BSK_DONE_BATTERY; rew -= cold->failure_penalty; }
-    if (dot(x.r, x.r) < cold->r_min2) why |= BSK_DONE_ORBIT;
+    double rew = (action == 0) ? tp->obs_cfg.reward_mult / fma(o0, o0, 1.0) : 0.0;
+    if (steps0 >= tp->obs_cfg.max_length) why |= BSK_DONE_LENGTH;
+    if (o2 > 1.0) { why |= BSK_DONE_WHEELS; rew -= tp->obs_cfg.failure_penalty; }
+    if (o3 == 0.0) { why |= BSK_DONE_BATTERY; rew -= tp->obs_cfg.failure_penalty; }
+    if (dot(x.r, x.r) < tp->obs_cfg.r_min2) why |= BSK_DONE_ORBIT;
 
     // wavefront reductions (every lane of the wave participates; tail lanes contribute nothing)
-    const unsigned long long dmask = __ballot(valid && why != 0);
-    const double rsum = wave_sum(valid ? rew : 0.0);
+    const unsigned long long dmask = __ballot(valid2 && why != 0);
+    const double rsum = wave_sum(valid2 ? rew : 0.0);
     if ((threadIdx.x & 63) == 0) {
-        a.done_mask[gid >> 6] = dmask;
-        a.wave_reward[gid >> 6] = rsum;
+        tp->done_mask[gid >> 6] = dmask;
+        tp->wave_reward[gid >> 6] = rsum;
     }
 
-    if (valid) {
-        st[(BSK_F_R + 0) * S + i] = x.r.x; st[(BSK_F_R + 1) * S + i] = x.r.y; st[(BSK_F_R + 2) * S + i] = x.r.z;
-        st[(BSK_F_V + 0) * S + i] = x.v.x; st[(BSK_F_V + 1) * S + i] = x.v.y; st[(BSK_F_V + 2) * S + i] = x.v.z;
-        st[(BSK_F_SIGMA + 0) * S + i] = x.s.x; st[(BSK_F_SIGMA + 1) * S + i] = x.s.y; st[(BSK_F_SIGMA + 2) * S + i] = x.s.z;
-        st[(BSK_F_OMEGA + 0) * S + i] = x.w.x; st[(BSK_F_OMEGA + 1) * S + i] = x.w.y; st[(BSK_F_OMEGA + 2) * S + i] = x.w.z;
+    if (valid2) {
+        double* __restrict__ so = tp->st;
+        so[(BSK_F_R + 0) * S2 + i] = x.r.x; so[(BSK_F_R + 1) * S2 + i] = x.r.y; so[(BSK_F_R + 2) * S2 + i] = x.r.z;
+        so[(BSK_F_V + 0) * S2 + i] = x.v.x; so[(BSK_F_V + 1) * S2 + i] = x.v.y; so[(BSK_F_V + 2) * S2 + i] = x.v.z;
+        so[(BSK_F_SIGMA + 0) * S2 + i] = x.s.x; so[(BSK_F_SIGMA + 1) * S2 + i] = x.s.y; so[(BSK_F_SIGMA + 2) * S2 + i] = x.s.z;
+        so[(BSK_F_OMEGA + 0) * S2 + i] = x.w.x; so[(BSK_F_OMEGA + 1) * S2 + i] = x.w.y; so[(BSK_F_OMEGA + 2) * S2 + i] = x.w.z;
 #pragma unroll
-        for (int k = 0; k < NRW; ++k) st[(BSK_NF_BASE + k) * S + i] = x.Om[k];
+        for (int k = 0; k < NRW; ++k) so[(BSK_NF_BASE + k) * S2 + i] = x.Om[k];
         if constexpr (NRW > 0) {
             if (fsw_ran) {
 #pragma unroll
-                for (int k = 0; k < NRW; ++k) st[(TAIL + BSK_T_UCMD + k) * S + i] = u[k];
+                for (int k = 0; k < NRW; ++k) so[(TAIL + BSK_T_UCMD + k) * S2 + i] = u[k];
             }
         }
-        a.cnt[i] = make_int2(cnt.x + 1, cnt.y + a.substeps);
-        a.obs[0 * S + i] = o0; a.obs[1 * S + i] = o1; a.obs[2 * S + i] = o2; a.obs[3 * S + i] = o3; a.obs[4 * S + i] = o4;
-        a.reward[i] = rew;
-        a.reason[i] = (unsigned char)why;
+        tp->cnt[i] = make_int2((steps0 + 1) | (phase << 20), cnt.y + tp->substeps);
+        double* __restrict__ ob = tp->obs;
+        ob[0 * S2 + i] = o0; ob[1 * S2 + i] = o1; ob[2 * S2 + i] = o2; ob[3 * S2 + i] = o3; ob[4 * S2 + i] = o4;
+        tp->reward[i] = rew;
+        tp->reason[i] = (unsigned char)why;
     }
 }
 
@@ -185,9 +200,11 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
                            hipEvent_t ev1) {
     StepArgs<NRW, DIAG> a;
     fill_hot<GRAV, NRW, DIAG>(p, a.hot);
-    a.cold = b.cold; a.st = b.st; a.cnt = b.cnt; a.act = b.act; a.obs = b.obs; a.reward = b.reward;
-    a.done_mask = b.done_mask; a.reason = b.reason; a.wave_reward = b.wave_reward;
+    a.cold = b.cold; a.st = b.st; a.cnt = b.cnt; a.act = b.act;
     a.stride = b.stride; a.n = b.n; a.substeps = b.substeps;
+    a.tail.obs_cfg = p.obs; a.tail.st = b.st; a.tail.cnt = b.cnt; a.tail.obs = b.obs; a.tail.reward = b.reward;
+    a.tail.done_mask = b.done_mask; a.tail.reason = b.reason; a.tail.wave_reward = b.wave_reward;
+    a.tail.stride = b.stride; a.tail.n = b.n; a.tail.substeps = b.substeps;
     const int grid = (b.n + block - 1) / block;
     // hipExtLaunchKernelGGL stamps ev0/ev1 from the dispatch packet itself (no marker packets), so
     // their difference is the kernel's own duration, as rocprofv3 --kernel-trace reports it.

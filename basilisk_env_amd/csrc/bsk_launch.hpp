@@ -8,14 +8,13 @@
 
 namespace bsk {
 
-// Passed by value to step_kernel (kernarg segment -> SGPRs).
-template <int NRW, bool DIAG>
-struct StepArgs {
-    HotCfg<NRW, DIAG> hot;
-    const ColdCfg* cold;           // device memory
-    double* st;                    // state slab [n_fields][stride]
-    int2* cnt;                     // per env {env steps, RK4 ticks} since reset
-    const int* act;                // actions, device
+// Everything the kernel needs only AFTER the RK4 loop.  It is re-read from the kernarg segment
+// behind an opaque pointer once the loop is done, so none of it occupies SGPRs across the loop
+// (the loop's HotCfg alone nearly fills the 102-SGPR budget).
+struct TailArgs {
+    ObsCfg obs_cfg;
+    double* st;
+    int2* cnt;
     double* obs;                   // [5][stride]
     double* reward;                // [stride]
     unsigned long long* done_mask; // [stride/64], one 64-bit ballot per wavefront
@@ -26,6 +25,20 @@ struct StepArgs {
     int substeps;
 };
 
+// Passed by value to step_kernel (kernarg segment -> SGPRs).
+template <int NRW, bool DIAG>
+struct StepArgs {
+    HotCfg<NRW, DIAG> hot;
+    const ColdCfg* cold;           // device memory
+    const double* st;              // state slab [n_fields][stride]
+    const int2* cnt;               // per env {env steps | FSW phase << 20, RK4 ticks} since reset
+    const int* act;                // actions, device
+    int64_t stride;
+    int n;
+    int substeps;
+    TailArgs tail;
+};
+
 // Host-side, variant-independent description of the hot constants (built once per handle).
 struct StepParams {
     double dt, mu, j2k;
@@ -33,6 +46,7 @@ struct StepParams {
     double gs[BSK_MAX_RW][3], js[BSK_MAX_RW];
     double f_coulomb;
     int32_t fsw_every;
+    ObsCfg obs;
 };
 
 struct StepBuffers {

@@ -245,7 +245,21 @@ static void gravity(orc_ctx* ctx, const double r[3], double t, double a[3]) {
     }
 }
 
-static void eom(orc_ctx* ctx, const double x[NX], const double u[BSK_MAX_RW], const double lext[3], double t,
+/* Wheel torque acting along each spin axis = held motor torque + Coulomb friction.  Like the
+ * motor command, the friction torque is evaluated once per effector update (dyn tick) from the
+ * wheel speed at that time and held through the integrator's stages (Basilisk computes both in
+ * the RW effector's ConfigureRWRequests, outside the equations of motion) [BSK-recall]. */
+static void wheel_torque(orc_ctx* ctx, const double x[NX], const double u[BSK_MAX_RW], double tq[BSK_MAX_RW]) {
+    const bsk_config* c = ctx->c;
+    for (int i = 0; i < BSK_MAX_RW; ++i) tq[i] = 0.0;
+    for (int i = 0; i < c->n_rw; ++i) {
+        double Om = x[12 + i], fr = 0.0;
+        if (Om > 0.0) fr = -c->f_coulomb; else if (Om < 0.0) fr = c->f_coulomb;
+        tq[i] = u[i] + fr;
+    }
+}
+
+static void eom(orc_ctx* ctx, const double x[NX], const double tq[BSK_MAX_RW], const double lext[3], double t,
                 double dx[NX]) {
     const bsk_config* c = ctx->c;
     const double *r = x, *v = x + 3, *sg = x + 6, *w = x + 9, *Om = x + 12;
@@ -257,16 +271,13 @@ static void eom(orc_ctx* ctx, const double x[NX], const double u[BSK_MAX_RW], co
     v3cross(sg, w, cx);
     for (int k = 0; k < 3; ++k) dx[6 + k] = 0.25 * ((1.0 - s2) * w[k] + 2.0 * cx[k] + 2.0 * sw * sg[k]);
     /* rotation, balanced wheels: back-substitution
-       [I - sum Js g g^T] w' = -w x (I w) - sum [ g (u + tau_f) + Js Omega (w x g) ] + L_ext      */
-    double Iw[3], rhs[3], tq[BSK_MAX_RW];
+       [I - sum Js g g^T] w' = -w x (I w) - sum [ g tq + Js Omega (w x g) ] + L_ext              */
+    double Iw[3], rhs[3];
     m33v3(c->inertia, w, Iw);
     v3cross(w, Iw, rhs);
     v3scale(-1.0, rhs, rhs);
     v3add(rhs, lext, rhs);
     for (int i = 0; i < c->n_rw; ++i) {
-        double fr = 0.0;
-        if (Om[i] > 0.0) fr = -c->f_coulomb; else if (Om[i] < 0.0) fr = c->f_coulomb;
-        tq[i] = u[i] + fr;
         double wg[3]; v3cross(w, c->gs[i], wg);
         for (int k = 0; k < 3; ++k) rhs[k] -= c->gs[i][k] * tq[i] + c->js[i] * Om[i] * wg[k];
     }
@@ -277,8 +288,9 @@ static void eom(orc_ctx* ctx, const double x[NX], const double u[BSK_MAX_RW], co
 
 /* classic RK4 (Basilisk default integrator svIntegratorRK4; the reference never selects another,
  * …Simulator.py:213-214), then the MRP shadow-set switch once per completed step. */
-static void rk4_step(orc_ctx* ctx, double x[NX], const double u[BSK_MAX_RW], const double lext[3], double t, double h) {
-    double k[NX], xt[NX], acc[NX];
+static void rk4_step(orc_ctx* ctx, double x[NX], const double ucmd[BSK_MAX_RW], const double lext[3], double t, double h) {
+    double k[NX], xt[NX], acc[NX], u[BSK_MAX_RW];
+    wheel_torque(ctx, x, ucmd, u); /* motor + friction torque, held over the step */
     eom(ctx, x, u, lext, t, k);
     for (int i = 0; i < NX; ++i) { acc[i] = x[i] + h / 6.0 * k[i]; xt[i] = x[i] + 0.5 * h * k[i]; }
     eom(ctx, xt, u, lext, t + 0.5 * h, k);
@@ -533,7 +545,9 @@ int orc_eom(const bsk_config* c, const double* x, const double* u, const double*
     double xx[NX] = {0}, uu[BSK_MAX_RW] = {0}, dd[NX];
     memcpy(xx, x, sizeof(double) * (12 + c->n_rw));
     memcpy(uu, u, sizeof(double) * c->n_rw);
-    eom(&ctx, xx, uu, lext, t, dd);
+    double tq[BSK_MAX_RW];
+    wheel_torque(&ctx, xx, uu, tq);
+    eom(&ctx, xx, tq, lext, t, dd);
     memcpy(dx, dd, sizeof(double) * (12 + c->n_rw));
     ctx_free(&ctx);
     return 0;

@@ -169,16 +169,22 @@ class Model(object):
             a = [a[0] + k * r[0] * (5 * z2 - 1), a[1] + k * r[1] * (5 * z2 - 1), a[2] + k * r[2] * (5 * z2 - 3)]
         return a
 
-    def eom(self, x, u, lext):
+    def wheel_torque(self, x, u):
+        """motor torque + Coulomb friction from the wheel speeds at the start of the step"""
+        tq = []
+        for i in range(self.n_rw):
+            Om = x[12 + i]
+            fr = -self.fc if Om > 0 else (self.fc if Om < 0 else M(0))
+            tq.append(u[i] + fr)
+        return tq
+
+    def eom(self, x, tq, lext):
         r, v, s, w, Om = x[0:3], x[3:6], x[6:9], x[9:12], x[12:]
         dv = self.gravity(r)
         s2, sw, sxw = dot(s, s), dot(s, w), cross(s, w)
         ds = [((1 - s2) * w[k] + 2 * sxw[k] + 2 * sw * s[k]) / 4 for k in range(3)]
         rhs = add(scale(-1, cross(w, matvec(self.I, w))), lext)
-        tq = []
         for i in range(self.n_rw):
-            fr = -self.fc if Om[i] > 0 else (self.fc if Om[i] < 0 else M(0))
-            tq.append(u[i] + fr)
             wg = cross(w, self.gs[i])
             rhs = [rhs[k] - self.gs[i][k] * tq[i] - self.js[i] * Om[i] * wg[k] for k in range(3)]
         dw = matvec(self.Dinv, rhs)
@@ -188,6 +194,7 @@ class Model(object):
     def rk4(self, x, u, lext):
         h = self.dt
         ax = lambda a, k, y: [yi + a * ki for yi, ki in zip(y, k)]  # noqa: E731
+        u = self.wheel_torque(x, u)   # held over the four stages
         k1 = self.eom(x, u, lext)
         k2 = self.eom(ax(h / 2, k1, x), u, lext)
         k3 = self.eom(ax(h / 2, k2, x), u, lext)

@@ -33,8 +33,9 @@ def test_no_torch_or_oracle_linkage():
     """The product library links HIP only: no torch, no oracle."""
     import subprocess
     out = subprocess.check_output(["ldd", _lib.lib_path()]).decode()
-    assert "amdhip64" in out
-    assert "torch" not in out and "oracle" not in out and "c10" not in out
+    names = [line.split()[0] for line in out.splitlines() if line.strip()]   # library names only (no load addresses)
+    assert any("amdhip64" in n for n in names)
+    assert not any(("torch" in n) or ("oracle" in n) or ("c10" in n) for n in names)
 
 
 @pytest.mark.parametrize("n_rw", [0, 3, 4])
