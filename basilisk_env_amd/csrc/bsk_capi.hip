@@ -308,7 +308,7 @@ int bsk_default_config(bsk_config* c, int n_rw, int gravity_model) {
 int bsk_create(const bsk_config* cfg, int n_envs, int device_id, void* stream, bsk_handle** out) {
     if (!cfg || !out) return fail(BSK_EINVAL, "cfg/out is NULL");
     *out = nullptr;
-    if (n_envs < 1) return fail(BSK_EINVAL, "n_envs must be >= 1");
+    if (n_envs < 1 || n_envs > (1 << 28)) return fail(BSK_EINVAL, "n_envs must be in 1..2^28");
     int rc = validate(*cfg);
     if (rc) return rc;
     int ndev = 0;

@@ -56,6 +56,43 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
     return fma(y * e, p, y);
 }
 
+// 1/x for normal x: v_rcp_f64 estimate + two Newton steps (error ~1 ulp), 5 ops instead of the
+// ~12-instruction IEEE divide expansion.
+__device__ __forceinline__ double rcp_nr(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+}
+// sqrt(x) for x >= 0 (0 -> 0): x * rsqrt(x)
+__device__ __forceinline__ double sqrt_nr(double x) { return x > 0.0 ? x * rsqrt_nr(x) : 0.0; }
+
+// Tell the compiler a value is wave-uniform (keeps it in SGPRs so that loads/stores through it
+// take the saddr form).  Free when the value already lives in SGPRs.
+__device__ __forceinline__ int64_t uniform64(int64_t v) {
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+// uniform pointer into GLOBAL memory (address space 1 is spelled out because an integer->pointer
+// round trip would otherwise fall back to flat addressing)
+template <class T>
+using gptr = T __attribute__((address_space(1)))*;
+template <class T>
+__device__ __forceinline__ gptr<T> uniform_ptr(T* p) {
+    return (gptr<T>)p;   // explicit flat -> global cast; the value itself comes from a scalar load
+}
+
+// Coalesced SoA access: uniform field base (SGPR pair) + one 32-bit per-lane byte offset shared by
+// every field -> global_load/store with the saddr form, no 64-bit VGPR address arithmetic.
+__device__ __forceinline__ double ldf(const double* __restrict__ base, uint32_t boff) {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + boff);
+}
+__device__ __forceinline__ void stf(gptr<double> base, uint32_t boff, double v) {
+    *(gptr<double>)((gptr<char>)base + boff) = v;
+}
+
 // --------------------------------------------------------------------------------------------
 // Hot constants (SGPR-resident).  M3 = 3 (diagonal) or 9 (full, row-major) doubles per matrix.
 template <int NRW, bool DIAG>
@@ -222,13 +259,13 @@ __device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, const Wheel
     eom<GRAV, NRW, DIAG>(c, wv, xt, rhs0, tqj, k);
     st_axpy<NRW>(c.h6, k, acc, x);
     double s2 = dot(x.s, x.s);
-    if (s2 > 1.0) x.s = (-1.0 / s2) * x.s;
+    if (s2 > 1.0) x.s = (-rcp_nr(s2)) * x.s;
 }
 
 // --------------------------------------------------------------------------------------------
 // attitude kinematics helpers (FSW chain / observation; run at 1/10 of the RK4 rate)
 __device__ __forceinline__ void mrp2c(V3 q, double* C) {
-    double q2 = dot(q, q), op = 1.0 + q2, id = 1.0 / (op * op);
+    double q2 = dot(q, q), op = 1.0 + q2, id = rcp_nr(op * op);
     double a = 8.0 * id, b = 4.0 * (1.0 - q2) * id;
     // t~^2 = q q^T - q2 I
     C[0] = fma(a, q.x * q.x - q2, 1.0);
@@ -253,7 +290,7 @@ __device__ __forceinline__ V3 c2mrp(const double* C) {
     if (b21 > mx) { mx = b21; i = 1; }
     if (b22 > mx) { mx = b22; i = 2; }
     if (b23 > mx) { mx = b23; i = 3; }
-    double p = sqrt(mx), q4 = 0.25 / p;
+    double ip = rsqrt_nr(mx), p = mx * ip, q4 = 0.25 * ip;   // mx >= 1/4 always
     // numerators of the four Sheppard cases, selected without divergent control flow
     double d0 = C[5] - C[7], d1 = C[6] - C[2], d2 = C[1] - C[3];
     double s0 = C[1] + C[3], s1 = C[6] + C[2], s2 = C[5] + C[7];
@@ -262,7 +299,7 @@ __device__ __forceinline__ V3 c2mrp(const double* C) {
     double b2 = (i == 2) ? p : q4 * ((i == 0) ? d1 : (i == 1) ? s0 : s2);
     double b3 = (i == 3) ? p : q4 * ((i == 0) ? d2 : (i == 1) ? s1 : s2);
     if (b0 < 0.0) { b0 = -b0; b1 = -b1; b2 = -b2; b3 = -b3; }
-    double id = 1.0 / (1.0 + b0);
+    double id = rcp_nr(1.0 + b0);
     return V3{b1 * id, b2 * id, b3 * id};
 }
 
@@ -271,15 +308,15 @@ __device__ __forceinline__ V3 submrp(V3 q1, V3 q2) {
     double d1 = dot(q1, q1), d2 = dot(q2, q2);
     double den = 1.0 + d1 * d2 + 2.0 * dot(q1, q2);
     if (fabs(den) < 0.1) {
-        q1 = (-1.0 / d1) * q1;
+        q1 = (-rcp_nr(d1)) * q1;
         d1 = dot(q1, q1);
         den = 1.0 + d1 * d2 + 2.0 * dot(q1, q2);
     }
     V3 t = cross(q1, q2);
-    double id = 1.0 / den;
+    double id = rcp_nr(den);
     V3 q = id * ((1.0 - d2) * q1 - (1.0 - d1) * q2 + 2.0 * t);
     double m = dot(q, q);
-    if (m > 1.0) q = (-1.0 / m) * q;
+    if (m > 1.0) q = (-rcp_nr(m)) * q;
     return q;
 }
 
@@ -292,9 +329,9 @@ template <int NRW>
 __device__ __forceinline__ Guid guidance(const double* __restrict__ sigma_R0N, const State<NRW>& x, int action) {
     V3 sRN, wRN_N, dwRN_N;
     if (action == 0) {
-        double ir = 1.0 / sqrt(dot(x.r, x.r));
+        double ir = rsqrt_nr(dot(x.r, x.r));
         V3 h = cross(x.r, x.v);
-        double hm = sqrt(dot(h, h)), ih = 1.0 / hm;
+        double h2 = dot(h, h), ih = rsqrt_nr(h2), hm = h2 * ih;
         V3 e_r = ir * x.r, e_h = ih * h, e_t = cross(e_h, e_r);
         double C[9] = {e_r.x, e_r.y, e_r.z, e_t.x, e_t.y, e_t.z, e_h.x, e_h.y, e_h.z};
         sRN = c2mrp(C);

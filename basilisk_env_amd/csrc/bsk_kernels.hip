@@ -33,26 +33,29 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs<NRW, DIAG> a) 
     const int i = valid ? gid : a.n - 1;  // tail lanes shadow the last env; their stores are masked
     const int64_t S = a.stride;
     const double* __restrict__ st = a.st;
+    const uint32_t bo = (uint32_t)i * 8u;   // per-lane byte offset inside every field row (n < 2^28)
+#define FLD(f) (st + (int64_t)(f) * S)
 
     // every load of the launch is issued here, before any use
     State<NRW> x;
-    x.r = mk(st[(BSK_F_R + 0) * S + i], st[(BSK_F_R + 1) * S + i], st[(BSK_F_R + 2) * S + i]);
-    x.v = mk(st[(BSK_F_V + 0) * S + i], st[(BSK_F_V + 1) * S + i], st[(BSK_F_V + 2) * S + i]);
-    x.s = mk(st[(BSK_F_SIGMA + 0) * S + i], st[(BSK_F_SIGMA + 1) * S + i], st[(BSK_F_SIGMA + 2) * S + i]);
-    x.w = mk(st[(BSK_F_OMEGA + 0) * S + i], st[(BSK_F_OMEGA + 1) * S + i], st[(BSK_F_OMEGA + 2) * S + i]);
+    x.r = mk(ldf(FLD(BSK_F_R + 0), bo), ldf(FLD(BSK_F_R + 1), bo), ldf(FLD(BSK_F_R + 2), bo));
+    x.v = mk(ldf(FLD(BSK_F_V + 0), bo), ldf(FLD(BSK_F_V + 1), bo), ldf(FLD(BSK_F_V + 2), bo));
+    x.s = mk(ldf(FLD(BSK_F_SIGMA + 0), bo), ldf(FLD(BSK_F_SIGMA + 1), bo), ldf(FLD(BSK_F_SIGMA + 2), bo));
+    x.w = mk(ldf(FLD(BSK_F_OMEGA + 0), bo), ldf(FLD(BSK_F_OMEGA + 1), bo), ldf(FLD(BSK_F_OMEGA + 2), bo));
 #pragma unroll
-    for (int k = 0; k < NRW; ++k) x.Om[k] = st[(BSK_NF_BASE + k) * S + i];
+    for (int k = 0; k < NRW; ++k) x.Om[k] = ldf(FLD(BSK_NF_BASE + k), bo);
     constexpr int TAIL = BSK_NF_BASE + NRW;
-    const V3 lext = mk(st[(TAIL + BSK_T_LEXT + 0) * S + i], st[(TAIL + BSK_T_LEXT + 1) * S + i],
-                       st[(TAIL + BSK_T_LEXT + 2) * S + i]);
-    const double charge = st[(TAIL + BSK_T_CHARGE) * S + i];
-    const int2 cnt = a.cnt[i];   // {env steps | FSW phase << 20, RK4 ticks}
-    const int action = a.act[i];
+    const V3 lext = mk(ldf(FLD(TAIL + BSK_T_LEXT + 0), bo), ldf(FLD(TAIL + BSK_T_LEXT + 1), bo),
+                       ldf(FLD(TAIL + BSK_T_LEXT + 2), bo));
+    const double charge = ldf(FLD(TAIL + BSK_T_CHARGE), bo);
+    const int2 cnt = *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(a.cnt) + bo);  // {steps | phase << 20, ticks}
+    const int action = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(a.act) + (bo >> 1));
     double u[NRW > 0 ? NRW : 1];
     // the held motor torque only matters when this launch starts between two FSW ticks; it is
     // loaded unconditionally so that all loads are in flight at once
 #pragma unroll
-    for (int k = 0; k < NRW; ++k) u[k] = st[(TAIL + BSK_T_UCMD + k) * S + i];
+    for (int k = 0; k < NRW; ++k) u[k] = ldf(FLD(TAIL + BSK_T_UCMD + k), bo);
+#undef FLD
 
     const int steps0 = cnt.x & 0xFFFFF;
     int phase = cnt.x >> 20;
@@ -86,25 +89,25 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs<NRW, DIAG> a) 
     TailPtr tp = (TailPtr)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() +
                            offsetof(StepArgs<NRW __COMMA__ DIAG>, tail));
     asm volatile("" : "+s"(tp));
-    const int64_t S2 = tp->stride;
+    const int64_t S2 = uniform64(tp->stride);
     const int n2 = tp->n;
     const bool valid2 = gid < n2;
 
     // observation: [|sigma_BR|, |omega_BN|, |Omega|/limit, charge/3600/power_max, shadow]
     double sR0N[3] = {tp->obs_cfg.sigma_R0N[0], tp->obs_cfg.sigma_R0N[1], tp->obs_cfg.sigma_R0N[2]};
     const Guid g = guidance<NRW>(sR0N, x, action);
-    const double o0 = sqrt(dot(g.sigma_BR, g.sigma_BR));
-    const double o1 = sqrt(dot(x.w, x.w));
+    const double o0 = sqrt_nr(dot(g.sigma_BR, g.sigma_BR));
+    const double o1 = sqrt_nr(dot(x.w, x.w));
     double om2 = 0.0;
 #pragma unroll
     for (int k = 0; k < NRW; ++k) om2 = fma(x.Om[k], x.Om[k], om2);
-    const double o2 = sqrt(om2) * tp->obs_cfg.inv_wheel_limit;
+    const double o2 = sqrt_nr(om2) * tp->obs_cfg.inv_wheel_limit;
     const double o3 = charge * tp->obs_cfg.charge_scale;
     const double o4 = 1.0;
 
     // reward and termination
     int why = 0;
-    double rew = (action == 0) ? tp->obs_cfg.reward_mult / fma(o0, o0, 1.0) : 0.0;
+    double rew = (action == 0) ? tp->obs_cfg.reward_mult * rcp_nr(fma(o0, o0, 1.0)) : 0.0;
     if (steps0 >= tp->obs_cfg.max_length) why |= BSK_DONE_LENGTH;
     if (o2 > 1.0) { why |= BSK_DONE_WHEELS; rew -= tp->obs_cfg.failure_penalty; }
     if (o3 == 0.0) { why |= BSK_DONE_BATTERY; rew -= tp->obs_cfg.failure_penalty; }
@@ -118,24 +121,32 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs<NRW, DIAG> a) 
         tp->wave_reward[gid >> 6] = rsum;
     }
 
-    if (valid2) {
-        double* __restrict__ so = tp->st;
-        so[(BSK_F_R + 0) * S2 + i] = x.r.x; so[(BSK_F_R + 1) * S2 + i] = x.r.y; so[(BSK_F_R + 2) * S2 + i] = x.r.z;
-        so[(BSK_F_V + 0) * S2 + i] = x.v.x; so[(BSK_F_V + 1) * S2 + i] = x.v.y; so[(BSK_F_V + 2) * S2 + i] = x.v.z;
-        so[(BSK_F_SIGMA + 0) * S2 + i] = x.s.x; so[(BSK_F_SIGMA + 1) * S2 + i] = x.s.y; so[(BSK_F_SIGMA + 2) * S2 + i] = x.s.z;
-        so[(BSK_F_OMEGA + 0) * S2 + i] = x.w.x; so[(BSK_F_OMEGA + 1) * S2 + i] = x.w.y; so[(BSK_F_OMEGA + 2) * S2 + i] = x.w.z;
+    // Tail lanes shadow env n-1 and computed bit-identical results from identical inputs, so their
+    // stores (same address, same value) need no mask.
+    {
+        gptr<double> so = uniform_ptr(tp->st);
+#define FLD(f) (so + (int64_t)(f) * S2)
+        stf(FLD(BSK_F_R + 0), bo, x.r.x); stf(FLD(BSK_F_R + 1), bo, x.r.y); stf(FLD(BSK_F_R + 2), bo, x.r.z);
+        stf(FLD(BSK_F_V + 0), bo, x.v.x); stf(FLD(BSK_F_V + 1), bo, x.v.y); stf(FLD(BSK_F_V + 2), bo, x.v.z);
+        stf(FLD(BSK_F_SIGMA + 0), bo, x.s.x); stf(FLD(BSK_F_SIGMA + 1), bo, x.s.y); stf(FLD(BSK_F_SIGMA + 2), bo, x.s.z);
+        stf(FLD(BSK_F_OMEGA + 0), bo, x.w.x); stf(FLD(BSK_F_OMEGA + 1), bo, x.w.y); stf(FLD(BSK_F_OMEGA + 2), bo, x.w.z);
 #pragma unroll
-        for (int k = 0; k < NRW; ++k) so[(BSK_NF_BASE + k) * S2 + i] = x.Om[k];
+        for (int k = 0; k < NRW; ++k) stf(FLD(BSK_NF_BASE + k), bo, x.Om[k]);
         if constexpr (NRW > 0) {
             if (fsw_ran) {
 #pragma unroll
-                for (int k = 0; k < NRW; ++k) so[(TAIL + BSK_T_UCMD + k) * S2 + i] = u[k];
+                for (int k = 0; k < NRW; ++k) stf(FLD(TAIL + BSK_T_UCMD + k), bo, u[k]);
             }
         }
-        tp->cnt[i] = make_int2((steps0 + 1) | (phase << 20), cnt.y + tp->substeps);
-        double* __restrict__ ob = tp->obs;
-        ob[0 * S2 + i] = o0; ob[1 * S2 + i] = o1; ob[2 * S2 + i] = o2; ob[3 * S2 + i] = o3; ob[4 * S2 + i] = o4;
-        tp->reward[i] = rew;
+#undef FLD
+        // int2 {steps | phase << 20, ticks} written as one 8-byte word
+        const unsigned long long packed = (unsigned long long)(unsigned)((steps0 + 1) | (phase << 20)) |
+                                          ((unsigned long long)(unsigned)(cnt.y + tp->substeps) << 32);
+        *(gptr<unsigned long long>)((gptr<char>)uniform_ptr(tp->cnt) + bo) = packed;
+        gptr<double> ob = uniform_ptr(tp->obs);
+        stf(ob + 0 * S2, bo, o0); stf(ob + 1 * S2, bo, o1); stf(ob + 2 * S2, bo, o2); stf(ob + 3 * S2, bo, o3);
+        stf(ob + 4 * S2, bo, o4);
+        stf(uniform_ptr(tp->reward), bo, rew);
         tp->reason[i] = (unsigned char)why;
     }
 }
