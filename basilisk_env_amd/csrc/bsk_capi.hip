@@ -55,6 +55,55 @@ void sun_position(double jd, double out[3]) {
     out[2] = R * std::sin(eps) * std::sin(lam);
 }
 
+// Fused Pines coefficient stream for gravity_sh (bsk_device.hpp), iteration order
+// M = 1..d+1, L = M..d+1, 8 doubles per step:
+//   [0] L == M: A[M][M] (diagonal constant);  L == M+1: A[M+1][M]/(u A[M][M]);  else n1[L][M]
+//   [1] n2[L][M] (L >= M+2)                      -- recursion A[L][M] = u n1 A[L-1][M] - n2 A[L-2][M]
+//   [2,3] M (Cbar, Sbar)[L][M]                   -- a1 / a2 sums            (L <= d)
+//   [4,5] nq1[L][M-1] (Cbar, Sbar)[L][M-1]       -- a3 sum                  (L <= d)
+//   [6,7] nq2[L-1][M-1] (Cbar, Sbar)[L-1][M-1]   -- a4 sum                  (L >= 2)
+// Constants as Basilisk's gravityEffector documents them (SURVEY.md §8 note N1).
+void build_sh_table(int d, const double* cbar, const double* sbar, std::vector<double>& tab) {
+    auto K = [](int i) { return i == 0 ? 1.0 : 2.0; };
+    auto idx = [](int l, int m) { return l * (l + 1) / 2 + m; };
+    std::vector<double> diag(d + 2), sd(d + 2);
+    diag[0] = 1.0;
+    for (int l = 1; l <= d + 1; ++l) diag[l] = std::sqrt((double)(2 * l + 1) * K(l) / ((double)(2 * l) * K(l - 1))) * diag[l - 1];
+    for (int l = 1; l <= d + 1; ++l) sd[l] = std::sqrt((double)(2 * l) * K(l - 1) / K(l)) * diag[l];
+    auto n1 = [](int l, int m) { return std::sqrt((double)(2 * l + 1) * (double)(2 * l - 1) / ((double)(l - m) * (double)(l + m))); };
+    auto n2 = [](int l, int m) {
+        return std::sqrt((double)(l + m - 1) * (double)(2 * l + 1) * (double)(l - m - 1) /
+                         ((double)(l + m) * (double)(l - m) * (double)(2 * l - 3)));
+    };
+    auto nq1 = [&](int l, int m) { return std::sqrt((double)(l - m) * K(m) * (double)(l + m + 1) / K(m + 1)); };
+    auto nq2 = [&](int l, int m) {
+        return std::sqrt((double)(l + m + 2) * (double)(l + m + 1) * (double)(2 * l + 1) * K(m) / ((double)(2 * l + 3) * K(m + 1)));
+    };
+    tab.clear();
+    tab.reserve((size_t)(d + 1) * (d + 2) / 2 * 8);
+    for (int M = 1; M <= d + 1; ++M)
+        for (int L = M; L <= d + 1; ++L) {
+            double e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (L == M) e[0] = diag[M];
+            else if (L == M + 1) e[0] = sd[M + 1] / diag[M];
+            else { e[0] = n1(L, M); e[1] = n2(L, M); }
+            if (L <= d) {
+                e[2] = M * cbar[idx(L, M)];
+                e[3] = M * sbar[idx(L, M)];
+                const double q = nq1(L, M - 1);
+                e[4] = q * cbar[idx(L, M - 1)];
+                e[5] = q * sbar[idx(L, M - 1)];
+            }
+            if (L >= 2) {
+                const double q = nq2(L - 1, M - 1);
+                e[6] = q * cbar[idx(L - 1, M - 1)];
+                e[7] = q * sbar[idx(L - 1, M - 1)];
+            }
+            tab.insert(tab.end(), e, e + 8);
+        }
+    tab.insert(tab.end(), 16, 0.0);   // spare entries: the kernel's software pipeline reads ahead
+}
+
 int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool& diag) {
     std::memset(&p, 0, sizeof p);
     std::memset(&k, 0, sizeof k);
@@ -102,6 +151,10 @@ int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool&
     }
     p.f_coulomb = c.f_coulomb;
     p.fsw_every = c.fsw_every;
+    p.req = c.req;
+    p.planet_rate = c.planet_rate;
+    p.sh_tab = nullptr;
+    p.sh_degree = 0;
     k.u_max = c.u_max;
     k.u_min = c.u_min;
     k.K = c.K;
@@ -144,6 +197,7 @@ struct bsk_handle {
     double* d_ic_stage = nullptr;
     int* d_idx_stage = nullptr;
     size_t stage_cap = 0;
+    double* d_sh_tab = nullptr;
     // profiling
     std::vector<hipEvent_t> ev;
     int ev_used = 0;
@@ -175,7 +229,8 @@ int validate(const bsk_config& c) {
     if (c.n_rw != 0 && c.n_rw != 3 && c.n_rw != 4) return fail(BSK_EINVAL, "n_rw must be 0, 3 or 4");
     if (c.gravity_model != BSK_GRAV_PM && c.gravity_model != BSK_GRAV_PM_J2 && c.gravity_model != BSK_GRAV_SH)
         return fail(BSK_EINVAL, "unknown gravity_model");
-    if (c.gravity_model == BSK_GRAV_SH) return fail(BSK_EINVAL, "gravity_model BSK_GRAV_SH is not built in this version");
+    if (c.gravity_model == BSK_GRAV_SH && (c.sh_degree < 2 || c.sh_degree > BSK_MAX_SH_DEGREE))
+        return fail(BSK_EINVAL, "sh_degree must be in 2..70 for BSK_GRAV_SH");
     const uint32_t unbuilt = BSK_FLAG_SUN_THIRD_BODY | BSK_FLAG_POWER | BSK_FLAG_DESAT | BSK_FLAG_DRAG |
                              BSK_FLAG_AUTO_RESET | BSK_FLAG_LDS_SCRATCH;
     if (c.flags & unbuilt) return fail(BSK_EINVAL, "config flag requests a feature that is not built in this version");
@@ -198,6 +253,8 @@ int ensure_stage(bsk_handle* h, size_t m) {
 }
 
 int do_step(bsk_handle* h, const int* d_actions, int substeps) {
+    if (h->cfg.gravity_model == BSK_GRAV_SH && !h->sp.sh_tab)
+        return fail(BSK_EINVAL, "BSK_GRAV_SH: call bsk_set_gravity_sh before stepping");
     bsk::StepBuffers b;
     b.cold = h->d_cold;
     b.st = h->d_state;
@@ -373,16 +430,28 @@ void bsk_destroy(bsk_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (hipEvent_t ev : h->ev) (void)hipEventDestroy(ev);
     void* bufs[] = {h->d_state, h->d_cnt, h->d_act, h->d_obs, h->d_reward, h->d_done_mask, h->d_reason,
-                    h->d_wave_reward, h->d_stat_sum, h->d_stat_done, h->d_ic_stage, h->d_idx_stage, h->d_cold};
+                    h->d_wave_reward, h->d_stat_sum, h->d_stat_done, h->d_ic_stage, h->d_idx_stage, h->d_cold, h->d_sh_tab};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
-int bsk_set_gravity_sh(bsk_handle* h, int, const double*, const double*) {
-    if (!h) return fail(BSK_EINVAL, "handle is NULL");
-    return fail(BSK_EINVAL, "spherical-harmonic gravity is not built in this version");
+int bsk_set_gravity_sh(bsk_handle* h, int degree, const double* cbar, const double* sbar) {
+    if (!h || !cbar || !sbar) return fail(BSK_EINVAL, "handle/cbar/sbar is NULL");
+    if (h->cfg.gravity_model != BSK_GRAV_SH) return fail(BSK_EINVAL, "handle was not created with BSK_GRAV_SH");
+    if (degree != h->cfg.sh_degree) return fail(BSK_EINVAL, "degree differs from bsk_config.sh_degree");
+    if (cbar[0] != 1.0) return fail(BSK_EINVAL, "Cbar[0][0] must be 1 (normalised coefficients)");
+    DeviceGuard guard(h->device);
+    std::vector<double> tab;
+    build_sh_table(degree, cbar, sbar, tab);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->d_sh_tab) { (void)hipFree(h->d_sh_tab); h->d_sh_tab = nullptr; }
+    HIP_TRY(hipMalloc(&h->d_sh_tab, tab.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(h->d_sh_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    h->sp.sh_tab = h->d_sh_tab;
+    h->sp.sh_degree = degree;
+    return BSK_OK;
 }
 
 int bsk_n_fields(const bsk_handle* h) { return h ? h->nf : BSK_EINVAL; }
@@ -561,7 +630,8 @@ int bsk_kernel_info(bsk_handle* h, char* name, int name_cap, int* vgprs, int* ld
     hipFuncAttributes at;
     HIP_TRY(hipFuncGetAttributes(&at, fp));
     if (name && name_cap > 0)
-        std::snprintf(name, name_cap, "step_kernel<%s,%d,%s>", h->cfg.gravity_model == BSK_GRAV_PM ? "PM" : "PM_J2", h->cfg.n_rw,
+        std::snprintf(name, name_cap, "step_kernel<%s,%d,%s>",
+                      h->cfg.gravity_model == BSK_GRAV_PM ? "PM" : (h->cfg.gravity_model == BSK_GRAV_PM_J2 ? "PM_J2" : "SH"), h->cfg.n_rw,
                       h->diag ? "diag" : "full");
     if (vgprs) *vgprs = at.numRegs;
     if (lds_bytes) *lds_bytes = (int)at.sharedSizeBytes;

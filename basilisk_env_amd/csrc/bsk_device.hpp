@@ -104,7 +104,10 @@ struct HotCfg {
     double g[NRW > 0 ? NRW : 1][3];
     double js[NRW > 0 ? NRW : 1], ijs[NRW > 0 ? NRW : 1];
     double fc;
-    int32_t fsw_every, pad_;
+    int32_t fsw_every, sh_degree;
+    // spherical harmonics (GRAV == BSK_GRAV_SH only; unused kernarg fields cost no SGPRs)
+    const double* sh_tab;   // fused Pines stream, 8 doubles per (l, m) step, iteration order
+    double mu_over_req, req, inv_req, planet_rate;
 };
 
 // Cold constants of the 1 Hz control law (device memory, s_load-ed inside the FSW block only).
@@ -160,23 +163,99 @@ struct State {
 };
 
 // --------------------------------------------------------------------------------------------
-// gravity: point mass (+ closed-form J2): 15 / 22 fp64 ops.
+// Pines' normalised spherical-harmonic field (SURVEY.md §8 note N1), degree d, position in the
+// planet-fixed frame.  All lanes walk the same (l, m) sequence, so the coefficient stream is
+// wave-uniform and is read with SCALAR loads: the host fuses Cbar/Sbar/n1/n2/nq1/nq2 into one
+// stream in iteration order (bsk_capi.hip: build_sh_table), 8 doubles = one s_load_dwordx16 per
+// step, and the VALU takes them as SGPR operands.  Columns M = 1..d+1 of the derived Legendre
+// function A[L][M], L = M..d+1, are generated by the three-term recursion on B = w_L A[L][M]
+// (w_L = mu/(r Re) (Re/r)^(L+1) folded into the recursion), and each column's six coefficient
+// sums are combined with (Re, Im)(s + i t)^(M-1) once per column: 10 fp64 ops per (L, M).
+typedef const double __attribute__((address_space(4))) * CTab;
+
+template <class Hot>
+__device__ __forceinline__ V3 gravity_sh(const Hot& c, V3 p) {
+    const double r2 = dot(p, p);
+    const double ir = rsqrt_nr(r2);
+    const double s = p.x * ir, t = p.y * ir, u = p.z * ir;
+    const double rho = c.req * ir;              // Re / r
+    const double irho = r2 * ir * c.inv_req;    // r / Re
+    const double w0 = c.mu_over_req * ir * rho; // mu/(r Re) * (Re/r)
+    const double ur = u * rho, rr = rho * rho;
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = -w0;
+    double cr = 1.0, ci = 0.0, wM = w0;
+    double B1 = 0.0, B2 = 0.0, X1 = 0.0, X2 = 0.0, Y1 = 0.0, Y2 = 0.0, Z1 = 0.0, Z2 = 0.0;
+    const int d1 = c.sh_degree + 1;
+
+    // recursion step A[L][M] <- A[L-1][M], A[L-2][M] and the six coefficient sums (10 fp64 ops)
+    auto rec = [&](CTab q) {
+        const double B = fma(ur, q[0] * B1, -rr * (q[1] * B2));
+        B2 = B1;
+        B1 = B;
+        X1 = fma(B, q[2], X1); X2 = fma(B, q[3], X2);
+        Y1 = fma(B, q[4], Y1); Y2 = fma(B, q[5], Y2);
+        Z1 = fma(B, q[6], Z1); Z2 = fma(B, q[7], Z2);
+    };
+
+    // The stream is read with plain scalar loads, four entries (4 x s_load_dwordx16, 64 SGPRs) per
+    // wait, so one scalar-cache round trip is amortised over 40 fp64 ops.  (A two-tuple software
+    // pipeline through inline-asm loads was tried: hipcc copies an in-flight tuple at the loop
+    // back-edge before its wait, which reads SGPRs the load has not written yet.)
+    CTab e = (CTab)c.sh_tab;
+    for (int M = 1; M <= d1; ++M) {
+        wM *= rho;                               // column start: A[M][M] is the diagonal constant
+        B1 = wM * e[0];
+        B2 = 0.0;
+        X1 = B1 * e[2]; X2 = B1 * e[3]; Y1 = B1 * e[4]; Y2 = B1 * e[5]; Z1 = B1 * e[6]; Z2 = B1 * e[7];
+        e += 8;
+        int n = d1 - M;                          // entries left in this column
+        for (; n >= 4; n -= 4) {
+            rec(e); rec(e + 8); rec(e + 16); rec(e + 24);
+            e += 32;
+        }
+        for (; n > 0; --n) {
+            rec(e);
+            e += 8;
+        }
+        // column end: combine with (Re, Im)(s + i t)^(M-1), advance to (s + i t)^M
+        a1 = fma(cr, X1, fma(ci, X2, a1));
+        a2 = fma(cr, X2, fma(-ci, X1, a2));
+        a3 = fma(cr, Y1, fma(ci, Y2, a3));
+        a4 = fma(-irho, fma(cr, Z1, ci * Z2), a4);
+        const double ncr = fma(s, cr, -t * ci);
+        ci = fma(s, ci, t * cr);
+        cr = ncr;
+    }
+    return V3{fma(s, a4, a1), fma(t, a4, a2), fma(u, a4, a3)};
+}
+
+// --------------------------------------------------------------------------------------------
+// gravity: point mass (+ closed-form J2): 15 / 22 fp64 ops; spherical harmonics above.
+// tsim is only used by the harmonics (planet rotation about the inertial z axis).
 template <int GRAV, class Hot>
-__device__ __forceinline__ V3 gravity(const Hot& c, V3 r) {
-    double zz = r.z * r.z;
-    double r2 = fma(r.x, r.x, fma(r.y, r.y, zz));
-    double ir = rsqrt_nr(r2);
-    double ir2 = ir * ir;
-    double ir3 = ir * ir2;
-    double k0 = c.nmu * ir3;
-    if constexpr (GRAV == BSK_GRAV_PM_J2) {
-        double z2 = zz * ir2;               // (z/r)^2
-        double kj = c.j2k * (ir3 * ir2);    // 1.5 J2 mu Re^2 / r^5
-        double kxy = fma(kj, fma(5.0, z2, -1.0), k0);
-        double kz = fma(-2.0, kj, kxy);     // k0 + kj (5 z2 - 3)
-        return V3{kxy * r.x, kxy * r.y, kz * r.z};
+__device__ __forceinline__ V3 gravity(const Hot& c, V3 r, double tsim) {
+    if constexpr (GRAV == BSK_GRAV_SH) {
+        double sn, cs;
+        sincos(c.planet_rate * tsim, &sn, &cs);
+        const V3 pf = mk(fma(cs, r.x, sn * r.y), fma(cs, r.y, -sn * r.x), r.z);
+        const V3 af = gravity_sh(c, pf);
+        return mk(fma(cs, af.x, -sn * af.y), fma(sn, af.x, cs * af.y), af.z);
     } else {
-        return k0 * r;
+        double zz = r.z * r.z;
+        double r2 = fma(r.x, r.x, fma(r.y, r.y, zz));
+        double ir = rsqrt_nr(r2);
+        double ir2 = ir * ir;
+        double ir3 = ir * ir2;
+        double k0 = c.nmu * ir3;
+        if constexpr (GRAV == BSK_GRAV_PM_J2) {
+            double z2 = zz * ir2;               // (z/r)^2
+            double kj = c.j2k * (ir3 * ir2);    // 1.5 J2 mu Re^2 / r^5
+            double kxy = fma(kj, fma(5.0, z2, -1.0), k0);
+            double kz = fma(-2.0, kj, kxy);     // k0 + kj (5 z2 - 3)
+            return V3{kxy * r.x, kxy * r.y, kz * r.z};
+        } else {
+            return k0 * r;
+        }
     }
 }
 
@@ -188,9 +267,9 @@ __device__ __forceinline__ V3 gravity(const Hot& c, V3 r) {
 // friction), so the caller passes rhs0 = L_ext - sum tq_i g_i and tqj_i = tq_i / Js_i.
 template <int GRAV, int NRW, bool DIAG>
 __device__ __forceinline__ void eom(const HotCfg<NRW, DIAG>& c, const WheelV<NRW>& wv, const State<NRW>& x, V3 rhs0,
-                                    const double* tqj, State<NRW>& d) {
+                                    const double* tqj, double tsim, State<NRW>& d) {
     d.r = x.v;
-    d.v = gravity<GRAV>(c, x.r);
+    d.v = gravity<GRAV>(c, x.r, tsim);
     // sigma' = 1/4 [(1 - s^2) w + 2 s x w + 2 (s.w) s],  with hw = w/2:
     //        = (1 - s^2)/2 hw + s x hw + (s.hw) s
     V3 hw = 0.5 * x.w;
@@ -243,20 +322,20 @@ __device__ __forceinline__ void st_axpy(double a, const State<NRW>& k, const Sta
 // effector updates both once per dyn tick, outside the equations of motion).
 template <int GRAV, int NRW, bool DIAG>
 __device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, const WheelV<NRW>& wv, State<NRW>& x,
-                                         const double* u, V3 lext) {
+                                         const double* u, V3 lext, double t0) {
     State<NRW> k, xt, acc;
     double tqj[NRW > 0 ? NRW : 1];
     const V3 rhs0 = wheel_torque<NRW, DIAG>(c, wv, x.Om, u, lext, tqj);
-    eom<GRAV, NRW, DIAG>(c, wv, x, rhs0, tqj, k);
+    eom<GRAV, NRW, DIAG>(c, wv, x, rhs0, tqj, t0, k);
     st_axpy<NRW>(c.h6, k, x, acc);
     st_axpy<NRW>(c.h2, k, x, xt);
-    eom<GRAV, NRW, DIAG>(c, wv, xt, rhs0, tqj, k);
+    eom<GRAV, NRW, DIAG>(c, wv, xt, rhs0, tqj, t0 + c.h2, k);
     st_axpy<NRW>(c.h3, k, acc, acc);
     st_axpy<NRW>(c.h2, k, x, xt);
-    eom<GRAV, NRW, DIAG>(c, wv, xt, rhs0, tqj, k);
+    eom<GRAV, NRW, DIAG>(c, wv, xt, rhs0, tqj, t0 + c.h2, k);
     st_axpy<NRW>(c.h3, k, acc, acc);
     st_axpy<NRW>(c.h, k, x, xt);
-    eom<GRAV, NRW, DIAG>(c, wv, xt, rhs0, tqj, k);
+    eom<GRAV, NRW, DIAG>(c, wv, xt, rhs0, tqj, t0 + c.h, k);
     st_axpy<NRW>(c.h6, k, acc, x);
     double s2 = dot(x.s, x.s);
     if (s2 > 1.0) x.s = (-rcp_nr(s2)) * x.s;

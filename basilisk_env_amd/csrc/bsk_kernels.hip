@@ -68,6 +68,7 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs<NRW, DIAG> a) 
     WheelV<NRW> wv;
     wv.load(c);
     int j = 0;
+    int tick = cnt.y;
     while (j < substeps) {
         int m = substeps - j;
         if constexpr (NRW > 0) {
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs<NRW, DIAG> a) 
             phase = (phase + m == fsw_every) ? 0 : phase + m;
         }
         j += m;
-        for (int t = 0; t < m; ++t) rk4_step<GRAV, NRW, DIAG>(c, wv, x, u, lext);
+        for (int t = 0; t < m; ++t, ++tick) rk4_step<GRAV, NRW, DIAG>(c, wv, x, u, lext, (double)tick * c.h);
     }
 
     // Re-read the post-loop arguments from the kernarg segment through an opaque pointer: the
@@ -203,7 +204,12 @@ static void fill_hot(const StepParams& p, HotCfg<NRW, DIAG>& h) {
     }
     h.fc = p.f_coulomb;
     h.fsw_every = p.fsw_every;
-    h.pad_ = 0;
+    h.sh_degree = p.sh_degree;
+    h.sh_tab = p.sh_tab;
+    h.mu_over_req = p.mu / p.req;
+    h.req = p.req;
+    h.inv_req = 1.0 / p.req;
+    h.planet_rate = p.planet_rate;
 }
 
 template <int GRAV, int NRW, bool DIAG>
@@ -224,6 +230,8 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
 }
 
 #define BSK_VARIANTS(X)                                                                                     \
+    X(BSK_GRAV_SH, 0, true) X(BSK_GRAV_SH, 3, true) X(BSK_GRAV_SH, 4, true)                                  \
+    X(BSK_GRAV_SH, 0, false) X(BSK_GRAV_SH, 3, false) X(BSK_GRAV_SH, 4, false)                               \
     X(BSK_GRAV_PM, 0, true) X(BSK_GRAV_PM, 3, true) X(BSK_GRAV_PM, 4, true)                                  \
     X(BSK_GRAV_PM_J2, 0, true) X(BSK_GRAV_PM_J2, 3, true) X(BSK_GRAV_PM_J2, 4, true)                         \
     X(BSK_GRAV_PM, 0, false) X(BSK_GRAV_PM, 3, false) X(BSK_GRAV_PM, 4, false)                               \

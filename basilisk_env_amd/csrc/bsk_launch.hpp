@@ -47,6 +47,10 @@ struct StepParams {
     double f_coulomb;
     int32_t fsw_every;
     ObsCfg obs;
+    // spherical harmonics
+    double req, planet_rate;
+    const double* sh_tab;   // device
+    int32_t sh_degree;
 };
 
 struct StepBuffers {

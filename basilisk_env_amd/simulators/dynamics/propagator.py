@@ -82,6 +82,16 @@ class BatchedPropagator(object):
             raise RuntimeError("propagator is closed")
         return self._h
 
+    def set_gravity_sh(self, degree, cbar, sbar):
+        """Normalised spherical-harmonic coefficients, packed l*(l+1)/2+m (gravity_sh.sh_index);
+        required before stepping a handle created with gravity_model = GRAV_SH."""
+        from .gravity_sh import sh_size
+        cbar = np.ascontiguousarray(cbar, dtype=np.float64)
+        sbar = np.ascontiguousarray(sbar, dtype=np.float64)
+        if cbar.shape != (sh_size(degree),) or sbar.shape != cbar.shape:
+            raise ValueError("cbar/sbar must have %d entries for degree %d" % (sh_size(degree), degree))
+        check(self._lib.bsk_set_gravity_sh(self._handle(), int(degree), cbar.ctypes.data, sbar.ctypes.data))
+
     # ------------------------------------------------------------------ state
     def reset(self, ic, mask=None):
         ic = np.ascontiguousarray(ic, dtype=np.float64)

@@ -41,6 +41,8 @@ def parse():
     p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--envs", type=int, default=65536, help="spacecraft per GPU")
     p.add_argument("--substeps", type=int, default=1, help="RK4 sub-steps per env step")
+    p.add_argument("--gravity", choices=["j2", "sh"], default="j2",
+                   help="j2 = BASELINE configs[2] (headline); sh = configs[4], degree-70 spherical harmonics")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true")
     return p.parse_args()
@@ -90,6 +92,11 @@ def cpu_baseline(cfg, n_rw, substeps):
                       % (n, done_steps, substeps, el)}
 
 
+def _with_degree(cfg, degree):
+    cfg.sh_degree = degree
+    return cfg
+
+
 def main():
     a = parse()
     import numpy as np
@@ -114,15 +121,20 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    from basilisk_env_amd._lib import GRAV_PM_J2
+    from basilisk_env_amd._lib import GRAV_PM_J2, GRAV_SH
     from basilisk_env_amd.simulators.dynamics import BatchedPropagator, default_config
+    from basilisk_env_amd.simulators.dynamics.gravity_sh import synthetic_sh_coefficients
     from basilisk_env_amd.simulators.initial_conditions.batch import sample_ic_batch
 
     n_rw = 4
-    cfg = default_config(n_rw=n_rw, gravity_model=GRAV_PM_J2)
+    sh = a.gravity == "sh"
+    cfg = default_config(n_rw=n_rw, gravity_model=GRAV_SH if sh else GRAV_PM_J2)
     n = a.envs
     ic = sample_ic_batch(n, n_rw, seed=rank)       # rank r owns env indices [r*n, (r+1)*n)
-    prop = BatchedPropagator(cfg, n, device=local)
+    prop = BatchedPropagator(cfg if not sh else _with_degree(cfg, 70), n, device=local)
+    if sh:
+        cfg = prop.cfg
+        prop.set_gravity_sh(70, *synthetic_sh_coefficients(70))
     prop.reset(ic)
     d_act = torch.zeros(n, dtype=torch.int32, device="cuda")  # action 0 = nadir pointing (reward mode)
     torch.cuda.synchronize()
@@ -156,9 +168,11 @@ def main():
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[2]: %d envs/GPU, J2 gravity + 4 reaction wheels (pyramid) + "
+        "config": {"workload": "BASELINE configs[%s]: %d envs/GPU, %s gravity + 4 reaction wheels (pyramid) + "
                                "nadir-pointing reward, fp64, dt 0.1 s, %d RK4 sub-step(s) per env step, fsw every 10 "
-                               "sub-steps, synthetic random-orbit batch PCG64(rank)" % (n, a.substeps),
+                               "sub-steps, synthetic random-orbit batch PCG64(rank)"
+                               % ("4" if sh else "2", n, "degree-70 spherical-harmonic (synthetic Kaula field)" if sh else "J2",
+                                  a.substeps),
                    "envs_per_gpu": n, "substeps": a.substeps, "sharding": "env ranges, no step-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -170,7 +184,12 @@ def main():
     if gather_ms is not None:
         out["gather_ms"] = gather_ms
 
-    if rank == 0 and world == 1 and not a.no_extra:
+    if sh:
+        # config 5 is fp64-VALU bound: ~10 fp64 ops per (l, m) step, 2 556 steps per field evaluation
+        flop = 4 * (2556 * 19 + 400) * a.substeps
+        out["sh"] = {"degree": 70, "fp64_tflops_algorithmic": n * world * a.steps * flop / el / 1e12,
+                     "field_evals_per_s": n * world * a.steps * a.substeps * 4 / el}
+    if rank == 0 and world == 1 and not a.no_extra and not sh:
         extra = {}
         # reference-faithful env step: 180 s of sim time = 1 800 RK4 sub-steps, 180 FSW updates
         ksteps = 5
@@ -189,7 +208,7 @@ def main():
                             "frac_of_8TBs": BYTES_PER_ENV_STEP * nl / (km3 * 1e-3) / 1e9 / HBM_PEAK_GBS}
         big.close()
         out["extra"] = extra
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not sh:
         out["cpu_baseline"] = cpu_baseline(cfg, n_rw, a.substeps)
     prop.close()
     if rank == 0:

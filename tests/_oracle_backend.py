@@ -20,6 +20,11 @@ class OraclePropagator(object):
         self.steps = np.zeros(self.n_envs, np.int32)
         self.ticks = np.zeros(self.n_envs, np.int32)
         self._out = None
+        self._cbar = self._sbar = None
+
+    def set_gravity_sh(self, degree, cbar, sbar):
+        assert degree == self.cfg.sh_degree
+        self._cbar, self._sbar = np.array(cbar, dtype=np.float64), np.array(sbar, dtype=np.float64)
 
     def close(self):
         pass
@@ -47,7 +52,8 @@ class OraclePropagator(object):
         return self.steps.copy(), self.ticks.copy()
 
     def step(self, actions, substeps):
-        self._out = oracle.step(self.cfg, self.state, self.steps, self.ticks, np.asarray(actions, np.int32), substeps)
+        self._out = oracle.step(self.cfg, self.state, self.steps, self.ticks, np.asarray(actions, np.int32), substeps,
+                                cbar=self._cbar, sbar=self._sbar)
 
     def get_obs(self):
         return self._out
