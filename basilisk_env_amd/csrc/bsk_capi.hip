@@ -155,6 +155,18 @@ int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool&
     p.planet_rate = c.planet_rate;
     p.sh_tab = nullptr;
     p.sh_degree = 0;
+    p.power = (c.flags & BSK_FLAG_POWER) != 0;
+    {
+        const double AU = 149597870700.0, RSUN = 695000.0e3;
+        for (int i = 0; i < 3; ++i) { p.pc.nB[i] = c.panel_normal[i]; p.pc.sun_r0[i] = c.sun_r0[i]; p.pc.sun_v[i] = c.sun_v[i]; }
+        p.pc.kflux = c.panel_area * c.panel_efficiency * c.solar_flux * AU * AU;
+        p.pc.draw = c.power_draw;
+        p.pc.cap = c.storage_capacity;
+        p.pc.req = c.req;
+        p.pc.rsun = RSUN;
+        p.pc.rs_plus = RSUN + c.req;
+        p.pc.rs_minus = RSUN - c.req;
+    }
     k.u_max = c.u_max;
     k.u_min = c.u_min;
     k.K = c.K;
@@ -231,11 +243,13 @@ int validate(const bsk_config& c) {
         return fail(BSK_EINVAL, "unknown gravity_model");
     if (c.gravity_model == BSK_GRAV_SH && (c.sh_degree < 2 || c.sh_degree > BSK_MAX_SH_DEGREE))
         return fail(BSK_EINVAL, "sh_degree must be in 2..70 for BSK_GRAV_SH");
-    const uint32_t unbuilt = BSK_FLAG_SUN_THIRD_BODY | BSK_FLAG_POWER | BSK_FLAG_DESAT | BSK_FLAG_DRAG |
+    const uint32_t unbuilt = BSK_FLAG_SUN_THIRD_BODY | BSK_FLAG_DESAT | BSK_FLAG_DRAG |
                              BSK_FLAG_AUTO_RESET | BSK_FLAG_LDS_SCRATCH;
     if (c.flags & unbuilt) return fail(BSK_EINVAL, "config flag requests a feature that is not built in this version");
     if (!(c.mu > 0.0) || !(c.req > 0.0)) return fail(BSK_EINVAL, "mu and req must be positive");
     if (!(c.wheel_limit > 0.0) || !(c.power_max > 0.0)) return fail(BSK_EINVAL, "wheel_limit and power_max must be positive");
+    if ((c.flags & BSK_FLAG_POWER) && !(c.storage_capacity > 0.0 && c.sun_r0[0] * c.sun_r0[0] + c.sun_r0[1] * c.sun_r0[1] + c.sun_r0[2] * c.sun_r0[2] > 0.0))
+        return fail(BSK_EINVAL, "BSK_FLAG_POWER needs storage_capacity > 0 and a Sun position");
     return BSK_OK;
 }
 
@@ -274,7 +288,7 @@ int do_step(bsk_handle* h, const int* d_actions, int substeps) {
         e1 = h->ev[h->ev_used + 1];
         h->ev_used += 2;
     }
-    HIP_TRY(bsk::launch_step(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp, b, h->block, h->stream, e0, e1));
+    HIP_TRY(bsk::launch_step(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp.power, h->sp, b, h->block, h->stream, e0, e1));
     h->sim_time += substeps * h->cfg.dt;
     return BSK_OK;
 }
@@ -625,14 +639,14 @@ int bsk_profile_end(bsk_handle* h, double* mean_kernel_ms, int* n_launches) {
 int bsk_kernel_info(bsk_handle* h, char* name, int name_cap, int* vgprs, int* lds_bytes, int* block, int* grid) {
     if (!h) return fail(BSK_EINVAL, "handle is NULL");
     DeviceGuard guard(h->device);
-    const void* fp = bsk::step_kernel_ptr(h->cfg.gravity_model, h->cfg.n_rw, h->diag);
+    const void* fp = bsk::step_kernel_ptr(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp.power);
     if (!fp) return fail(BSK_EINVAL, "no kernel variant for this config");
     hipFuncAttributes at;
     HIP_TRY(hipFuncGetAttributes(&at, fp));
     if (name && name_cap > 0)
         std::snprintf(name, name_cap, "step_kernel<%s,%d,%s>",
                       h->cfg.gravity_model == BSK_GRAV_PM ? "PM" : (h->cfg.gravity_model == BSK_GRAV_PM_J2 ? "PM_J2" : "SH"), h->cfg.n_rw,
-                      h->diag ? "diag" : "full");
+                      h->sp.power ? (h->diag ? "diag,power" : "full,power") : (h->diag ? "diag" : "full"));
     if (vgprs) *vgprs = at.numRegs;
     if (lds_bytes) *lds_bytes = (int)at.sharedSizeBytes;
     if (block) *block = h->block;

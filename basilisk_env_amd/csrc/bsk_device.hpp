@@ -150,6 +150,84 @@ struct WheelV {
     }
 };
 
+// --------------------------------------------------------------------------------------------
+// Power system: eclipse -> simpleSolarPanel -> simpleBattery <- simplePowerSink,
+// reference wiring leoPowerAttitudeSimulator.py:286-288, 326-345, 363-366, parameters :158-167.
+struct PowerCfg {
+    double nB[3];            // panel normal, body frame
+    double kflux;            // panel_area * efficiency * solar_flux(1 AU) * AU^2   [W m^2]
+    double draw, cap;        // sink power [W] (negative), battery capacity [W s]
+    double req, rs_plus, rs_minus;  // planet radius, R_sun + R_planet, R_sun - R_planet
+    double rsun;
+    double sun_r0[3], sun_v[3];
+};
+
+// Per-launch Sun geometry (the Sun is held over the env step like the 180 s SPICE task): everything
+// that depends only on the Sun position is computed once, so the per-step eclipse test needs no
+// transcendental function outside the penumbra.
+struct SunGeom {
+    V3 sun;
+    double ism;              // 1 / |sun|
+    double re_sf1, re_sf2;   // Re / sin f1, Re / sin f2   (penumbra / umbra cone half-angles)
+    double tf1, tf2;         // tan f1, tan f2
+};
+
+__device__ __forceinline__ SunGeom sun_setup(const PowerCfg& pc, double t0) {
+    SunGeom g;
+    g.sun = mk(fma(pc.sun_v[0], t0, pc.sun_r0[0]), fma(pc.sun_v[1], t0, pc.sun_r0[1]), fma(pc.sun_v[2], t0, pc.sun_r0[2]));
+    g.ism = rsqrt_nr(dot(g.sun, g.sun));
+    const double sf1 = pc.rs_plus * g.ism, sf2 = pc.rs_minus * g.ism;
+    g.re_sf1 = pc.req * rcp_nr(sf1);
+    g.re_sf2 = pc.req * rcp_nr(sf2);
+    g.tf1 = sf1 * rsqrt_nr(fma(-sf1, sf1, 1.0));
+    g.tf2 = sf2 * rsqrt_nr(fma(-sf2, sf2, 1.0));
+    return g;
+}
+
+// visible fraction of the solar disc inside the shadow cones: total eclipse is decided on cosines
+// (no inverse trigonometry); only partial / annular phases take the asin/acos path.
+__device__ __forceinline__ double percent_shadow(const PowerCfg& pc, V3 r_HB, V3 r, double r2) {
+    const double nh2 = dot(r_HB, r_HB);
+    const double inh = rsqrt_nr(nh2), ins = rsqrt_nr(r2);
+    const double sa = fmin(pc.rsun * inh, 1.0), sb = fmin(pc.req * ins, 1.0);   // sin a, sin b
+    const double cc = fmax(fmin(-dot(r, r_HB) * inh * ins, 1.0), -1.0);         // cos c
+    const double ca = sqrt_nr(fma(-sa, sa, 1.0)), cb = sqrt_nr(fma(-sb, sb, 1.0));
+    if (sb > sa && cc > fma(cb, ca, sb * sa)) return 0.0;                       // c < b - a : total
+    if (cc <= fma(cb, ca, -(sb * sa))) return 1.0;                              // c >= a + b : none
+    const double a = asin(sa), b = asin(sb), c = acos(cc);
+    if (c < a - b) return 1.0 - (b * b) / (a * a);                              // annular
+    const double x = (c * c + a * a - b * b) / (2.0 * c), y = sqrt(fmax(a * a - x * x, 0.0));
+    const double area = a * a * acos(x / a) + b * b * acos((c - x) / b) - c * y;
+    return 1.0 - area / (3.14159265358979323846 * a * a);
+}
+
+__device__ __forceinline__ double shadow_factor(const PowerCfg& pc, const SunGeom& g, V3 r) {
+    const double rs = dot(r, g.sun), r2 = dot(r, r);
+    if (r2 < 2.0 * rs) return 1.0;                       // day side of the planet
+    const double s0 = -rs * g.ism;
+    const double c1 = s0 + g.re_sf1, c2 = s0 - g.re_sf2;
+    const double l2v = fma(-s0, s0, r2);                 // squared distance from the shadow axis
+    const double l1 = c1 * g.tf1, l2 = c2 * g.tf2;
+    if (l2v < l2 * l2 || l2v < l1 * l1) return percent_shadow(pc, g.sun - r, r, r2);
+    return 1.0;
+}
+
+// one EnvTask tick: shadow factor, panel power, Euler battery update with clamping
+__device__ __forceinline__ void power_step(const PowerCfg& pc, const SunGeom& g, V3 r, V3 sig, double h, double& charge,
+                                           double& shadow) {
+    shadow = shadow_factor(pc, g, r);
+    const V3 d = g.sun - r;
+    const double d2 = dot(d, d), id = rsqrt_nr(d2);
+    const V3 sN = id * d;
+    // sB = [BN] sN with C = I + (8 s~^2 - 4 (1 - s^2) s~) / (1 + s^2)^2
+    const double q2 = dot(sig, sig), op = 1.0 + q2, iop2 = rcp_nr(op * op);
+    const V3 t1 = cross(sig, sN), t2 = cross(sig, t1);
+    const V3 sB = sN + (8.0 * iop2) * t2 - (4.0 * (1.0 - q2) * iop2) * t1;
+    const double proj = fmax(fma(pc.nB[0], sB.x, fma(pc.nB[1], sB.y, pc.nB[2] * sB.z)), 0.0);
+    const double p = fma(pc.kflux * (id * id), proj * shadow, pc.draw);
+    charge = fmin(fmax(fma(p, h, charge), 0.0), pc.cap);
+}
+
 template <bool DIAG>
 __device__ __forceinline__ V3 mv3(const double* m, V3 v) {
     if constexpr (DIAG) return V3{m[0] * v.x, m[1] * v.y, m[2] * v.z};

@@ -24,7 +24,7 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-template <int GRAV, int NRW, bool DIAG>
+template <int GRAV, int NRW, bool DIAG, bool POWER>
 __global__ __launch_bounds__(256) void step_kernel(const StepArgs<NRW, DIAG> a) {
     const HotCfg<NRW, DIAG>& c = a.hot;
     const ColdCfg* __restrict__ cold = a.cold;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs<NRW, DIAG> a) 
     constexpr int TAIL = BSK_NF_BASE + NRW;
     const V3 lext = mk(ldf(FLD(TAIL + BSK_T_LEXT + 0), bo), ldf(FLD(TAIL + BSK_T_LEXT + 1), bo),
                        ldf(FLD(TAIL + BSK_T_LEXT + 2), bo));
-    const double charge = ldf(FLD(TAIL + BSK_T_CHARGE), bo);
+    double charge = ldf(FLD(TAIL + BSK_T_CHARGE), bo);
     const int2 cnt = *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(a.cnt) + bo);  // {steps | phase << 20, ticks}
     const int action = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(a.act) + (bo >> 1));
     double u[NRW > 0 ? NRW : 1];
@@ -69,6 +69,9 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs<NRW, DIAG> a) 
     wv.load(c);
     int j = 0;
     int tick = cnt.y;
+    double shadow = 1.0;
+    SunGeom sg;
+    if constexpr (POWER) sg = sun_setup(a.power, (double)tick * c.h);
     while (j < substeps) {
         int m = substeps - j;
         if constexpr (NRW > 0) {
@@ -81,7 +84,10 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs<NRW, DIAG> a) 
             phase = (phase + m == fsw_every) ? 0 : phase + m;
         }
         j += m;
-        for (int t = 0; t < m; ++t, ++tick) rk4_step<GRAV, NRW, DIAG>(c, wv, x, u, lext, (double)tick * c.h);
+        for (int t = 0; t < m; ++t, ++tick) {
+            rk4_step<GRAV, NRW, DIAG>(c, wv, x, u, lext, (double)tick * c.h);
+            if constexpr (POWER) power_step(a.power, sg, x.r, x.s, c.h, charge, shadow);
+        }
     }
 
     // Re-read the post-loop arguments from the kernarg segment through an opaque pointer: the
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs<NRW, DIAG> a) 
     for (int k = 0; k < NRW; ++k) om2 = fma(x.Om[k], x.Om[k], om2);
     const double o2 = sqrt_nr(om2) * tp->obs_cfg.inv_wheel_limit;
     const double o3 = charge * tp->obs_cfg.charge_scale;
-    const double o4 = 1.0;
+    const double o4 = shadow;
 
     // reward and termination
     int why = 0;
@@ -133,6 +139,7 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs<NRW, DIAG> a) 
         stf(FLD(BSK_F_OMEGA + 0), bo, x.w.x); stf(FLD(BSK_F_OMEGA + 1), bo, x.w.y); stf(FLD(BSK_F_OMEGA + 2), bo, x.w.z);
 #pragma unroll
         for (int k = 0; k < NRW; ++k) stf(FLD(BSK_NF_BASE + k), bo, x.Om[k]);
+        if constexpr (POWER) stf(FLD(TAIL + BSK_T_CHARGE), bo, charge);
         if constexpr (NRW > 0) {
             if (fsw_ran) {
 #pragma unroll
@@ -212,43 +219,45 @@ static void fill_hot(const StepParams& p, HotCfg<NRW, DIAG>& h) {
     h.planet_rate = p.planet_rate;
 }
 
-template <int GRAV, int NRW, bool DIAG>
+template <int GRAV, int NRW, bool DIAG, bool POWER>
 static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block, hipStream_t s, hipEvent_t ev0,
                            hipEvent_t ev1) {
     StepArgs<NRW, DIAG> a;
     fill_hot<GRAV, NRW, DIAG>(p, a.hot);
     a.cold = b.cold; a.st = b.st; a.cnt = b.cnt; a.act = b.act;
     a.stride = b.stride; a.n = b.n; a.substeps = b.substeps;
+    a.power = p.pc;
     a.tail.obs_cfg = p.obs; a.tail.st = b.st; a.tail.cnt = b.cnt; a.tail.obs = b.obs; a.tail.reward = b.reward;
     a.tail.done_mask = b.done_mask; a.tail.reason = b.reason; a.tail.wave_reward = b.wave_reward;
     a.tail.stride = b.stride; a.tail.n = b.n; a.tail.substeps = b.substeps;
     const int grid = (b.n + block - 1) / block;
     // hipExtLaunchKernelGGL stamps ev0/ev1 from the dispatch packet itself (no marker packets), so
     // their difference is the kernel's own duration, as rocprofv3 --kernel-trace reports it.
-    hipExtLaunchKernelGGL((step_kernel<GRAV, NRW, DIAG>), dim3(grid), dim3(block), 0, s, ev0, ev1, 0, a);
+    hipExtLaunchKernelGGL((step_kernel<GRAV, NRW, DIAG, POWER>), dim3(grid), dim3(block), 0, s, ev0, ev1, 0, a);
     return hipGetLastError();
 }
 
-#define BSK_VARIANTS(X)                                                                                     \
-    X(BSK_GRAV_SH, 0, true) X(BSK_GRAV_SH, 3, true) X(BSK_GRAV_SH, 4, true)                                  \
-    X(BSK_GRAV_SH, 0, false) X(BSK_GRAV_SH, 3, false) X(BSK_GRAV_SH, 4, false)                               \
-    X(BSK_GRAV_PM, 0, true) X(BSK_GRAV_PM, 3, true) X(BSK_GRAV_PM, 4, true)                                  \
-    X(BSK_GRAV_PM_J2, 0, true) X(BSK_GRAV_PM_J2, 3, true) X(BSK_GRAV_PM_J2, 4, true)                         \
-    X(BSK_GRAV_PM, 0, false) X(BSK_GRAV_PM, 3, false) X(BSK_GRAV_PM, 4, false)                               \
-    X(BSK_GRAV_PM_J2, 0, false) X(BSK_GRAV_PM_J2, 3, false) X(BSK_GRAV_PM_J2, 4, false)
+#define BSK_VARIANTS_P(X, P)                                                                                \
+    X(BSK_GRAV_SH, 0, true, P) X(BSK_GRAV_SH, 3, true, P) X(BSK_GRAV_SH, 4, true, P)                         \
+    X(BSK_GRAV_SH, 0, false, P) X(BSK_GRAV_SH, 3, false, P) X(BSK_GRAV_SH, 4, false, P)                      \
+    X(BSK_GRAV_PM, 0, true, P) X(BSK_GRAV_PM, 3, true, P) X(BSK_GRAV_PM, 4, true, P)                         \
+    X(BSK_GRAV_PM_J2, 0, true, P) X(BSK_GRAV_PM_J2, 3, true, P) X(BSK_GRAV_PM_J2, 4, true, P)                \
+    X(BSK_GRAV_PM, 0, false, P) X(BSK_GRAV_PM, 3, false, P) X(BSK_GRAV_PM, 4, false, P)                      \
+    X(BSK_GRAV_PM_J2, 0, false, P) X(BSK_GRAV_PM_J2, 3, false, P) X(BSK_GRAV_PM_J2, 4, false, P)
+#define BSK_VARIANTS(X) BSK_VARIANTS_P(X, false) BSK_VARIANTS_P(X, true)
 
-hipError_t launch_step(int grav, int nrw, bool diag, const StepParams& p, const StepBuffers& b, int block,
+hipError_t launch_step(int grav, int nrw, bool diag, bool power, const StepParams& p, const StepBuffers& b, int block,
                        hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-#define CASE(G, R, D) \
-    if (grav == G && nrw == R && diag == D) return launch_t<G, R, D>(p, b, block, s, ev0, ev1);
+#define CASE(G, R, D, P) \
+    if (grav == G && nrw == R && diag == D && power == P) return launch_t<G, R, D, P>(p, b, block, s, ev0, ev1);
     BSK_VARIANTS(CASE)
 #undef CASE
     return hipErrorInvalidValue;
 }
 
-const void* step_kernel_ptr(int grav, int nrw, bool diag) {
-#define CASE(G, R, D) \
-    if (grav == G && nrw == R && diag == D) return (const void*)&step_kernel<G, R, D>;
+const void* step_kernel_ptr(int grav, int nrw, bool diag, bool power) {
+#define CASE(G, R, D, P) \
+    if (grav == G && nrw == R && diag == D && power == P) return (const void*)&step_kernel<G, R, D, P>;
     BSK_VARIANTS(CASE)
 #undef CASE
     return nullptr;

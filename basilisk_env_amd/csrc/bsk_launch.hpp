@@ -36,6 +36,7 @@ struct StepArgs {
     int64_t stride;
     int n;
     int substeps;
+    PowerCfg power;               // read only by the POWER variants
     TailArgs tail;
 };
 
@@ -51,6 +52,8 @@ struct StepParams {
     double req, planet_rate;
     const double* sh_tab;   // device
     int32_t sh_degree;
+    bool power;
+    PowerCfg pc;
 };
 
 struct StepBuffers {
@@ -68,9 +71,9 @@ struct StepBuffers {
     int substeps;
 };
 
-hipError_t launch_step(int grav, int nrw, bool diag, const StepParams& p, const StepBuffers& b, int block,
+hipError_t launch_step(int grav, int nrw, bool diag, bool power, const StepParams& p, const StepBuffers& b, int block,
                        hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
-const void* step_kernel_ptr(int grav, int nrw, bool diag);
+const void* step_kernel_ptr(int grav, int nrw, bool diag, bool power);
 hipError_t launch_stats(const double* wave_reward, const unsigned long long* done_mask, int n_waves, double* out_sum,
                         long long* out_done, hipStream_t s);
 hipError_t launch_scatter_reset(double* st, int64_t stride, int nf, const double* ic, const int* idx, int m, int2* cnt,

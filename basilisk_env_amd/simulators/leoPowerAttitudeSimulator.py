@@ -12,7 +12,7 @@ import math
 
 import numpy as np
 
-from .._lib import GRAV_PM
+from .._lib import FLAG_POWER, GRAV_PM
 from .dynamics import config as _config
 from .dynamics.effectorPrimatives import actuatorPrimatives as ap
 from .dynamics.propagator import BatchedPropagator, pack_ic
@@ -83,6 +83,7 @@ class LEOPowerAttitudeSimulator(object):
         cfg.panel_efficiency = float(ic.get("panelEfficiency"))
         for j in range(3):
             cfg.panel_normal[j] = float(ic.get("nHat_B")[j])
+        cfg.flags |= FLAG_POWER   # eclipse + solar panel + battery + sink, as the reference wires them (:286-288, 326-345)
         self.cfg = cfg
 
         factory = propagator_factory or BatchedPropagator

@@ -139,8 +139,6 @@ typedef struct {
     int deg;
     const double *cbar, *sbar;     /* packed l(l+1)/2+m                                        */
     double *abar, *n1, *n2, *nq1, *nq2; /* (deg+2)x(deg+2) square, row l col m                 */
-    /* sun */
-    double sun[3];
 } orc_ctx;
 
 #define SQ(l, m) ((l) * (ctx->deg + 2) + (m))
@@ -217,7 +215,7 @@ static void sh_field(orc_ctx* ctx, const double pos[3], double acc[3]) {
  * (disturbance torque), :301-310 + actuatorPrimatives.py:7-63 (wheels).  */
 #define NX (12 + BSK_MAX_RW)
 
-static void gravity(orc_ctx* ctx, const double r[3], double t, double a[3]) {
+static void gravity(orc_ctx* ctx, const double r[3], double t, const double sun[3], double a[3]) {
     const bsk_config* c = ctx->c;
     if (c->gravity_model == BSK_GRAV_SH) {
         /* planet-fixed frame = R3(planet_rate * t) from inertial */
@@ -239,9 +237,9 @@ static void gravity(orc_ctx* ctx, const double r[3], double t, double a[3]) {
     }
     if (c->flags & BSK_FLAG_SUN_THIRD_BODY) {
         /* third-body perturbation relative to the central body (…Simulator.py:227-229) */
-        double d[3]; v3sub(ctx->sun, r, d);
-        double dm = v3norm(d), sm = v3norm(ctx->sun);
-        for (int k = 0; k < 3; ++k) a[k] += c->mu_sun * (d[k] / (dm * dm * dm) - ctx->sun[k] / (sm * sm * sm));
+        double d[3]; v3sub(sun, r, d);
+        double dm = v3norm(d), sm = v3norm(sun);
+        for (int k = 0; k < 3; ++k) a[k] += c->mu_sun * (d[k] / (dm * dm * dm) - sun[k] / (sm * sm * sm));
     }
 }
 
@@ -260,12 +258,12 @@ static void wheel_torque(orc_ctx* ctx, const double x[NX], const double u[BSK_MA
 }
 
 static void eom(orc_ctx* ctx, const double x[NX], const double tq[BSK_MAX_RW], const double lext[3], double t,
-                double dx[NX]) {
+                const double sun[3], double dx[NX]) {
     const bsk_config* c = ctx->c;
     const double *r = x, *v = x + 3, *sg = x + 6, *w = x + 9, *Om = x + 12;
     /* translation */
     v3copy(v, dx);
-    gravity(ctx, r, t, dx + 3);
+    gravity(ctx, r, t, sun, dx + 3);
     /* MRP kinematics: sigma' = 1/4 [(1 - s^2) I + 2 s~ + 2 s s^T] omega */
     double s2 = v3dot(sg, sg), sw = v3dot(sg, w), cx[3];
     v3cross(sg, w, cx);
@@ -288,16 +286,17 @@ static void eom(orc_ctx* ctx, const double x[NX], const double tq[BSK_MAX_RW], c
 
 /* classic RK4 (Basilisk default integrator svIntegratorRK4; the reference never selects another,
  * …Simulator.py:213-214), then the MRP shadow-set switch once per completed step. */
-static void rk4_step(orc_ctx* ctx, double x[NX], const double ucmd[BSK_MAX_RW], const double lext[3], double t, double h) {
+static void rk4_step(orc_ctx* ctx, double x[NX], const double ucmd[BSK_MAX_RW], const double lext[3], double t, double h,
+                     const double sun[3]) {
     double k[NX], xt[NX], acc[NX], u[BSK_MAX_RW];
     wheel_torque(ctx, x, ucmd, u); /* motor + friction torque, held over the step */
-    eom(ctx, x, u, lext, t, k);
+    eom(ctx, x, u, lext, t, sun, k);
     for (int i = 0; i < NX; ++i) { acc[i] = x[i] + h / 6.0 * k[i]; xt[i] = x[i] + 0.5 * h * k[i]; }
-    eom(ctx, xt, u, lext, t + 0.5 * h, k);
+    eom(ctx, xt, u, lext, t + 0.5 * h, sun, k);
     for (int i = 0; i < NX; ++i) { acc[i] += h / 3.0 * k[i]; xt[i] = x[i] + 0.5 * h * k[i]; }
-    eom(ctx, xt, u, lext, t + 0.5 * h, k);
+    eom(ctx, xt, u, lext, t + 0.5 * h, sun, k);
     for (int i = 0; i < NX; ++i) { acc[i] += h / 3.0 * k[i]; xt[i] = x[i] + h * k[i]; }
-    eom(ctx, xt, u, lext, t + h, k);
+    eom(ctx, xt, u, lext, t + h, sun, k);
     for (int i = 0; i < NX; ++i) x[i] = acc[i] + h / 6.0 * k[i];
     double s2 = v3dot(x + 6, x + 6);
     if (s2 > 1.0) v3scale(-1.0 / s2, x + 6, x + 6);
@@ -450,8 +449,7 @@ int orc_step(const bsk_config* c, int n, double* state, int32_t* steps, int32_t*
     orc_ctx ctx;
     if (ctx_init(&ctx, c, cbar, sbar)) return -1;
     const int nrw = c->n_rw, tail = BSK_NF_BASE + nrw;
-    /* Sun position held over the env step, like the 180 s SPICE task (…Simulator.py:102,357) */
-    for (int k = 0; k < 3; ++k) ctx.sun[k] = c->sun_r0[k] + c->sun_v[k] * sim_time0;
+    (void)sim_time0;
 #define S(f, i) state[(size_t)(f) * n + (i)]
 #ifdef ORC_OMP
 #pragma omp parallel for schedule(static)
@@ -463,6 +461,10 @@ int orc_step(const bsk_config* c, int n, double* state, int32_t* steps, int32_t*
         for (int i = 0; i < BSK_MAX_RW; ++i) u[i] = S(tail + BSK_T_UCMD + i, e);
         double charge = S(tail + BSK_T_CHARGE, e), shadow = 1.0;
         int act = actions[e], tick = ticks[e];
+        /* Sun position: evaluated at the start of the env step from this spacecraft's own clock and
+           held over the step, like the 180 s SPICE task (…Simulator.py:102,357) */
+        double sun[3];
+        for (int k = 0; k < 3; ++k) sun[k] = c->sun_r0[k] + c->sun_v[k] * (tick * c->dt);
         for (int j = 0; j < substeps; ++j, ++tick) {
             if (nrw > 0 && tick % c->fsw_every == 0) {
                 att_guid g;
@@ -470,12 +472,12 @@ int orc_step(const bsk_config* c, int n, double* state, int32_t* steps, int32_t*
                 control(&ctx, &g, u);
             }
             double t = tick * c->dt;
-            rk4_step(&ctx, x, u, lext, t, c->dt);
+            rk4_step(&ctx, x, u, lext, t, c->dt, sun);
             if (c->flags & BSK_FLAG_POWER) {
                 /* EnvTask at the dyn rate (…Simulator.py:363-366): eclipse -> panel -> battery */
-                shadow = shadow_factor(c, x, ctx.sun);
+                shadow = shadow_factor(c, x, sun);
                 double bn[9], sB[3], sN[3];
-                v3sub(ctx.sun, x, sN);
+                v3sub(sun, x, sN);
                 double d = v3norm(sN);
                 v3scale(1.0 / d, sN, sN);
                 mrp2c(x + 6, bn);
@@ -497,7 +499,7 @@ int orc_step(const bsk_config* c, int n, double* state, int32_t* steps, int32_t*
         for (int i = 0; i < nrw; ++i) o2 += x[12 + i] * x[12 + i];
         o2 = sqrt(o2) / c->wheel_limit;
         double o3 = charge / 3600.0 / c->power_max;
-        if (c->flags & BSK_FLAG_POWER) shadow = shadow_factor(c, x, ctx.sun);
+        if (c->flags & BSK_FLAG_POWER) shadow = shadow_factor(c, x, sun);
         /* reward and termination (leoPowerAttitudeEnvironment.py:98-127, 161-170) */
         uint8_t why = 0;
         double rw = (act == 0) ? c->reward_mult / (1.0 + o0 * o0) : 0.0;
@@ -534,8 +536,9 @@ int orc_get_threads(void) { return 1; }
 int orc_gravity(const bsk_config* c, const double* cbar, const double* sbar, const double r[3], double t, double a[3]) {
     orc_ctx ctx;
     if (ctx_init(&ctx, c, cbar, sbar)) return -1;
-    for (int k = 0; k < 3; ++k) ctx.sun[k] = c->sun_r0[k] + c->sun_v[k] * t;
-    gravity(&ctx, r, t, a);
+    double sun[3];
+    for (int k = 0; k < 3; ++k) sun[k] = c->sun_r0[k] + c->sun_v[k] * t;
+    gravity(&ctx, r, t, sun, a);
     ctx_free(&ctx);
     return 0;
 }
@@ -547,7 +550,9 @@ int orc_eom(const bsk_config* c, const double* x, const double* u, const double*
     memcpy(uu, u, sizeof(double) * c->n_rw);
     double tq[BSK_MAX_RW];
     wheel_torque(&ctx, xx, uu, tq);
-    eom(&ctx, xx, tq, lext, t, dd);
+    double sun[3];
+    for (int k = 0; k < 3; ++k) sun[k] = c->sun_r0[k] + c->sun_v[k] * t;
+    eom(&ctx, xx, tq, lext, t, sun, dd);
     memcpy(dx, dd, sizeof(double) * (12 + c->n_rw));
     ctx_free(&ctx);
     return 0;

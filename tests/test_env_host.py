@@ -129,6 +129,7 @@ def test_battery_empty_termination():
     env.reset()
     ic = dict(env.simulator.initial_conditions)
     ic["storedCharge_Init"] = 0.0
+    ic["panelEfficiency"] = 0.0          # dead panel: the -5 W sink keeps the battery at the lower clamp
     env.simulator = LEOPowerAttitudeSimulator(.1, 1.0, 180., ic, **KW)
     ob, reward, done, info = env.step(0)
     assert done and ob[3, 0] == 0
