@@ -155,7 +155,18 @@ int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool&
     p.planet_rate = c.planet_rate;
     p.sh_tab = nullptr;
     p.sh_degree = 0;
-    p.power = (c.flags & BSK_FLAG_POWER) != 0;
+    const bool full = (c.flags & (BSK_FLAG_SUN_THIRD_BODY | BSK_FLAG_DRAG)) != 0;
+    p.feat = full ? bsk::FEAT_FULL : ((c.flags & BSK_FLAG_POWER) ? bsk::FEAT_POWER : bsk::FEAT_BARE);
+    p.ex.mu_sun = (c.flags & BSK_FLAG_SUN_THIRD_BODY) ? c.mu_sun : 0.0;
+    p.ex.base_density = (c.flags & BSK_FLAG_DRAG) ? c.base_density : 0.0;
+    p.ex.inv_scale_height = c.scale_height > 0.0 ? 1.0 / c.scale_height : 0.0;
+    p.ex.inv_mass = c.mass > 0.0 ? 1.0 / c.mass : 0.0;
+    p.ex.rho_skip = 1e-25;
+    k.n_facets = c.n_facets;
+    for (int i = 0; i < 8; ++i) {
+        k.facet_acd[i] = c.facet_area[i] * c.facet_cd[i];
+        for (int j = 0; j < 3; ++j) { k.facet_n[i][j] = c.facet_normal[i][j]; k.facet_r[i][j] = c.facet_pos[i][j]; }
+    }
     {
         const double AU = 149597870700.0, RSUN = 695000.0e3;
         for (int i = 0; i < 3; ++i) { p.pc.nB[i] = c.panel_normal[i]; p.pc.sun_r0[i] = c.sun_r0[i]; p.pc.sun_v[i] = c.sun_v[i]; }
@@ -243,8 +254,11 @@ int validate(const bsk_config& c) {
         return fail(BSK_EINVAL, "unknown gravity_model");
     if (c.gravity_model == BSK_GRAV_SH && (c.sh_degree < 2 || c.sh_degree > BSK_MAX_SH_DEGREE))
         return fail(BSK_EINVAL, "sh_degree must be in 2..70 for BSK_GRAV_SH");
-    const uint32_t unbuilt = BSK_FLAG_SUN_THIRD_BODY | BSK_FLAG_DESAT | BSK_FLAG_DRAG |
-                             BSK_FLAG_AUTO_RESET | BSK_FLAG_LDS_SCRATCH;
+    const uint32_t unbuilt = BSK_FLAG_DESAT | BSK_FLAG_AUTO_RESET | BSK_FLAG_LDS_SCRATCH;
+    if ((c.flags & (BSK_FLAG_SUN_THIRD_BODY | BSK_FLAG_DRAG)) && !(c.flags & BSK_FLAG_POWER))
+        return fail(BSK_EINVAL, "BSK_FLAG_SUN_THIRD_BODY / BSK_FLAG_DRAG are built in the full-scenario kernel: set BSK_FLAG_POWER too");
+    if ((c.flags & BSK_FLAG_DRAG) && (c.n_facets < 0 || c.n_facets > 8 || !(c.scale_height > 0.0) || !(c.mass > 0.0)))
+        return fail(BSK_EINVAL, "BSK_FLAG_DRAG needs 0..8 facets, scale_height > 0 and mass > 0");
     if (c.flags & unbuilt) return fail(BSK_EINVAL, "config flag requests a feature that is not built in this version");
     if (!(c.mu > 0.0) || !(c.req > 0.0)) return fail(BSK_EINVAL, "mu and req must be positive");
     if (!(c.wheel_limit > 0.0) || !(c.power_max > 0.0)) return fail(BSK_EINVAL, "wheel_limit and power_max must be positive");
@@ -288,7 +302,7 @@ int do_step(bsk_handle* h, const int* d_actions, int substeps) {
         e1 = h->ev[h->ev_used + 1];
         h->ev_used += 2;
     }
-    HIP_TRY(bsk::launch_step(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp.power, h->sp, b, h->block, h->stream, e0, e1));
+    HIP_TRY(bsk::launch_step(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp.feat, h->sp, b, h->block, h->stream, e0, e1));
     h->sim_time += substeps * h->cfg.dt;
     return BSK_OK;
 }
@@ -373,6 +387,16 @@ int bsk_default_config(bsk_config* c, int n_rw, int gravity_model) {
     c->thr_min_fire_time = 0.002;
     c->base_density = 1.22;
     c->scale_height = 8.0e3;
+    // 6U cubesat facets + two 1x2 m panels, Cd 2.2 (leoPowerAttitudeSimulator.py:272-281)
+    const double fa[8] = {0.2 * 0.3, 0.2 * 0.3, 0.1 * 0.2, 0.1 * 0.2, 0.1 * 0.3, 0.1 * 0.3, 1. * 2., 1. * 2.};
+    const double fn[8][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}, {0, 1, 0}, {0, -1, 0}};
+    const double fp[8][3] = {{0.05, 0, 0}, {0.05, 0, 0}, {0, 0.15, 0}, {0, -0.15, 0}, {0, 0, 0.1}, {0, 0, -0.1}, {0, 2., 0}, {0, 2., 0}};
+    c->n_facets = 8;
+    for (int i = 0; i < 8; ++i) {
+        c->facet_area[i] = fa[i];
+        c->facet_cd[i] = 2.2;
+        for (int k = 0; k < 3; ++k) { c->facet_normal[i][k] = fn[i][k]; c->facet_pos[i][k] = fp[i][k]; }
+    }
     return BSK_OK;
 }
 
@@ -639,14 +663,15 @@ int bsk_profile_end(bsk_handle* h, double* mean_kernel_ms, int* n_launches) {
 int bsk_kernel_info(bsk_handle* h, char* name, int name_cap, int* vgprs, int* lds_bytes, int* block, int* grid) {
     if (!h) return fail(BSK_EINVAL, "handle is NULL");
     DeviceGuard guard(h->device);
-    const void* fp = bsk::step_kernel_ptr(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp.power);
+    const void* fp = bsk::step_kernel_ptr(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp.feat);
     if (!fp) return fail(BSK_EINVAL, "no kernel variant for this config");
     hipFuncAttributes at;
     HIP_TRY(hipFuncGetAttributes(&at, fp));
     if (name && name_cap > 0)
         std::snprintf(name, name_cap, "step_kernel<%s,%d,%s>",
                       h->cfg.gravity_model == BSK_GRAV_PM ? "PM" : (h->cfg.gravity_model == BSK_GRAV_PM_J2 ? "PM_J2" : "SH"), h->cfg.n_rw,
-                      h->sp.power ? (h->diag ? "diag,power" : "full,power") : (h->diag ? "diag" : "full"));
+                      h->sp.feat == 2 ? (h->diag ? "diag,scenario" : "full,scenario")
+                                      : (h->sp.feat == 1 ? (h->diag ? "diag,power" : "full,power") : (h->diag ? "diag" : "full")));
     if (vgprs) *vgprs = at.numRegs;
     if (lds_bytes) *lds_bytes = (int)at.sharedSizeBytes;
     if (block) *block = h->block;

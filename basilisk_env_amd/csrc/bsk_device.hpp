@@ -117,6 +117,10 @@ struct ColdCfg {
     double u_max, u_min;
     double K, P;
     double sigma_R0N[3];
+    // facetDragDynamicEffector geometry (read only inside the drag branch)
+    double facet_acd[8];        // area * Cd
+    double facet_n[8][3], facet_r[8][3];
+    int32_t n_facets, pad_;
 };
 
 // Guidance / observation / reward constants: by value in the kernarg (used once per launch, outside
@@ -148,6 +152,19 @@ struct WheelV {
             js[i] = to_vgpr(c.js[i]); ijs[i] = to_vgpr(c.ijs[i]);
         }
     }
+};
+
+// Feature level of a kernel variant (template parameter FEAT):
+//   0 bare propagator (the bench headline), 1 + power system, 2 full scenario = power + the
+//   wave-uniform runtime switches below (Sun third-body gravity, atmospheric drag).
+enum { FEAT_BARE = 0, FEAT_POWER = 1, FEAT_FULL = 2 };
+
+// Sun third-body gravity (leoPowerAttitudeSimulator.py:227-232) and exponentialAtmosphere +
+// facet drag (:265-284, parameters :146-148); FEAT_FULL only.
+struct ExtraCfg {
+    double mu_sun;             // 0 = third body off
+    double base_density;       // 0 = drag off
+    double inv_scale_height, inv_mass, rho_skip;
 };
 
 // --------------------------------------------------------------------------------------------
@@ -310,6 +327,17 @@ __device__ __forceinline__ V3 gravity_sh(const Hot& c, V3 p) {
 // --------------------------------------------------------------------------------------------
 // gravity: point mass (+ closed-form J2): 15 / 22 fp64 ops; spherical harmonics above.
 // tsim is only used by the harmonics (planet rotation about the inertial z axis).
+// third-body perturbation relative to the central body: mu_s [ (s - r)/|s - r|^3 - s/|s|^3 ]
+struct Sun3 {
+    V3 sun, sun3;   // Sun position, mu_s s/|s|^3 (per launch)
+    double mu;
+};
+__device__ __forceinline__ V3 third_body(const Sun3& s3, V3 r) {
+    const V3 d = s3.sun - r;
+    const double id = rsqrt_nr(dot(d, d));
+    return (s3.mu * id * id * id) * d - s3.sun3;
+}
+
 template <int GRAV, class Hot>
 __device__ __forceinline__ V3 gravity(const Hot& c, V3 r, double tsim) {
     if constexpr (GRAV == BSK_GRAV_SH) {
@@ -343,11 +371,53 @@ __device__ __forceinline__ V3 gravity(const Hot& c, V3 r, double tsim) {
 //   Om_i' = (u_i + tau_f,i)/Js_i - g_i . w'
 // The wheel torque tq_i = u_i + tau_f,i depends on the state only through sign(Om_i) (Coulomb
 // friction), so the caller passes rhs0 = L_ext - sum tq_i g_i and tqj_i = tq_i / Js_i.
-template <int GRAV, int NRW, bool DIAG>
+// Per-step environment handed to the equations of motion by FEAT_FULL (nothing at lower levels).
+struct Env {
+    Sun3 s3;
+    bool sun_on, drag_on;
+    double rho, inv_mass;
+    const ColdCfg* cold;
+};
+
+// facet drag in the body frame: F = -1/2 rho |v|^2 sum_i Cd_i A_i max(0, n_i . v_hat) v_hat,
+// L = sum_i r_i x F_i; v = inertial velocity expressed in the body frame
+__device__ __forceinline__ void facet_drag(const Env& ev, V3 sig, V3 vN, V3& aN, V3& LB) {
+    const double q2 = dot(sig, sig), op = 1.0 + q2, iop2 = rcp_nr(op * op);
+    const double ka = 8.0 * iop2, kb = 4.0 * (1.0 - q2) * iop2;
+    const V3 t1 = cross(sig, vN), t2 = cross(sig, t1);
+    const V3 vB = vN + ka * t2 - kb * t1;                 // [BN] v
+    const double v2 = dot(vB, vB), iv = rsqrt_nr(v2);
+    const V3 vh = iv * vB;
+    V3 FB = mk(0, 0, 0);
+    LB = mk(0, 0, 0);
+    const ColdCfg* cc = ev.cold;
+    for (int i = 0; i < cc->n_facets; ++i) {
+        const double proj = fma(cc->facet_n[i][0], vh.x, fma(cc->facet_n[i][1], vh.y, cc->facet_n[i][2] * vh.z));
+        if (proj > 0.0) {
+            const V3 f = (-0.5 * v2 * cc->facet_acd[i] * proj * ev.rho) * vh;
+            FB = FB + f;
+            LB = LB + cross(mk(cc->facet_r[i][0], cc->facet_r[i][1], cc->facet_r[i][2]), f);
+        }
+    }
+    // a_N = [BN]^T F_B / m  (transpose: flip the sign of the odd term)
+    const V3 u1 = cross(sig, FB), u2 = cross(sig, u1);
+    aN = ev.inv_mass * (FB + ka * u2 + kb * u1);
+}
+
+template <int GRAV, int NRW, bool DIAG, int FEAT>
 __device__ __forceinline__ void eom(const HotCfg<NRW, DIAG>& c, const WheelV<NRW>& wv, const State<NRW>& x, V3 rhs0,
-                                    const double* tqj, double tsim, State<NRW>& d) {
+                                    const double* tqj, double tsim, const Env& ev, State<NRW>& d) {
     d.r = x.v;
     d.v = gravity<GRAV>(c, x.r, tsim);
+    if constexpr (FEAT == FEAT_FULL) {
+        if (ev.sun_on) d.v = d.v + third_body(ev.s3, x.r);
+        if (ev.drag_on) {
+            V3 aN, LB;
+            facet_drag(ev, x.s, x.v, aN, LB);
+            d.v = d.v + aN;
+            rhs0 = rhs0 + LB;
+        }
+    }
     // sigma' = 1/4 [(1 - s^2) w + 2 s x w + 2 (s.w) s],  with hw = w/2:
     //        = (1 - s^2)/2 hw + s x hw + (s.hw) s
     V3 hw = 0.5 * x.w;
@@ -398,22 +468,22 @@ __device__ __forceinline__ void st_axpy(double a, const State<NRW>& k, const Sta
 // shadow-set switch once per completed step.  Motor torque and Coulomb friction are evaluated
 // from the wheel speeds at the start of the step and held through its four stages (the RW
 // effector updates both once per dyn tick, outside the equations of motion).
-template <int GRAV, int NRW, bool DIAG>
+template <int GRAV, int NRW, bool DIAG, int FEAT>
 __device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, const WheelV<NRW>& wv, State<NRW>& x,
-                                         const double* u, V3 lext, double t0) {
+                                         const double* u, V3 lext, double t0, const Env& ev) {
     State<NRW> k, xt, acc;
     double tqj[NRW > 0 ? NRW : 1];
     const V3 rhs0 = wheel_torque<NRW, DIAG>(c, wv, x.Om, u, lext, tqj);
-    eom<GRAV, NRW, DIAG>(c, wv, x, rhs0, tqj, t0, k);
+    eom<GRAV, NRW, DIAG, FEAT>(c, wv, x, rhs0, tqj, t0, ev, k);
     st_axpy<NRW>(c.h6, k, x, acc);
     st_axpy<NRW>(c.h2, k, x, xt);
-    eom<GRAV, NRW, DIAG>(c, wv, xt, rhs0, tqj, t0 + c.h2, k);
+    eom<GRAV, NRW, DIAG, FEAT>(c, wv, xt, rhs0, tqj, t0 + c.h2, ev, k);
     st_axpy<NRW>(c.h3, k, acc, acc);
     st_axpy<NRW>(c.h2, k, x, xt);
-    eom<GRAV, NRW, DIAG>(c, wv, xt, rhs0, tqj, t0 + c.h2, k);
+    eom<GRAV, NRW, DIAG, FEAT>(c, wv, xt, rhs0, tqj, t0 + c.h2, ev, k);
     st_axpy<NRW>(c.h3, k, acc, acc);
     st_axpy<NRW>(c.h, k, x, xt);
-    eom<GRAV, NRW, DIAG>(c, wv, xt, rhs0, tqj, t0 + c.h, k);
+    eom<GRAV, NRW, DIAG, FEAT>(c, wv, xt, rhs0, tqj, t0 + c.h, ev, k);
     st_axpy<NRW>(c.h6, k, acc, x);
     double s2 = dot(x.s, x.s);
     if (s2 > 1.0) x.s = (-rcp_nr(s2)) * x.s;

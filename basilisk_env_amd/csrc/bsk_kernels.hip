@@ -24,7 +24,7 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-template <int GRAV, int NRW, bool DIAG, bool POWER>
+template <int GRAV, int NRW, bool DIAG, int FEAT>
 __global__ __launch_bounds__(256) void step_kernel(const StepArgs<NRW, DIAG> a) {
     const HotCfg<NRW, DIAG>& c = a.hot;
     const ColdCfg* __restrict__ cold = a.cold;
@@ -71,7 +71,19 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs<NRW, DIAG> a) 
     int tick = cnt.y;
     double shadow = 1.0;
     SunGeom sg;
+    constexpr bool POWER = FEAT >= FEAT_POWER;
     if constexpr (POWER) sg = sun_setup(a.power, (double)tick * c.h);
+    Env ev;
+    if constexpr (FEAT == FEAT_FULL) {
+        ev.cold = cold;
+        ev.inv_mass = a.extra.inv_mass;
+        ev.sun_on = a.extra.mu_sun != 0.0;
+        ev.drag_on = false;
+        ev.rho = 0.0;
+        ev.s3.sun = sg.sun;
+        ev.s3.mu = a.extra.mu_sun;
+        ev.s3.sun3 = (a.extra.mu_sun * sg.ism * sg.ism * sg.ism) * sg.sun;
+    }
     while (j < substeps) {
         int m = substeps - j;
         if constexpr (NRW > 0) {
@@ -85,7 +97,14 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs<NRW, DIAG> a) 
         }
         j += m;
         for (int t = 0; t < m; ++t, ++tick) {
-            rk4_step<GRAV, NRW, DIAG>(c, wv, x, u, lext, (double)tick * c.h);
+            if constexpr (FEAT == FEAT_FULL) {
+                if (a.extra.base_density != 0.0) {   // exponentialAtmosphere, refreshed once per dyn tick
+                    const double r2 = dot(x.r, x.r), rm = r2 * rsqrt_nr(r2);
+                    ev.rho = a.extra.base_density * exp(-(rm - a.power.req) * a.extra.inv_scale_height);
+                    ev.drag_on = ev.rho >= a.extra.rho_skip;   // below it |a_drag| < 1e-19 m/s^2: dropped
+                }
+            }
+            rk4_step<GRAV, NRW, DIAG, FEAT>(c, wv, x, u, lext, (double)tick * c.h, ev);
             if constexpr (POWER) power_step(a.power, sg, x.r, x.s, c.h, charge, shadow);
         }
     }
@@ -219,7 +238,7 @@ static void fill_hot(const StepParams& p, HotCfg<NRW, DIAG>& h) {
     h.planet_rate = p.planet_rate;
 }
 
-template <int GRAV, int NRW, bool DIAG, bool POWER>
+template <int GRAV, int NRW, bool DIAG, int FEAT>
 static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block, hipStream_t s, hipEvent_t ev0,
                            hipEvent_t ev1) {
     StepArgs<NRW, DIAG> a;
@@ -227,13 +246,14 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     a.cold = b.cold; a.st = b.st; a.cnt = b.cnt; a.act = b.act;
     a.stride = b.stride; a.n = b.n; a.substeps = b.substeps;
     a.power = p.pc;
+    a.extra = p.ex;
     a.tail.obs_cfg = p.obs; a.tail.st = b.st; a.tail.cnt = b.cnt; a.tail.obs = b.obs; a.tail.reward = b.reward;
     a.tail.done_mask = b.done_mask; a.tail.reason = b.reason; a.tail.wave_reward = b.wave_reward;
     a.tail.stride = b.stride; a.tail.n = b.n; a.tail.substeps = b.substeps;
     const int grid = (b.n + block - 1) / block;
     // hipExtLaunchKernelGGL stamps ev0/ev1 from the dispatch packet itself (no marker packets), so
     // their difference is the kernel's own duration, as rocprofv3 --kernel-trace reports it.
-    hipExtLaunchKernelGGL((step_kernel<GRAV, NRW, DIAG, POWER>), dim3(grid), dim3(block), 0, s, ev0, ev1, 0, a);
+    hipExtLaunchKernelGGL((step_kernel<GRAV, NRW, DIAG, FEAT>), dim3(grid), dim3(block), 0, s, ev0, ev1, 0, a);
     return hipGetLastError();
 }
 
@@ -244,20 +264,20 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     X(BSK_GRAV_PM_J2, 0, true, P) X(BSK_GRAV_PM_J2, 3, true, P) X(BSK_GRAV_PM_J2, 4, true, P)                \
     X(BSK_GRAV_PM, 0, false, P) X(BSK_GRAV_PM, 3, false, P) X(BSK_GRAV_PM, 4, false, P)                      \
     X(BSK_GRAV_PM_J2, 0, false, P) X(BSK_GRAV_PM_J2, 3, false, P) X(BSK_GRAV_PM_J2, 4, false, P)
-#define BSK_VARIANTS(X) BSK_VARIANTS_P(X, false) BSK_VARIANTS_P(X, true)
+#define BSK_VARIANTS(X) BSK_VARIANTS_P(X, 0) BSK_VARIANTS_P(X, 1) BSK_VARIANTS_P(X, 2)
 
-hipError_t launch_step(int grav, int nrw, bool diag, bool power, const StepParams& p, const StepBuffers& b, int block,
+hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams& p, const StepBuffers& b, int block,
                        hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
 #define CASE(G, R, D, P) \
-    if (grav == G && nrw == R && diag == D && power == P) return launch_t<G, R, D, P>(p, b, block, s, ev0, ev1);
+    if (grav == G && nrw == R && diag == D && feat == P) return launch_t<G, R, D, P>(p, b, block, s, ev0, ev1);
     BSK_VARIANTS(CASE)
 #undef CASE
     return hipErrorInvalidValue;
 }
 
-const void* step_kernel_ptr(int grav, int nrw, bool diag, bool power) {
+const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat) {
 #define CASE(G, R, D, P) \
-    if (grav == G && nrw == R && diag == D && power == P) return (const void*)&step_kernel<G, R, D, P>;
+    if (grav == G && nrw == R && diag == D && feat == P) return (const void*)&step_kernel<G, R, D, P>;
     BSK_VARIANTS(CASE)
 #undef CASE
     return nullptr;

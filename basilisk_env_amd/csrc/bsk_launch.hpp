@@ -36,7 +36,8 @@ struct StepArgs {
     int64_t stride;
     int n;
     int substeps;
-    PowerCfg power;               // read only by the POWER variants
+    PowerCfg power;               // read only by FEAT >= FEAT_POWER
+    ExtraCfg extra;               // read only by FEAT_FULL
     TailArgs tail;
 };
 
@@ -52,8 +53,9 @@ struct StepParams {
     double req, planet_rate;
     const double* sh_tab;   // device
     int32_t sh_degree;
-    bool power;
+    int feat;               // FEAT_BARE / FEAT_POWER / FEAT_FULL
     PowerCfg pc;
+    ExtraCfg ex;
 };
 
 struct StepBuffers {
@@ -71,9 +73,9 @@ struct StepBuffers {
     int substeps;
 };
 
-hipError_t launch_step(int grav, int nrw, bool diag, bool power, const StepParams& p, const StepBuffers& b, int block,
+hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams& p, const StepBuffers& b, int block,
                        hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
-const void* step_kernel_ptr(int grav, int nrw, bool diag, bool power);
+const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat);
 hipError_t launch_stats(const double* wave_reward, const unsigned long long* done_mask, int n_waves, double* out_sum,
                         long long* out_done, hipStream_t s);
 hipError_t launch_scatter_reset(double* st, int64_t stride, int nf, const double* ic, const int* idx, int m, int2* cnt,

@@ -10,7 +10,7 @@ done flags are computed on the device by the step kernel.
 import numpy as np
 
 from .. import spaces
-from .._lib import FLAG_POWER, GRAV_PM_J2, DONE_BATTERY, DONE_LENGTH, DONE_ORBIT, DONE_WHEELS
+from .._lib import FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY, GRAV_PM_J2, DONE_BATTERY, DONE_LENGTH, DONE_ORBIT, DONE_WHEELS
 from ..simulators.dynamics.config import default_config
 from ..simulators.dynamics.propagator import BatchedPropagator
 from ..simulators.initial_conditions.batch import sample_ic_batch
@@ -20,7 +20,7 @@ _EMPTY = {}
 
 class LeoPowerAttVecEnv(object):
     def __init__(self, num_envs, n_rw=4, gravity_model=GRAV_PM_J2, step_duration=180., dynRate=0.1, fswRate=1.0,
-                 seed=0, device=0, cfg=None, auto_reset=True, propagator_factory=None, power=True):
+                 seed=0, device=0, cfg=None, auto_reset=True, propagator_factory=None, power=True, sun_third_body=True, drag=True):
         self.num_envs = int(num_envs)
         self.observation_space = spaces.Box(-1e16, 1e16, shape=(5, 1))
         self.action_space = spaces.Discrete(3)
@@ -31,6 +31,10 @@ class LeoPowerAttVecEnv(object):
             cfg.fsw_every = int(round(fswRate / dynRate))
             if power:
                 cfg.flags |= FLAG_POWER
+                if sun_third_body:
+                    cfg.flags |= FLAG_SUN_THIRD_BODY
+                if drag:
+                    cfg.flags |= FLAG_DRAG
         self.cfg = cfg
         self.n_rw = int(cfg.n_rw)
         self.max_length = int(cfg.max_length)

@@ -23,6 +23,18 @@ AU = 149597870700.0
 EPOCH_JD = 2459338.5 + (7.0 * 3600.0 + 47.0 * 60.0 + 48.965) / 86400.0  # '2021 MAY 04 07:47:48.965 (UTC)', ...Simulator.py:219
 
 
+FACETS = [
+    (0.2 * 0.3, 2.2, [1, 0, 0], [0.05, 0.0, 0]),
+    (0.2 * 0.3, 2.2, [-1, 0, 0], [0.05, 0.0, 0]),
+    (0.1 * 0.2, 2.2, [0, 1, 0], [0, 0.15, 0]),
+    (0.1 * 0.2, 2.2, [0, -1, 0], [0, -0.15, 0]),
+    (0.1 * 0.3, 2.2, [0, 0, 1], [0, 0, 0.1]),
+    (0.1 * 0.3, 2.2, [0, 0, -1], [0, 0, -0.1]),
+    (1. * 2., 2.2, [0, 1, 0], [0, 2., 0]),
+    (1. * 2., 2.2, [0, -1, 0], [0, 2., 0]),
+]
+
+
 def sun_position(jd):
     """Low-precision solar position (Astronomical Almanac), equatorial frame, metres, Earth-centred.
     Stands in for the SPICE de430 lookup of the reference (...Simulator.py:219-225)."""
@@ -86,6 +98,13 @@ def default_config(n_rw=3, gravity_model=GRAV_PM, mass=330.0, width=1.38, depth=
     c.thr_min_fire_time = 0.002
     c.base_density = 1.22
     c.scale_height = 8.0e3
+    # 6U cubesat facets + two 1x2 m panels, Cd 2.2 (...Simulator.py:272-281)
+    c.n_facets = len(FACETS)
+    for i, (area, cd, normal, pos) in enumerate(FACETS):
+        c.facet_area[i], c.facet_cd[i] = area, cd
+        for k in range(3):
+            c.facet_normal[i][k] = normal[k]
+            c.facet_pos[i][k] = pos[k]
     return c
 
 

@@ -12,7 +12,7 @@ import math
 
 import numpy as np
 
-from .._lib import FLAG_POWER, GRAV_PM
+from .._lib import FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY, GRAV_PM
 from .dynamics import config as _config
 from .dynamics.effectorPrimatives import actuatorPrimatives as ap
 from .dynamics.propagator import BatchedPropagator, pack_ic
@@ -83,7 +83,11 @@ class LEOPowerAttitudeSimulator(object):
         cfg.panel_efficiency = float(ic.get("panelEfficiency"))
         for j in range(3):
             cfg.panel_normal[j] = float(ic.get("nHat_B")[j])
-        cfg.flags |= FLAG_POWER   # eclipse + solar panel + battery + sink, as the reference wires them (:286-288, 326-345)
+        # the reference scenario: eclipse + solar panel + battery + sink (:286-288, 326-345), Sun as a
+        # third body (:227-232), exponential atmosphere + facet drag (:265-284)
+        cfg.flags |= FLAG_POWER | FLAG_SUN_THIRD_BODY | FLAG_DRAG
+        cfg.base_density = float(ic.get("baseDensity"))
+        cfg.scale_height = float(ic.get("scaleHeight"))
         self.cfg = cfg
 
         factory = propagator_factory or BatchedPropagator

@@ -257,13 +257,46 @@ static void wheel_torque(orc_ctx* ctx, const double x[NX], const double u[BSK_MA
     }
 }
 
-static void eom(orc_ctx* ctx, const double x[NX], const double tq[BSK_MAX_RW], const double lext[3], double t,
-                const double sun[3], double dx[NX]) {
+/* facetDragDynamicEffector (…Simulator.py:272-284): per facet, projected area A n.v_hat (only when
+ * positive), force -1/2 rho |v|^2 Cd A_proj v_hat in the body frame, torque r_facet x F; v is the
+ * inertial velocity expressed in the body frame.  rho comes from exponentialAtmosphere
+ * (…Simulator.py:265-270, parameters :146-148), updated once per dyn tick. */
+static void facet_drag(const bsk_config* c, const double sigma[3], const double v_N[3], double rho, double F_B[3], double L_B[3]) {
+    double bn[9], vB[3];
+    v3set(0, 0, 0, F_B); v3set(0, 0, 0, L_B);
+    mrp2c(sigma, bn);
+    m33v3(bn, v_N, vB);
+    double vm = v3norm(vB);
+    if (!(vm > 0.0)) return;
+    double vhat[3]; v3scale(1.0 / vm, vB, vhat);
+    for (int i = 0; i < c->n_facets; ++i) {
+        double proj = c->facet_area[i] * v3dot(c->facet_normal[i], vhat);
+        if (proj > 0.0) {
+            double f[3], tq[3];
+            v3scale(-0.5 * vm * vm * c->facet_cd[i] * proj * rho, vhat, f);
+            v3cross(c->facet_pos[i], f, tq);
+            v3add(F_B, f, F_B); v3add(L_B, tq, L_B);
+        }
+    }
+}
+
+static void eom(orc_ctx* ctx, const double x[NX], const double tq[BSK_MAX_RW], const double lext_in[3], double t,
+                const double sun[3], double rho, double dx[NX]) {
     const bsk_config* c = ctx->c;
     const double *r = x, *v = x + 3, *sg = x + 6, *w = x + 9, *Om = x + 12;
+    double lext[3];
+    v3copy(lext_in, lext);
     /* translation */
     v3copy(v, dx);
     gravity(ctx, r, t, sun, dx + 3);
+    if (c->flags & BSK_FLAG_DRAG) {
+        double F_B[3], L_B[3], bn[9], F_N[3];
+        facet_drag(c, sg, v, rho, F_B, L_B);
+        mrp2c(sg, bn);
+        for (int i = 0; i < 3; ++i) F_N[i] = bn[i] * F_B[0] + bn[3 + i] * F_B[1] + bn[6 + i] * F_B[2];
+        for (int i = 0; i < 3; ++i) dx[3 + i] += F_N[i] / c->mass;
+        v3add(lext, L_B, lext);
+    }
     /* MRP kinematics: sigma' = 1/4 [(1 - s^2) I + 2 s~ + 2 s s^T] omega */
     double s2 = v3dot(sg, sg), sw = v3dot(sg, w), cx[3];
     v3cross(sg, w, cx);
@@ -289,14 +322,17 @@ static void eom(orc_ctx* ctx, const double x[NX], const double tq[BSK_MAX_RW], c
 static void rk4_step(orc_ctx* ctx, double x[NX], const double ucmd[BSK_MAX_RW], const double lext[3], double t, double h,
                      const double sun[3]) {
     double k[NX], xt[NX], acc[NX], u[BSK_MAX_RW];
+    /* exponentialAtmosphere: density at the spacecraft's position, refreshed once per dyn tick */
+    double rho = 0.0;
+    if (ctx->c->flags & BSK_FLAG_DRAG) rho = ctx->c->base_density * exp(-(v3norm(x) - ctx->c->req) / ctx->c->scale_height);
     wheel_torque(ctx, x, ucmd, u); /* motor + friction torque, held over the step */
-    eom(ctx, x, u, lext, t, sun, k);
+    eom(ctx, x, u, lext, t, sun, rho, k);
     for (int i = 0; i < NX; ++i) { acc[i] = x[i] + h / 6.0 * k[i]; xt[i] = x[i] + 0.5 * h * k[i]; }
-    eom(ctx, xt, u, lext, t + 0.5 * h, sun, k);
+    eom(ctx, xt, u, lext, t + 0.5 * h, sun, rho, k);
     for (int i = 0; i < NX; ++i) { acc[i] += h / 3.0 * k[i]; xt[i] = x[i] + 0.5 * h * k[i]; }
-    eom(ctx, xt, u, lext, t + 0.5 * h, sun, k);
+    eom(ctx, xt, u, lext, t + 0.5 * h, sun, rho, k);
     for (int i = 0; i < NX; ++i) { acc[i] += h / 3.0 * k[i]; xt[i] = x[i] + h * k[i]; }
-    eom(ctx, xt, u, lext, t + h, sun, k);
+    eom(ctx, xt, u, lext, t + h, sun, rho, k);
     for (int i = 0; i < NX; ++i) x[i] = acc[i] + h / 6.0 * k[i];
     double s2 = v3dot(x + 6, x + 6);
     if (s2 > 1.0) v3scale(-1.0 / s2, x + 6, x + 6);
@@ -552,7 +588,8 @@ int orc_eom(const bsk_config* c, const double* x, const double* u, const double*
     wheel_torque(&ctx, xx, uu, tq);
     double sun[3];
     for (int k = 0; k < 3; ++k) sun[k] = c->sun_r0[k] + c->sun_v[k] * t;
-    eom(&ctx, xx, tq, lext, t, sun, dd);
+    double rho = (c->flags & BSK_FLAG_DRAG) ? c->base_density * exp(-(v3norm(xx) - c->req) / c->scale_height) : 0.0;
+    eom(&ctx, xx, tq, lext, t, sun, rho, dd);
     memcpy(dx, dd, sizeof(double) * (12 + c->n_rw));
     ctx_free(&ctx);
     return 0;
