@@ -125,6 +125,7 @@ int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool&
         p.js[i] = c.js[i];
     }
     if (!inv3(D, p.dinv)) return fail(BSK_EINVAL, "hub inertia minus wheel inertia is singular");
+    for (int i = 0; i < 9; ++i) p.wmat[i] = c.inertia[i] - D[i];
     // Diagonal fast path: only when every off-diagonal of I_sc and of (I_sc - sum Js g g^T) is
     // EXACTLY zero (true for the reference's cuboid hub with the triad or the symmetric pyramid).
     diag = true;

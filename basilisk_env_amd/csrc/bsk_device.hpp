@@ -101,6 +101,7 @@ struct HotCfg {
     double nmu, j2k;       // -mu,  1.5 * J2 * mu * req^2
     double I[DIAG ? 3 : 9];
     double Di[DIAG ? 3 : 9];  // (I_sc - sum Js g g^T)^-1
+    double W[DIAG ? 3 : 9];   // sum Js g g^T  (wheel-momentum ODE, see rk4_step)
     double g[NRW > 0 ? NRW : 1][3];
     double js[NRW > 0 ? NRW : 1], ijs[NRW > 0 ? NRW : 1];
     double fc;
@@ -404,9 +405,20 @@ __device__ __forceinline__ void facet_drag(const Env& ev, V3 sig, V3 vN, V3& aN,
     aN = ev.inv_mass * (FB + ka * u2 + kb * u1);
 }
 
+// Integration state inside one RK4 step.  The hub sees the wheels only through their total
+// momentum p = sum Js Om_i g_i (body frame), and with the wheel torque tq held over the step the
+// momentum obeys a closed ODE:
+//     [I - W] w' = L_ext - T - w x (I w + p),      p' = T - W w',      T = sum tq_i g_i,  W = sum Js g g^T
+// so the four stages integrate (r, v, sigma, w, p) — 15 doubles — and the individual wheel
+// speeds follow EXACTLY (RK4 is linear in w') from  Om_i(t+h) = Om_i + h tq_i/Js_i - g_i . (w(t+h) - w(t)).
+// That is the same map as RK4 on [.., Om_1..n] with 36 wheel ops per stage replaced by 9.
+struct Core {
+    V3 r, v, s, w, p;
+};
+
 template <int GRAV, int NRW, bool DIAG, int FEAT>
-__device__ __forceinline__ void eom(const HotCfg<NRW, DIAG>& c, const WheelV<NRW>& wv, const State<NRW>& x, V3 rhs0,
-                                    const double* tqj, double tsim, const Env& ev, State<NRW>& d) {
+__device__ __forceinline__ void eom(const HotCfg<NRW, DIAG>& c, const Core& x, V3 rhs0, V3 T, double tsim, const Env& ev,
+                                    Core& d) {
     d.r = x.v;
     d.v = gravity<GRAV>(c, x.r, tsim);
     if constexpr (FEAT == FEAT_FULL) {
@@ -427,41 +439,27 @@ __device__ __forceinline__ void eom(const HotCfg<NRW, DIAG>& c, const WheelV<NRW
     d.s = V3{fma(a, hw.x, fma(b, x.s.x, fma(x.s.y, hw.z, -(x.s.z * hw.y)))),
              fma(a, hw.y, fma(b, x.s.y, fma(x.s.z, hw.x, -(x.s.x * hw.z)))),
              fma(a, hw.z, fma(b, x.s.z, fma(x.s.x, hw.y, -(x.s.y * hw.x))))};
-    V3 H = mv3<DIAG>(c.I, x.w);
-#pragma unroll
-    for (int i = 0; i < NRW; ++i) H = axpy(wv.js[i] * x.Om[i], mk(wv.g[i][0], wv.g[i][1], wv.g[i][2]), H);
-    V3 rhs = sub_cross(rhs0, x.w, H);
-    d.w = mv3<DIAG>(c.Di, rhs);
-#pragma unroll
-    for (int i = 0; i < NRW; ++i)
-        d.Om[i] = fma(-wv.g[i][0], d.w.x, fma(-wv.g[i][1], d.w.y, fma(-wv.g[i][2], d.w.z, tqj[i])));
-}
-
-// wheel torque terms for the sign pattern of Om: rhs0 = L_ext - sum tq_i g_i, tqj_i = tq_i / Js_i
-template <int NRW, bool DIAG>
-__device__ __forceinline__ V3 wheel_torque(const HotCfg<NRW, DIAG>& c, const WheelV<NRW>& wv, const double* Om,
-                                           const double* u, V3 lext, double* tqj) {
-    V3 rhs0 = lext;
-#pragma unroll
-    for (int i = 0; i < NRW; ++i) {
-        // Coulomb friction -fc sign(Om), 0 at rest; branch-free
-        double fr = __builtin_copysign(c.fc, -Om[i]);
-        fr = (Om[i] == 0.0) ? 0.0 : fr;
-        double tq = u[i] + fr;
-        rhs0 = axpy(-tq, mk(wv.g[i][0], wv.g[i][1], wv.g[i][2]), rhs0);
-        tqj[i] = tq * wv.ijs[i];
+    V3 H;
+    if constexpr (NRW > 0) {
+        if constexpr (DIAG) H = V3{fma(c.I[0], x.w.x, x.p.x), fma(c.I[1], x.w.y, x.p.y), fma(c.I[2], x.w.z, x.p.z)};
+        else H = mv(c.I, x.w) + x.p;
+    } else {
+        H = mv3<DIAG>(c.I, x.w);
     }
-    return rhs0;
+    d.w = mv3<DIAG>(c.Di, sub_cross(rhs0, x.w, H));
+    if constexpr (NRW > 0) {
+        if constexpr (DIAG) d.p = V3{fma(-c.W[0], d.w.x, T.x), fma(-c.W[1], d.w.y, T.y), fma(-c.W[2], d.w.z, T.z)};
+        else d.p = T - mv(c.W, d.w);
+    }
 }
 
 template <int NRW>
-__device__ __forceinline__ void st_axpy(double a, const State<NRW>& k, const State<NRW>& x, State<NRW>& o) {
+__device__ __forceinline__ void core_axpy(double a, const Core& k, const Core& x, Core& o) {
     o.r = axpy(a, k.r, x.r);
     o.v = axpy(a, k.v, x.v);
     o.s = axpy(a, k.s, x.s);
     o.w = axpy(a, k.w, x.w);
-#pragma unroll
-    for (int i = 0; i < NRW; ++i) o.Om[i] = fma(a, k.Om[i], x.Om[i]);
+    if constexpr (NRW > 0) o.p = axpy(a, k.p, x.p);
 }
 
 // classic RK4, sequential accumulation x0 + h/6 k1 + h/3 k2 + h/3 k3 + h/6 k4, then the MRP
@@ -471,20 +469,39 @@ __device__ __forceinline__ void st_axpy(double a, const State<NRW>& k, const Sta
 template <int GRAV, int NRW, bool DIAG, int FEAT>
 __device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, const WheelV<NRW>& wv, State<NRW>& x,
                                          const double* u, V3 lext, double t0, const Env& ev) {
-    State<NRW> k, xt, acc;
+    Core y, k, yt, acc;
+    y.r = x.r; y.v = x.v; y.s = x.s; y.w = x.w;
+    y.p = mk(0, 0, 0);
+    V3 T = mk(0, 0, 0);
     double tqj[NRW > 0 ? NRW : 1];
-    const V3 rhs0 = wheel_torque<NRW, DIAG>(c, wv, x.Om, u, lext, tqj);
-    eom<GRAV, NRW, DIAG, FEAT>(c, wv, x, rhs0, tqj, t0, ev, k);
-    st_axpy<NRW>(c.h6, k, x, acc);
-    st_axpy<NRW>(c.h2, k, x, xt);
-    eom<GRAV, NRW, DIAG, FEAT>(c, wv, xt, rhs0, tqj, t0 + c.h2, ev, k);
-    st_axpy<NRW>(c.h3, k, acc, acc);
-    st_axpy<NRW>(c.h2, k, x, xt);
-    eom<GRAV, NRW, DIAG, FEAT>(c, wv, xt, rhs0, tqj, t0 + c.h2, ev, k);
-    st_axpy<NRW>(c.h3, k, acc, acc);
-    st_axpy<NRW>(c.h, k, x, xt);
-    eom<GRAV, NRW, DIAG, FEAT>(c, wv, xt, rhs0, tqj, t0 + c.h, ev, k);
-    st_axpy<NRW>(c.h6, k, acc, x);
+#pragma unroll
+    for (int i = 0; i < NRW; ++i) {
+        // Coulomb friction -fc sign(Om), 0 at rest; branch-free
+        double fr = __builtin_copysign(c.fc, -x.Om[i]);
+        fr = (x.Om[i] == 0.0) ? 0.0 : fr;
+        const double tq = u[i] + fr;
+        const V3 g = mk(wv.g[i][0], wv.g[i][1], wv.g[i][2]);
+        T = axpy(tq, g, T);
+        y.p = axpy(wv.js[i] * x.Om[i], g, y.p);
+        tqj[i] = tq * wv.ijs[i];
+    }
+    const V3 rhs0 = lext - T;
+    eom<GRAV, NRW, DIAG, FEAT>(c, y, rhs0, T, t0, ev, k);
+    core_axpy<NRW>(c.h6, k, y, acc);
+    core_axpy<NRW>(c.h2, k, y, yt);
+    eom<GRAV, NRW, DIAG, FEAT>(c, yt, rhs0, T, t0 + c.h2, ev, k);
+    core_axpy<NRW>(c.h3, k, acc, acc);
+    core_axpy<NRW>(c.h2, k, y, yt);
+    eom<GRAV, NRW, DIAG, FEAT>(c, yt, rhs0, T, t0 + c.h2, ev, k);
+    core_axpy<NRW>(c.h3, k, acc, acc);
+    core_axpy<NRW>(c.h, k, y, yt);
+    eom<GRAV, NRW, DIAG, FEAT>(c, yt, rhs0, T, t0 + c.h, ev, k);
+    core_axpy<NRW>(c.h6, k, acc, yt);
+    const V3 dw = yt.w - y.w;
+#pragma unroll
+    for (int i = 0; i < NRW; ++i)
+        x.Om[i] = fma(-wv.g[i][0], dw.x, fma(-wv.g[i][1], dw.y, fma(-wv.g[i][2], dw.z, fma(c.h, tqj[i], x.Om[i]))));
+    x.r = yt.r; x.v = yt.v; x.s = yt.s; x.w = yt.w;
     double s2 = dot(x.s, x.s);
     if (s2 > 1.0) x.s = (-rcp_nr(s2)) * x.s;
 }

@@ -222,6 +222,7 @@ static void fill_hot(const StepParams& p, HotCfg<NRW, DIAG>& h) {
     for (int i = 0; i < (DIAG ? 3 : 9); ++i) {
         h.I[i] = DIAG ? p.inertia[4 * i] : p.inertia[i];
         h.Di[i] = DIAG ? p.dinv[4 * i] : p.dinv[i];
+        h.W[i] = DIAG ? p.wmat[4 * i] : p.wmat[i];
     }
     for (int i = 0; i < NRW; ++i) {
         for (int k = 0; k < 3; ++k) h.g[i][k] = p.gs[i][k];

@@ -44,7 +44,7 @@ struct StepArgs {
 // Host-side, variant-independent description of the hot constants (built once per handle).
 struct StepParams {
     double dt, mu, j2k;
-    double inertia[9], dinv[9];
+    double inertia[9], dinv[9], wmat[9];   // wmat = sum Js g g^T
     double gs[BSK_MAX_RW][3], js[BSK_MAX_RW];
     double f_coulomb;
     int32_t fsw_every;
