@@ -222,6 +222,10 @@ struct bsk_handle {
     int* d_idx_stage = nullptr;
     size_t stage_cap = 0;
     double* d_sh_tab = nullptr;
+    double* d_pool = nullptr;
+    double* d_term_obs = nullptr;
+    int* d_episodes = nullptr;
+    int n_pool = 0;
     // profiling
     std::vector<hipEvent_t> ev;
     int ev_used = 0;
@@ -255,7 +259,7 @@ int validate(const bsk_config& c) {
         return fail(BSK_EINVAL, "unknown gravity_model");
     if (c.gravity_model == BSK_GRAV_SH && (c.sh_degree < 2 || c.sh_degree > BSK_MAX_SH_DEGREE))
         return fail(BSK_EINVAL, "sh_degree must be in 2..70 for BSK_GRAV_SH");
-    const uint32_t unbuilt = BSK_FLAG_DESAT | BSK_FLAG_AUTO_RESET | BSK_FLAG_LDS_SCRATCH;
+    const uint32_t unbuilt = BSK_FLAG_DESAT | BSK_FLAG_LDS_SCRATCH;
     if ((c.flags & (BSK_FLAG_SUN_THIRD_BODY | BSK_FLAG_DRAG)) && !(c.flags & BSK_FLAG_POWER))
         return fail(BSK_EINVAL, "BSK_FLAG_SUN_THIRD_BODY / BSK_FLAG_DRAG are built in the full-scenario kernel: set BSK_FLAG_POWER too");
     if ((c.flags & BSK_FLAG_DRAG) && (c.n_facets < 0 || c.n_facets > 8 || !(c.scale_height > 0.0) || !(c.mass > 0.0)))
@@ -284,6 +288,8 @@ int ensure_stage(bsk_handle* h, size_t m) {
 int do_step(bsk_handle* h, const int* d_actions, int substeps) {
     if (h->cfg.gravity_model == BSK_GRAV_SH && !h->sp.sh_tab)
         return fail(BSK_EINVAL, "BSK_GRAV_SH: call bsk_set_gravity_sh before stepping");
+    if ((h->cfg.flags & BSK_FLAG_AUTO_RESET) && h->n_pool == 0)
+        return fail(BSK_EINVAL, "BSK_FLAG_AUTO_RESET: call bsk_set_ic_pool before stepping");
     bsk::StepBuffers b;
     b.cold = h->d_cold;
     b.st = h->d_state;
@@ -297,6 +303,11 @@ int do_step(bsk_handle* h, const int* d_actions, int substeps) {
     b.stride = h->stride;
     b.n = h->n;
     b.substeps = substeps;
+    b.pool = h->d_pool;
+    b.term_obs = h->d_term_obs;
+    b.episodes = h->d_episodes;
+    b.n_pool = h->n_pool;
+    b.n_fields = h->nf;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->prof && h->ev_used + 2 <= (int)h->ev.size()) {
         e0 = h->ev[h->ev_used];
@@ -469,7 +480,7 @@ void bsk_destroy(bsk_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (hipEvent_t ev : h->ev) (void)hipEventDestroy(ev);
     void* bufs[] = {h->d_state, h->d_cnt, h->d_act, h->d_obs, h->d_reward, h->d_done_mask, h->d_reason,
-                    h->d_wave_reward, h->d_stat_sum, h->d_stat_done, h->d_ic_stage, h->d_idx_stage, h->d_cold, h->d_sh_tab};
+                    h->d_wave_reward, h->d_stat_sum, h->d_stat_done, h->d_ic_stage, h->d_idx_stage, h->d_cold, h->d_sh_tab, h->d_pool, h->d_term_obs, h->d_episodes};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -612,9 +623,36 @@ int bsk_get_counters(bsk_handle* h, int32_t* steps, int32_t* ticks) {
     return BSK_OK;
 }
 
-int bsk_set_ic_pool(bsk_handle* h, int, const double*) {
+int bsk_set_ic_pool(bsk_handle* h, int n_pool, const double* ic_pool) {
+    if (!h || !ic_pool) return fail(BSK_EINVAL, "handle/ic_pool is NULL");
+    if (!(h->cfg.flags & BSK_FLAG_AUTO_RESET)) return fail(BSK_EINVAL, "handle was not created with BSK_FLAG_AUTO_RESET");
+    if (n_pool < 1) return fail(BSK_EINVAL, "n_pool must be >= 1");
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->d_pool) { (void)hipFree(h->d_pool); h->d_pool = nullptr; h->n_pool = 0; }
+    const size_t bytes = (size_t)h->nf * n_pool * sizeof(double);
+    HIP_TRY(hipMalloc(&h->d_pool, bytes));
+    HIP_TRY(hipMemcpy(h->d_pool, ic_pool, bytes, hipMemcpyHostToDevice));
+    if (!h->d_term_obs) {
+        HIP_TRY(hipMalloc(&h->d_term_obs, (size_t)5 * h->stride * sizeof(double)));
+        HIP_TRY(hipMemset(h->d_term_obs, 0, (size_t)5 * h->stride * sizeof(double)));
+        HIP_TRY(hipMalloc(&h->d_episodes, (size_t)h->stride * sizeof(int)));
+        HIP_TRY(hipMemset(h->d_episodes, 0, (size_t)h->stride * sizeof(int)));
+    }
+    h->n_pool = n_pool;
+    return BSK_OK;
+}
+
+int bsk_get_terminal_obs(bsk_handle* h, double* term_obs, int32_t* episodes) {
     if (!h) return fail(BSK_EINVAL, "handle is NULL");
-    return fail(BSK_EINVAL, "device-side auto-reset is not built in this version");
+    if (!h->d_term_obs) return fail(BSK_EINVAL, "no IC pool staged (bsk_set_ic_pool)");
+    DeviceGuard guard(h->device);
+    const size_t row = (size_t)h->n * sizeof(double);
+    if (term_obs)
+        HIP_TRY(hipMemcpy2DAsync(term_obs, row, h->d_term_obs, (size_t)h->stride * sizeof(double), row, 5, hipMemcpyDeviceToHost, h->stream));
+    if (episodes) HIP_TRY(hipMemcpyAsync(episodes, h->d_episodes, (size_t)h->n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return BSK_OK;
 }
 
 int bsk_set_sim_time(bsk_handle* h, double t) {

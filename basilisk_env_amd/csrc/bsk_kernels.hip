@@ -24,8 +24,11 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+#ifndef BSK_MIN_WAVES
+#define BSK_MIN_WAVES 1
+#endif
 template <int GRAV, int NRW, bool DIAG, int FEAT>
-__global__ __launch_bounds__(256) void step_kernel(const StepArgs<NRW, DIAG> a) {
+__global__ __launch_bounds__(256, BSK_MIN_WAVES) void step_kernel(const StepArgs<NRW, DIAG> a) {
     const HotCfg<NRW, DIAG>& c = a.hot;
     const ColdCfg* __restrict__ cold = a.cold;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -149,9 +152,41 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs<NRW, DIAG> a) 
 
     // Tail lanes shadow env n-1 and computed bit-identical results from identical inputs, so their
     // stores (same address, same value) need no mask.
-    {
-        gptr<double> so = uniform_ptr(tp->st);
+    gptr<double> so = uniform_ptr(tp->st);
+    gptr<double> ob = uniform_ptr(tp->obs);
 #define FLD(f) (so + (int64_t)(f) * S2)
+    const int n_pool = tp->n_pool;
+    if (n_pool > 0 && why != 0) {
+      if (valid2) {   // tail lanes shadow env n-1: its own lane performs the reset, they must not repeat it
+        // Device-side auto-reset (rare, divergent): reload this env from the staged IC pool, keep the
+        // finished episode's observation as terminal observation, report the new episode's first one.
+        gptr<double> tob = uniform_ptr(tp->term_obs);
+        stf(tob + 0 * S2, bo, o0); stf(tob + 1 * S2, bo, o1); stf(tob + 2 * S2, bo, o2); stf(tob + 3 * S2, bo, o3);
+        stf(tob + 4 * S2, bo, o4);
+        const int ep = tp->episodes[i];
+        tp->episodes[i] = ep + 1;
+        const unsigned slot = ((unsigned)i * 2654435761u + (unsigned)ep * 40503u + 12345u) % (unsigned)n_pool;
+        const double* __restrict__ pool = tp->pool;
+        const int nf = tp->n_fields;
+        for (int f = 0; f < nf; ++f) stf(FLD(f), bo, pool[(int64_t)f * n_pool + slot]);
+        const V3 ps = mk(pool[(int64_t)(BSK_F_SIGMA + 0) * n_pool + slot], pool[(int64_t)(BSK_F_SIGMA + 1) * n_pool + slot],
+                         pool[(int64_t)(BSK_F_SIGMA + 2) * n_pool + slot]);
+        const V3 pw = mk(pool[(int64_t)(BSK_F_OMEGA + 0) * n_pool + slot], pool[(int64_t)(BSK_F_OMEGA + 1) * n_pool + slot],
+                         pool[(int64_t)(BSK_F_OMEGA + 2) * n_pool + slot]);
+        double pom2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NRW; ++k) {
+            const double v = pool[(int64_t)(BSK_NF_BASE + k) * n_pool + slot];
+            pom2 = fma(v, v, pom2);
+        }
+        stf(ob + 0 * S2, bo, sqrt_nr(dot(ps, ps)));
+        stf(ob + 1 * S2, bo, sqrt_nr(dot(pw, pw)));
+        stf(ob + 2 * S2, bo, sqrt_nr(pom2) * tp->obs_cfg.inv_wheel_limit);
+        stf(ob + 3 * S2, bo, pool[(int64_t)(TAIL + BSK_T_CHARGE) * n_pool + slot] * tp->obs_cfg.charge_scale);
+        stf(ob + 4 * S2, bo, 1.0);
+        *(gptr<unsigned long long>)((gptr<char>)uniform_ptr(tp->cnt) + bo) = 0ull;
+      }
+    } else {
         stf(FLD(BSK_F_R + 0), bo, x.r.x); stf(FLD(BSK_F_R + 1), bo, x.r.y); stf(FLD(BSK_F_R + 2), bo, x.r.z);
         stf(FLD(BSK_F_V + 0), bo, x.v.x); stf(FLD(BSK_F_V + 1), bo, x.v.y); stf(FLD(BSK_F_V + 2), bo, x.v.z);
         stf(FLD(BSK_F_SIGMA + 0), bo, x.s.x); stf(FLD(BSK_F_SIGMA + 1), bo, x.s.y); stf(FLD(BSK_F_SIGMA + 2), bo, x.s.z);
@@ -165,17 +200,16 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs<NRW, DIAG> a) 
                 for (int k = 0; k < NRW; ++k) stf(FLD(TAIL + BSK_T_UCMD + k), bo, u[k]);
             }
         }
-#undef FLD
         // int2 {steps | phase << 20, ticks} written as one 8-byte word
         const unsigned long long packed = (unsigned long long)(unsigned)((steps0 + 1) | (phase << 20)) |
                                           ((unsigned long long)(unsigned)(cnt.y + tp->substeps) << 32);
         *(gptr<unsigned long long>)((gptr<char>)uniform_ptr(tp->cnt) + bo) = packed;
-        gptr<double> ob = uniform_ptr(tp->obs);
         stf(ob + 0 * S2, bo, o0); stf(ob + 1 * S2, bo, o1); stf(ob + 2 * S2, bo, o2); stf(ob + 3 * S2, bo, o3);
         stf(ob + 4 * S2, bo, o4);
-        stf(uniform_ptr(tp->reward), bo, rew);
-        tp->reason[i] = (unsigned char)why;
     }
+#undef FLD
+    stf(uniform_ptr(tp->reward), bo, rew);
+    tp->reason[i] = (unsigned char)why;
 }
 
 // Deterministic batch scalars from the per-wave partials: one 256-thread workgroup, fixed order.
@@ -251,6 +285,8 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     a.tail.obs_cfg = p.obs; a.tail.st = b.st; a.tail.cnt = b.cnt; a.tail.obs = b.obs; a.tail.reward = b.reward;
     a.tail.done_mask = b.done_mask; a.tail.reason = b.reason; a.tail.wave_reward = b.wave_reward;
     a.tail.stride = b.stride; a.tail.n = b.n; a.tail.substeps = b.substeps;
+    a.tail.pool = b.pool; a.tail.term_obs = b.term_obs; a.tail.episodes = b.episodes;
+    a.tail.n_pool = b.n_pool; a.tail.n_fields = b.n_fields;
     const int grid = (b.n + block - 1) / block;
     // hipExtLaunchKernelGGL stamps ev0/ev1 from the dispatch packet itself (no marker packets), so
     // their difference is the kernel's own duration, as rocprofv3 --kernel-trace reports it.

@@ -23,6 +23,12 @@ struct TailArgs {
     int64_t stride;
     int n;
     int substeps;
+    // device-side auto-reset (n_pool == 0: off)
+    const double* pool;            // [n_fields][n_pool]
+    double* term_obs;              // [5][stride]
+    int* episodes;                 // [stride]
+    int n_pool;
+    int n_fields;
 };
 
 // Passed by value to step_kernel (kernarg segment -> SGPRs).
@@ -71,6 +77,11 @@ struct StepBuffers {
     int64_t stride;
     int n;
     int substeps;
+    const double* pool;
+    double* term_obs;
+    int* episodes;
+    int n_pool;
+    int n_fields;
 };
 
 hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams& p, const StepBuffers& b, int block,

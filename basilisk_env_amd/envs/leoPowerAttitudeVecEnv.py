@@ -10,7 +10,7 @@ done flags are computed on the device by the step kernel.
 import numpy as np
 
 from .. import spaces
-from .._lib import FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY, GRAV_PM_J2, DONE_BATTERY, DONE_LENGTH, DONE_ORBIT, DONE_WHEELS
+from .._lib import FLAG_AUTO_RESET, FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY, GRAV_PM_J2, DONE_BATTERY, DONE_LENGTH, DONE_ORBIT, DONE_WHEELS
 from ..simulators.dynamics.config import default_config
 from ..simulators.dynamics.propagator import BatchedPropagator
 from ..simulators.initial_conditions.batch import sample_ic_batch
@@ -20,7 +20,11 @@ _EMPTY = {}
 
 class LeoPowerAttVecEnv(object):
     def __init__(self, num_envs, n_rw=4, gravity_model=GRAV_PM_J2, step_duration=180., dynRate=0.1, fswRate=1.0,
-                 seed=0, device=0, cfg=None, auto_reset=True, propagator_factory=None, power=True, sun_third_body=True, drag=True):
+                 seed=0, device=0, cfg=None, auto_reset=True, propagator_factory=None, power=True, sun_third_body=True, drag=True,
+                 device_reset_pool=0):
+        """``device_reset_pool`` > 0 stages that many random initial conditions on the device and lets
+        the step kernel reset finished envs itself (no host round trip at episode boundaries); 0 keeps
+        the host-side masked reset with freshly sampled ICs."""
         self.num_envs = int(num_envs)
         self.observation_space = spaces.Box(-1e16, 1e16, shape=(5, 1))
         self.action_space = spaces.Discrete(3)
@@ -35,6 +39,8 @@ class LeoPowerAttVecEnv(object):
                     cfg.flags |= FLAG_SUN_THIRD_BODY
                 if drag:
                     cfg.flags |= FLAG_DRAG
+            if device_reset_pool:
+                cfg.flags |= FLAG_AUTO_RESET
         self.cfg = cfg
         self.n_rw = int(cfg.n_rw)
         self.max_length = int(cfg.max_length)
@@ -48,6 +54,10 @@ class LeoPowerAttVecEnv(object):
         self.propagator = (propagator_factory or BatchedPropagator)(cfg, self.num_envs, device=device)
         self._ic = None
         self._actions = None
+        self.device_reset = bool(cfg.flags & FLAG_AUTO_RESET)
+        if self.device_reset:
+            n_pool = int(device_reset_pool) or self.num_envs
+            self.propagator.set_ic_pool(sample_ic_batch(n_pool, self.n_rw, rng=self._rng))
         self.episode_returns = np.zeros(self.num_envs)
         self.episode_lengths = np.zeros(self.num_envs, dtype=np.int64)
 
@@ -95,7 +105,19 @@ class LeoPowerAttVecEnv(object):
         infos = [_EMPTY] * self.num_envs
         obs_out = obs.T.reshape(self.num_envs, 5, 1).copy()
         idx = np.flatnonzero(done)
-        if idx.size:
+        if idx.size and self.device_reset:
+            # the kernel already reset these envs and wrote their new first observation into obs
+            term, _ = self.propagator.get_terminal_obs()
+            for i in idx:
+                infos[i] = {
+                    "episode": {"r": float(self.episode_returns[i]), "l": int(self.episode_lengths[i])},
+                    "terminal_observation": term[:, i].reshape(5, 1).copy(),
+                    "done_reason": {"length": bool(why[i] & DONE_LENGTH), "wheels": bool(why[i] & DONE_WHEELS),
+                                    "battery": bool(why[i] & DONE_BATTERY), "orbit": bool(why[i] & DONE_ORBIT)},
+                }
+            self.episode_returns[idx] = 0
+            self.episode_lengths[idx] = -1
+        elif idx.size:
             for i in idx:
                 infos[i] = {
                     "episode": {"r": float(self.episode_returns[i]), "l": int(self.episode_lengths[i])},

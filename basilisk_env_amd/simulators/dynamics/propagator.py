@@ -161,6 +161,21 @@ class BatchedPropagator(object):
             "stride": st.value,
         }
 
+    def set_ic_pool(self, ic_pool):
+        """Stage initial conditions [n_fields, n_pool] for device-side auto-reset (FLAG_AUTO_RESET)."""
+        pool = np.ascontiguousarray(ic_pool, dtype=np.float64)
+        if pool.ndim != 2 or pool.shape[0] != self.n_fields:
+            raise ValueError("ic_pool must have shape (%d, n_pool)" % self.n_fields)
+        check(self._lib.bsk_set_ic_pool(self._handle(), pool.shape[1], pool.ctypes.data))
+
+    def get_terminal_obs(self):
+        """-> terminal observations (5, N) (valid where the last step reported done), finished-episode
+        counts (N,) int32."""
+        tob = np.empty((5, self.n_envs), dtype=np.float64)
+        eps = np.empty(self.n_envs, dtype=np.int32)
+        check(self._lib.bsk_get_terminal_obs(self._handle(), tob.ctypes.data, eps.ctypes.data))
+        return tob, eps
+
     def sync(self):
         check(self._lib.bsk_sync(self._handle()))
 

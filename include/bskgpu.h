@@ -193,8 +193,17 @@ int bsk_set_state(bsk_handle* h, const double* state);
 /* per-env counters: env steps and RK4 ticks since reset, int32[n_envs] each (may be NULL) */
 int bsk_get_counters(bsk_handle* h, int32_t* steps, int32_t* ticks);
 
-/* Stage a pool of initial conditions for BSK_FLAG_AUTO_RESET: host SoA [n_fields][n_pool]. */
+/* Device-side auto-reset (BSK_FLAG_AUTO_RESET; reference reset semantics,
+ * envs/leoPowerAttitudeEnvironment.py:172-191, without the host round trip).  Stage a pool of
+ * initial conditions, host SoA [n_fields][n_pool].  When an env finishes, the step kernel itself
+ * reloads it from pool slot  (env * 2654435761 + episode * 40503 + 12345) mod 2^32 mod n_pool
+ * (episode = that env's count of finished episodes), zeroes its counters, writes the NEW episode's
+ * initial observation [|sigma_BN|, |omega|, |Omega|/limit, charge/3600/power_max, 1] to obs and keeps
+ * the finished episode's last observation in the terminal-observation buffer. */
 int bsk_set_ic_pool(bsk_handle* h, int n_pool, const double* ic_pool);
+/* terminal observations f64[5][n_envs] (valid for envs whose done flag is set) and per-env
+ * finished-episode counts int32[n_envs]; either pointer may be NULL.  Synchronises. */
+int bsk_get_terminal_obs(bsk_handle* h, double* term_obs, int32_t* episodes);
 
 /* Sun state override for the next steps (inertial, Earth-centred) — see sun_r0/sun_v. */
 int bsk_set_sim_time(bsk_handle* h, double t_seconds);

@@ -21,6 +21,9 @@ class OraclePropagator(object):
         self.ticks = np.zeros(self.n_envs, np.int32)
         self._out = None
         self._cbar = self._sbar = None
+        self._pool = None
+        self.episodes = np.zeros(self.n_envs, np.int32)
+        self._term_obs = np.zeros((5, self.n_envs))
 
     def set_gravity_sh(self, degree, cbar, sbar):
         assert degree == self.cfg.sh_degree
@@ -54,6 +57,32 @@ class OraclePropagator(object):
     def step(self, actions, substeps):
         self._out = oracle.step(self.cfg, self.state, self.steps, self.ticks, np.asarray(actions, np.int32), substeps,
                                 cbar=self._cbar, sbar=self._sbar)
+        if self._pool is not None:
+            self._auto_reset()
+
+    def set_ic_pool(self, ic_pool):
+        self._pool = np.array(ic_pool, dtype=np.float64)
+
+    def get_terminal_obs(self):
+        return self._term_obs.copy(), self.episodes.copy()
+
+    def _auto_reset(self):
+        """Same rule as the step kernel's epilogue (include/bskgpu.h: bsk_set_ic_pool)."""
+        obs, rew, done, why = self._out
+        obs = obs.copy()
+        n_pool = self._pool.shape[1]
+        t = 12 + self.n_rw
+        for i in np.flatnonzero(done):
+            self._term_obs[:, i] = obs[:, i]
+            slot = ((i * 2654435761 + int(self.episodes[i]) * 40503 + 12345) & 0xFFFFFFFF) % n_pool
+            self.episodes[i] += 1
+            ic = self._pool[:, slot]
+            self.state[:, i] = ic
+            self.steps[i] = 0
+            self.ticks[i] = 0
+            wl = np.linalg.norm(ic[12:12 + self.n_rw]) / self.cfg.wheel_limit if self.n_rw else 0.0
+            obs[:, i] = [np.linalg.norm(ic[6:9]), np.linalg.norm(ic[9:12]), wl, ic[t + 7] / 3600.0 / self.cfg.power_max, 1.0]
+        self._out = (obs, rew, done, why)
 
     def get_obs(self):
         return self._out

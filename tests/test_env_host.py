@@ -203,3 +203,31 @@ def test_vec_env_matches_single_env_semantics():
         ob, rew, done, info = env.step(a)
         vob, vrew, vdone, _ = venv.step([a])
         assert np.abs(vob[0] - ob).max() < 1e-14 and abs(vrew[0] - rew) < 1e-16 and bool(vdone[0]) == done
+
+
+def test_vec_env_device_reset_bookkeeping():
+    """device_reset_pool: finished envs restart from the staged pool (rule of include/bskgpu.h), the
+    step returns the new episode's first observation and the old one as terminal_observation."""
+    n = 40
+    env = LeoPowerAttVecEnv(n, n_rw=3, gravity_model=GRAV_PM, step_duration=1.0, seed=1, device_reset_pool=16, **KW)
+    env.cfg.max_length = 2
+    env.propagator.cfg.max_length = 2
+    env.reset()
+    pool = env.propagator._pool
+    acts = np.zeros(n, np.int64)
+    env.step(acts)
+    env.step(acts)
+    obs, rew, done, infos = env.step(acts)
+    assert done.all() and all("terminal_observation" in i and i["episode"]["l"] == 2 for i in infos)
+    st = env.propagator.get_state()
+    for i in range(n):
+        slot = ((i * 2654435761 + 0 * 40503 + 12345) & 0xFFFFFFFF) % 16
+        assert np.array_equal(st[:, i], pool[:, slot])
+        assert obs[i, 0, 0] == np.linalg.norm(pool[6:9, slot]) and obs[i, 4, 0] == 1.0
+    steps, ticks = env.propagator.get_counters()
+    assert (steps == 0).all() and (ticks == 0).all()
+    _, eps = env.propagator.get_terminal_obs()
+    assert (eps == 1).all()
+    o2, r2, d2, _ = env.step(acts)
+    assert not d2.any()
+    env.close()
