@@ -92,6 +92,26 @@ def cpu_baseline(cfg, n_rw, substeps):
                       % (n, done_steps, substeps, el)}
 
 
+def pmc_traffic(n_envs, substeps):
+    """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC passes
+    (tools/prof.sh -> profiles/*/summary_latest.json; separate FETCH_SIZE / WRITE_SIZE runs of this
+    same command, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  None when no matching profile."""
+    if substeps != 1:
+        return None, None
+    best = None
+    for d in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+        f = os.path.join(ROOT, "profiles", d, "summary_latest.json")
+        if os.path.exists(f):
+            best = f
+    if not best:
+        return None, None
+    try:
+        t = json.load(open(best)).get("traffic", {}).get(str(n_envs))
+        return (t["traffic_bytes"], os.path.relpath(best, ROOT)) if t else (None, None)
+    except Exception:
+        return None, None
+
+
 def _with_degree(cfg, degree):
     cfg.sh_degree = degree
     return cfg
@@ -161,6 +181,7 @@ def main():
         assert full.shape == (world, 5, n)
 
     value = n * world * a.steps / el
+    traffic_bytes, traffic_src = pmc_traffic(n, a.substeps) if not sh else (None, None)
     kernel_s = kernel_ms * 1e-3
     achieved = BYTES_PER_ENV_STEP * n / kernel_s / 1e9 if kernel_s > 0 else 0.0
     out = {
@@ -175,7 +196,8 @@ def main():
                                   a.substeps),
                    "envs_per_gpu": n, "substeps": a.substeps, "sharding": "env ranges, no step-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_bytes, "traffic_unit": "bytes/launch",
+                     "traffic_source": traffic_src, "algorithmic_bytes": BYTES_PER_ENV_STEP * n,
                      "kernel": info["name"], "kernel_us": kernel_ms * 1e3, "launches_timed": n_launch,
                      "bytes_per_env_step": BYTES_PER_ENV_STEP, "vgprs": info["vgprs"], "block": info["block"],
                      "grid": info["grid"]},
