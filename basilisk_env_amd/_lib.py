@@ -6,7 +6,7 @@ visible, the product raises (:class:`BskGpuUnavailable`); there is no CPU or PyT
 import ctypes as C
 import os
 
-BSK_ABI_VERSION = 1
+BSK_ABI_VERSION = 2
 BSK_MAX_RW = 4
 BSK_MAX_THR = 8
 
@@ -16,7 +16,7 @@ DONE_LENGTH, DONE_WHEELS, DONE_BATTERY, DONE_ORBIT = 1, 2, 4, 8
 
 # state field offsets (include/bskgpu.h)
 F_R, F_V, F_SIGMA, F_OMEGA, NF_BASE = 0, 3, 6, 9, 12
-T_LEXT, T_UCMD, T_CHARGE, NF_TAIL = 0, 3, 7, 8
+T_LEXT, T_UCMD, T_CHARGE, T_THR_REM, T_THR_LIM, T_THR_T0, T_THR_CNT, NF_TAIL = 0, 3, 7, 8, 16, 24, 25, 26
 
 
 def n_fields(n_rw):
@@ -51,7 +51,7 @@ class BskConfig(C.Structure):
         ("storage_capacity", d), ("solar_flux", d),
         ("sun_r0", d * 3), ("sun_v", d * 3), ("mu_sun", d),
         ("n_thr", i32), ("thr_max_counter", i32), ("thr_pos", (d * 3) * BSK_MAX_THR), ("thr_dir", (d * 3) * BSK_MAX_THR),
-        ("thr_max_thrust", d), ("thr_min_fire_time", d), ("hs_min", d),
+        ("thr_max_thrust", d), ("thr_min_fire_time", d), ("thr_min_on_time", d), ("hs_min", d),
         ("base_density", d), ("scale_height", d), ("n_facets", i32), ("pad0_", i32),
         ("facet_area", d * 8), ("facet_cd", d * 8), ("facet_normal", (d * 3) * 8), ("facet_pos", (d * 3) * 8),
     ]

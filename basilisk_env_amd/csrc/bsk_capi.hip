@@ -156,7 +156,30 @@ int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool&
     p.planet_rate = c.planet_rate;
     p.sh_tab = nullptr;
     p.sh_degree = 0;
-    const bool full = (c.flags & (BSK_FLAG_SUN_THIRD_BODY | BSK_FLAG_DRAG)) != 0;
+    const bool full = (c.flags & (BSK_FLAG_SUN_THIRD_BODY | BSK_FLAG_DRAG | BSK_FLAG_DESAT)) != 0;
+    p.ex.desat = (c.flags & BSK_FLAG_DESAT) ? 1 : 0;
+    p.ex.pad_ = 0;
+    k.n_thr = c.n_thr;
+    k.hs_min = c.hs_min;
+    k.inv_max_thrust = c.thr_max_thrust > 0.0 ? 1.0 / c.thr_max_thrust : 0.0;
+    k.thr_min_fire_time = c.thr_min_fire_time;
+    k.thr_min_on_time = c.thr_min_on_time;
+    k.thr_max_counter = c.thr_max_counter;
+    for (int i = 0; i < c.n_rw; ++i) { k.js[i] = c.js[i]; for (int j = 0; j < 3; ++j) k.gs[i][j] = c.gs[i][j]; }
+    if (c.flags & BSK_FLAG_DESAT) {
+        double dd[9] = {0}, ddi[9], Dm[BSK_MAX_THR][3];
+        for (int i = 0; i < c.n_thr; ++i) {
+            const double* r = c.thr_pos[i];
+            const double* g = c.thr_dir[i];
+            Dm[i][0] = r[1] * g[2] - r[2] * g[1]; Dm[i][1] = r[2] * g[0] - r[0] * g[2]; Dm[i][2] = r[0] * g[1] - r[1] * g[0];
+            for (int j = 0; j < 3; ++j) { k.thr_f[i][j] = c.thr_max_thrust * g[j]; k.thr_l[i][j] = c.thr_max_thrust * Dm[i][j]; }
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) dd[3 * a + b] += Dm[i][a] * Dm[i][b];
+        }
+        if (!inv3(dd, ddi)) return fail(BSK_EINVAL, "thruster set does not span the three torque axes");
+        for (int i = 0; i < c.n_thr; ++i)
+            for (int a = 0; a < 3; ++a) k.thr_map[i][a] = ddi[3 * a] * Dm[i][0] + ddi[3 * a + 1] * Dm[i][1] + ddi[3 * a + 2] * Dm[i][2];
+    }
     p.feat = full ? bsk::FEAT_FULL : ((c.flags & BSK_FLAG_POWER) ? bsk::FEAT_POWER : bsk::FEAT_BARE);
     p.ex.mu_sun = (c.flags & BSK_FLAG_SUN_THIRD_BODY) ? c.mu_sun : 0.0;
     p.ex.base_density = (c.flags & BSK_FLAG_DRAG) ? c.base_density : 0.0;
@@ -259,9 +282,11 @@ int validate(const bsk_config& c) {
         return fail(BSK_EINVAL, "unknown gravity_model");
     if (c.gravity_model == BSK_GRAV_SH && (c.sh_degree < 2 || c.sh_degree > BSK_MAX_SH_DEGREE))
         return fail(BSK_EINVAL, "sh_degree must be in 2..70 for BSK_GRAV_SH");
-    const uint32_t unbuilt = BSK_FLAG_DESAT | BSK_FLAG_LDS_SCRATCH;
-    if ((c.flags & (BSK_FLAG_SUN_THIRD_BODY | BSK_FLAG_DRAG)) && !(c.flags & BSK_FLAG_POWER))
-        return fail(BSK_EINVAL, "BSK_FLAG_SUN_THIRD_BODY / BSK_FLAG_DRAG are built in the full-scenario kernel: set BSK_FLAG_POWER too");
+    const uint32_t unbuilt = BSK_FLAG_LDS_SCRATCH;
+    if ((c.flags & (BSK_FLAG_SUN_THIRD_BODY | BSK_FLAG_DRAG | BSK_FLAG_DESAT)) && !(c.flags & BSK_FLAG_POWER))
+        return fail(BSK_EINVAL, "BSK_FLAG_SUN_THIRD_BODY / BSK_FLAG_DRAG / BSK_FLAG_DESAT are built in the full-scenario kernel: set BSK_FLAG_POWER too");
+    if ((c.flags & BSK_FLAG_DESAT) && (c.n_thr < 3 || c.n_thr > BSK_MAX_THR || c.n_rw == 0 || !(c.thr_max_thrust > 0.0) || !(c.mass > 0.0)))
+        return fail(BSK_EINVAL, "BSK_FLAG_DESAT needs 3..8 thrusters, wheels, thr_max_thrust > 0 and mass > 0");
     if ((c.flags & BSK_FLAG_DRAG) && (c.n_facets < 0 || c.n_facets > 8 || !(c.scale_height > 0.0) || !(c.mass > 0.0)))
         return fail(BSK_EINVAL, "BSK_FLAG_DRAG needs 0..8 facets, scale_height > 0 and mass > 0");
     if (c.flags & unbuilt) return fail(BSK_EINVAL, "config flag requests a feature that is not built in this version");
@@ -397,6 +422,17 @@ int bsk_default_config(bsk_config* c, int n_rw, int gravity_model) {
     c->hs_min = 4.0;
     c->thr_max_counter = 4;
     c->thr_min_fire_time = 0.002;
+    {   // idealMonarc1Octet (actuatorPrimatives.py:66-161), MOOG Monarc-1: 0.9 N, MinOnTime 0.02 s
+        const double x = 3.874945160902288e-2, y = 1.206182747348013, z = 0.85245, x2 = 3.8749451609022656e-2;
+        const double loc[8][3] = {{x, -y, z}, {x, -y, -z}, {-x2, -y, z}, {-x2, -y, -z}, {-x, y, z}, {-x, y, -z}, {x2, y, z}, {x2, y, -z}};
+        const double a = 0.7071067811865476, b = 0.7071067811865475;
+        const double dir[8][3] = {{-a, b, 0}, {-a, b, 0}, {b, a, 0}, {b, a, 0}, {a, -b, 0}, {a, -b, 0}, {-b, -a, 0}, {-b, -a, 0}};
+        c->n_thr = 8;
+        for (int i = 0; i < 8; ++i)
+            for (int k = 0; k < 3; ++k) { c->thr_pos[i][k] = loc[i][k]; c->thr_dir[i][k] = dir[i][k]; }
+        c->thr_max_thrust = 0.9;
+        c->thr_min_on_time = 0.020;
+    }
     c->base_density = 1.22;
     c->scale_height = 8.0e3;
     // 6U cubesat facets + two 1x2 m panels, Cd 2.2 (leoPowerAttitudeSimulator.py:272-281)

@@ -121,7 +121,13 @@ struct ColdCfg {
     // facetDragDynamicEffector geometry (read only inside the drag branch)
     double facet_acd[8];        // area * Cd
     double facet_n[8][3], facet_r[8][3];
-    int32_t n_facets, pad_;
+    int32_t n_facets, n_thr;
+    // desaturation chain (FEAT_FULL + BSK_FLAG_DESAT)
+    double thr_map[BSK_MAX_THR][3];   // thrForceMapping: [D]^T ([D][D]^T)^-1, D_i = r_i x dir_i
+    double thr_f[BSK_MAX_THR][3], thr_l[BSK_MAX_THR][3];  // force / torque of thruster i at full thrust, body frame
+    double hs_min, inv_max_thrust, thr_min_fire_time, thr_min_on_time;
+    double gs[BSK_MAX_RW][3], js[BSK_MAX_RW];
+    int32_t thr_max_counter, pad_;
 };
 
 // Guidance / observation / reward constants: by value in the kernarg (used once per launch, outside
@@ -166,6 +172,7 @@ struct ExtraCfg {
     double mu_sun;             // 0 = third body off
     double base_density;       // 0 = drag off
     double inv_scale_height, inv_mass, rho_skip;
+    int32_t desat, pad_;       // BSK_FLAG_DESAT
 };
 
 // --------------------------------------------------------------------------------------------
@@ -375,10 +382,31 @@ __device__ __forceinline__ V3 gravity(const Hot& c, V3 r, double tsim) {
 // Per-step environment handed to the equations of motion by FEAT_FULL (nothing at lower levels).
 struct Env {
     Sun3 s3;
-    bool sun_on, drag_on;
+    bool sun_on, drag_on, thr_on;
     double rho, inv_mass;
     const ColdCfg* cold;
+    // thrusterDynamicEffector: current burst, on-time per thruster in half dyn steps, elapsed e2
+    double thr_lim[BSK_MAX_THR];
+    int e2;
 };
+
+// thrust of the active thrusters at integrator time e2 (half dyn steps since the burst started)
+__device__ __forceinline__ void thrusters(const Env& ev, int e2, V3 sig, V3& aN, V3& LB) {
+    const ColdCfg* cc = ev.cold;
+    V3 FB = mk(0, 0, 0);
+    LB = mk(0, 0, 0);
+    const double e = (double)e2;
+#pragma unroll
+    for (int i = 0; i < BSK_MAX_THR; ++i) {
+        if (i < cc->n_thr && ev.thr_lim[i] > 0.0 && e <= ev.thr_lim[i]) {
+            FB = FB + mk(cc->thr_f[i][0], cc->thr_f[i][1], cc->thr_f[i][2]);
+            LB = LB + mk(cc->thr_l[i][0], cc->thr_l[i][1], cc->thr_l[i][2]);
+        }
+    }
+    const double q2 = dot(sig, sig), op = 1.0 + q2, iop2 = rcp_nr(op * op);
+    const V3 u1 = cross(sig, FB), u2 = cross(sig, u1);
+    aN = ev.inv_mass * (FB + (8.0 * iop2) * u2 + (4.0 * (1.0 - q2) * iop2) * u1);   // [BN]^T F_B / m
+}
 
 // facet drag in the body frame: F = -1/2 rho |v|^2 sum_i Cd_i A_i max(0, n_i . v_hat) v_hat,
 // L = sum_i r_i x F_i; v = inertial velocity expressed in the body frame
@@ -418,7 +446,7 @@ struct Core {
 
 template <int GRAV, int NRW, bool DIAG, int FEAT>
 __device__ __forceinline__ void eom(const HotCfg<NRW, DIAG>& c, const Core& x, V3 rhs0, V3 T, double tsim, const Env& ev,
-                                    Core& d) {
+                                    int de2, Core& d) {
     d.r = x.v;
     d.v = gravity<GRAV>(c, x.r, tsim);
     if constexpr (FEAT == FEAT_FULL) {
@@ -426,6 +454,12 @@ __device__ __forceinline__ void eom(const HotCfg<NRW, DIAG>& c, const Core& x, V
         if (ev.drag_on) {
             V3 aN, LB;
             facet_drag(ev, x.s, x.v, aN, LB);
+            d.v = d.v + aN;
+            rhs0 = rhs0 + LB;
+        }
+        if (ev.thr_on) {
+            V3 aN, LB;
+            thrusters(ev, ev.e2 + de2, x.s, aN, LB);
             d.v = d.v + aN;
             rhs0 = rhs0 + LB;
         }
@@ -486,16 +520,16 @@ __device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, const Wheel
         tqj[i] = tq * wv.ijs[i];
     }
     const V3 rhs0 = lext - T;
-    eom<GRAV, NRW, DIAG, FEAT>(c, y, rhs0, T, t0, ev, k);
+    eom<GRAV, NRW, DIAG, FEAT>(c, y, rhs0, T, t0, ev, 0, k);
     core_axpy<NRW>(c.h6, k, y, acc);
     core_axpy<NRW>(c.h2, k, y, yt);
-    eom<GRAV, NRW, DIAG, FEAT>(c, yt, rhs0, T, t0 + c.h2, ev, k);
+    eom<GRAV, NRW, DIAG, FEAT>(c, yt, rhs0, T, t0 + c.h2, ev, 1, k);
     core_axpy<NRW>(c.h3, k, acc, acc);
     core_axpy<NRW>(c.h2, k, y, yt);
-    eom<GRAV, NRW, DIAG, FEAT>(c, yt, rhs0, T, t0 + c.h2, ev, k);
+    eom<GRAV, NRW, DIAG, FEAT>(c, yt, rhs0, T, t0 + c.h2, ev, 1, k);
     core_axpy<NRW>(c.h3, k, acc, acc);
     core_axpy<NRW>(c.h, k, y, yt);
-    eom<GRAV, NRW, DIAG, FEAT>(c, yt, rhs0, T, t0 + c.h, ev, k);
+    eom<GRAV, NRW, DIAG, FEAT>(c, yt, rhs0, T, t0 + c.h, ev, 2, k);
     core_axpy<NRW>(c.h6, k, acc, yt);
     const V3 dw = yt.w - y.w;
 #pragma unroll
@@ -613,6 +647,52 @@ __device__ __forceinline__ void control(const ColdCfg* __restrict__ c, const Gui
         if (u_max > 0.0) us = fmin(fmax(us, -u_max), u_max);
         if (fabs(us) < u_min) us = 0.0;
         u[i] = us;
+    }
+}
+
+// rwDesatTask at an FSW tick in mode 2 (reference leoPowerAttitudeSimulator.py:452-478, 488-490,
+// 574-588): thrMomentumManagement (one request per mode entry) -> thrForceMapping (on-pulsing
+// minimum-norm impulses, smallest subtracted) -> thrMomentumDumping (bursts of at most one control
+// period every thr_max_counter+1 periods, pulses below thrMinFireTime dropped, stretched to the
+// thruster's MinOnTime).  thr_lim is the new burst in half dyn steps.
+template <int NRW>
+__device__ __forceinline__ void desat_tick(const ColdCfg* __restrict__ cc, const double* Om, bool first, double Tc,
+                                           double two_over_dt, int fsw_every, int tick, double* thr_rem, double* thr_lim,
+                                           int& thr_t0, int& thr_cnt) {
+    if (first) {
+        V3 hs = mk(0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NRW; ++i) hs = axpy(cc->js[i] * Om[i], mk(cc->gs[i][0], cc->gs[i][1], cc->gs[i][2]), hs);
+        const double hm = sqrt(dot(hs, hs));
+        V3 dH = mk(0, 0, 0);
+        if (hm > cc->hs_min) dH = (-(hm - cc->hs_min) / hm) * hs;
+        double F[BSK_MAX_THR], fmin = 0.0;
+#pragma unroll
+        for (int i = 0; i < BSK_MAX_THR; ++i) {
+            F[i] = (i < cc->n_thr) ? fma(cc->thr_map[i][0], dH.x, fma(cc->thr_map[i][1], dH.y, cc->thr_map[i][2] * dH.z)) : 0.0;
+            if (i == 0 || (i < cc->n_thr && F[i] < fmin)) fmin = F[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BSK_MAX_THR; ++i) thr_rem[i] = (i < cc->n_thr) ? (F[i] - fmin) * cc->inv_max_thrust : 0.0;
+        thr_cnt = 0;
+    }
+    if (thr_cnt <= 0) {
+#pragma unroll
+        for (int i = 0; i < BSK_MAX_THR; ++i) {
+            if (i >= cc->n_thr) continue;
+            double on = fmin(thr_rem[i], Tc);
+            if (on < cc->thr_min_fire_time) {
+                thr_rem[i] = 0.0;
+                thr_lim[i] = 0.0;
+            } else {
+                thr_rem[i] -= on;
+                thr_lim[i] = (on >= Tc) ? 2.0 * fsw_every : floor(fmax(on, cc->thr_min_on_time) * two_over_dt);
+            }
+        }
+        thr_t0 = tick;
+        thr_cnt = cc->thr_max_counter;
+    } else {
+        thr_cnt -= 1;
     }
 }
 

@@ -60,6 +60,12 @@ __global__ __launch_bounds__(256, BSK_MIN_WAVES) void step_kernel(const StepArgs
     for (int k = 0; k < NRW; ++k) u[k] = ldf(FLD(TAIL + BSK_T_UCMD + k), bo);
 #undef FLD
 
+    // desaturation state (FEAT_FULL with BSK_FLAG_DESAT)
+    double thr_rem[BSK_MAX_THR];
+    int thr_t0 = 0, thr_cnt = 0;
+    bool desat = false;
+    if constexpr (FEAT == FEAT_FULL) desat = a.extra.desat != 0;
+
     const int steps0 = cnt.x & 0xFFFFF;
     int phase = cnt.x >> 20;
     bool fsw_ran = false;
@@ -86,7 +92,21 @@ __global__ __launch_bounds__(256, BSK_MIN_WAVES) void step_kernel(const StepArgs
         ev.s3.sun = sg.sun;
         ev.s3.mu = a.extra.mu_sun;
         ev.s3.sun3 = (a.extra.mu_sun * sg.ism * sg.ism * sg.ism) * sg.sun;
+        ev.thr_on = false;
+        ev.e2 = 0;
+#pragma unroll
+        for (int k = 0; k < BSK_MAX_THR; ++k) { ev.thr_lim[k] = 0.0; thr_rem[k] = 0.0; }
+        if (desat) {
+#pragma unroll
+            for (int k = 0; k < BSK_MAX_THR; ++k) {
+                thr_rem[k] = ldf(st + (int64_t)(TAIL + BSK_T_THR_REM + k) * S, bo);
+                ev.thr_lim[k] = ldf(st + (int64_t)(TAIL + BSK_T_THR_LIM + k) * S, bo);
+            }
+            thr_t0 = (int)ldf(st + (int64_t)(TAIL + BSK_T_THR_T0) * S, bo);
+            thr_cnt = (int)ldf(st + (int64_t)(TAIL + BSK_T_THR_CNT) * S, bo);
+        }
     }
+    bool first_fsw = true;
     while (j < substeps) {
         int m = substeps - j;
         if constexpr (NRW > 0) {
@@ -94,6 +114,12 @@ __global__ __launch_bounds__(256, BSK_MIN_WAVES) void step_kernel(const StepArgs
                 Guid g = guidance<NRW>(cold->sigma_R0N, x, action);
                 control<NRW>(cold, g, u);
                 fsw_ran = true;
+                if constexpr (FEAT == FEAT_FULL) {
+                    if (desat && action == 2)
+                        desat_tick<NRW>(cold, x.Om, first_fsw, fsw_every * c.h, 2.0 / c.h, fsw_every, tick, thr_rem, ev.thr_lim,
+                                        thr_t0, thr_cnt);
+                }
+                first_fsw = false;
             }
             m = min(m, fsw_every - phase);
             phase = (phase + m == fsw_every) ? 0 : phase + m;
@@ -105,6 +131,15 @@ __global__ __launch_bounds__(256, BSK_MIN_WAVES) void step_kernel(const StepArgs
                     const double r2 = dot(x.r, x.r), rm = r2 * rsqrt_nr(r2);
                     ev.rho = a.extra.base_density * exp(-(rm - a.power.req) * a.extra.inv_scale_height);
                     ev.drag_on = ev.rho >= a.extra.rho_skip;   // below it |a_drag| < 1e-19 m/s^2: dropped
+                }
+            }
+            if constexpr (FEAT == FEAT_FULL) {
+                if (desat) {
+                    ev.e2 = 2 * (tick - thr_t0);
+                    bool on = false;
+#pragma unroll
+                    for (int k = 0; k < BSK_MAX_THR; ++k) on |= (ev.thr_lim[k] > 0.0 && (double)ev.e2 <= ev.thr_lim[k]);
+                    ev.thr_on = on;
                 }
             }
             rk4_step<GRAV, NRW, DIAG, FEAT>(c, wv, x, u, lext, (double)tick * c.h, ev);
@@ -194,6 +229,17 @@ __global__ __launch_bounds__(256, BSK_MIN_WAVES) void step_kernel(const StepArgs
 #pragma unroll
         for (int k = 0; k < NRW; ++k) stf(FLD(BSK_NF_BASE + k), bo, x.Om[k]);
         if constexpr (POWER) stf(FLD(TAIL + BSK_T_CHARGE), bo, charge);
+        if constexpr (FEAT == FEAT_FULL) {
+            if (desat) {
+#pragma unroll
+                for (int k = 0; k < BSK_MAX_THR; ++k) {
+                    stf(FLD(TAIL + BSK_T_THR_REM + k), bo, thr_rem[k]);
+                    stf(FLD(TAIL + BSK_T_THR_LIM + k), bo, ev.thr_lim[k]);
+                }
+                stf(FLD(TAIL + BSK_T_THR_T0), bo, (double)thr_t0);
+                stf(FLD(TAIL + BSK_T_THR_CNT), bo, (double)thr_cnt);
+            }
+        }
         if constexpr (NRW > 0) {
             if (fsw_ran) {
 #pragma unroll

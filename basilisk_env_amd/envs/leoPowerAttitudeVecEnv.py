@@ -10,7 +10,7 @@ done flags are computed on the device by the step kernel.
 import numpy as np
 
 from .. import spaces
-from .._lib import FLAG_AUTO_RESET, FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY, GRAV_PM_J2, DONE_BATTERY, DONE_LENGTH, DONE_ORBIT, DONE_WHEELS
+from .._lib import FLAG_AUTO_RESET, FLAG_DESAT, FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY, GRAV_PM_J2, DONE_BATTERY, DONE_LENGTH, DONE_ORBIT, DONE_WHEELS
 from ..simulators.dynamics.config import default_config
 from ..simulators.dynamics.propagator import BatchedPropagator
 from ..simulators.initial_conditions.batch import sample_ic_batch
@@ -20,7 +20,7 @@ _EMPTY = {}
 
 class LeoPowerAttVecEnv(object):
     def __init__(self, num_envs, n_rw=4, gravity_model=GRAV_PM_J2, step_duration=180., dynRate=0.1, fswRate=1.0,
-                 seed=0, device=0, cfg=None, auto_reset=True, propagator_factory=None, power=True, sun_third_body=True, drag=True,
+                 seed=0, device=0, cfg=None, auto_reset=True, propagator_factory=None, power=True, sun_third_body=True, drag=True, desat=True,
                  device_reset_pool=0):
         """``device_reset_pool`` > 0 stages that many random initial conditions on the device and lets
         the step kernel reset finished envs itself (no host round trip at episode boundaries); 0 keeps
@@ -39,6 +39,8 @@ class LeoPowerAttVecEnv(object):
                     cfg.flags |= FLAG_SUN_THIRD_BODY
                 if drag:
                     cfg.flags |= FLAG_DRAG
+                if desat and n_rw:
+                    cfg.flags |= FLAG_DESAT
             if device_reset_pool:
                 cfg.flags |= FLAG_AUTO_RESET
         self.cfg = cfg

@@ -96,6 +96,14 @@ def default_config(n_rw=3, gravity_model=GRAV_PM, mass=330.0, width=1.38, depth=
     c.hs_min = 4.0
     c.thr_max_counter = 4
     c.thr_min_fire_time = 0.002
+    thr = ap.idealMonarc1Octet()
+    c.n_thr = len(thr)
+    for i, t in enumerate(thr):
+        for k in range(3):
+            c.thr_pos[i][k] = t.pos_B[k]
+            c.thr_dir[i][k] = t.dir_B[k]
+    c.thr_max_thrust = thr[0].MaxThrust
+    c.thr_min_on_time = thr[0].MinOnTime
     c.base_density = 1.22
     c.scale_height = 8.0e3
     # 6U cubesat facets + two 1x2 m panels, Cd 2.2 (...Simulator.py:272-281)

@@ -58,3 +58,24 @@ def balancedHR16Pyramid(wheelSpeedsRPM=(0.0, 0.0, 0.0, 0.0)):
     cx, cy, cz = cx / n, cy / n, cz / n
     signs = ((1, 1), (-1, 1), (-1, -1), (1, -1))
     return [_wheel([sx * cx, sy * cy, cz], s) for (sx, sy), s in zip(signs, wheelSpeedsRPM)]
+
+
+# Basilisk simIncludeThruster 'MOOG_Monarc_1' preset: MaxThrust 0.9 N, MinOnTime 0.02 s.
+MOOG_MONARC_1 = {"MaxThrust": 0.9, "MinOnTime": 0.020}
+
+Thruster = namedtuple("Thruster", "pos_B dir_B MaxThrust MinOnTime")
+
+
+def idealMonarc1Octet():
+    """Eight ADCS thrusters with MOOG Monarc-1 attributes at the reference's locations/directions
+    (reference actuatorPrimatives.py:66-161: two clusters at y = -/+1.206 m, z = +/-0.85245 m, firing
+    along the four (+/-1, +/-1, 0)/sqrt(2) diagonals)."""
+    x, y, z = 3.874945160902288e-2, 1.206182747348013, 0.85245
+    x2 = 3.8749451609022656e-2
+    location = [[x, -y, z], [x, -y, -z], [-x2, -y, z], [-x2, -y, -z],
+                [-x, y, z], [-x, y, -z], [x2, y, z], [x2, y, -z]]
+    a, b = 0.7071067811865476, 0.7071067811865475
+    direction = [[-a, b, 0.0], [-a, b, 0.0], [b, a, 0.0], [b, a, 0.0],
+                 [a, -b, 0.0], [a, -b, 0.0], [-b, -a, 0.0], [-b, -a, 0.0]]
+    p = MOOG_MONARC_1
+    return [Thruster(np.array(r), np.array(g), p["MaxThrust"], p["MinOnTime"]) for r, g in zip(location, direction)]

@@ -12,7 +12,7 @@ import math
 
 import numpy as np
 
-from .._lib import FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY, GRAV_PM
+from .._lib import FLAG_DESAT, FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY, GRAV_PM
 from .dynamics import config as _config
 from .dynamics.effectorPrimatives import actuatorPrimatives as ap
 from .dynamics.propagator import BatchedPropagator, pack_ic
@@ -86,6 +86,12 @@ class LEOPowerAttitudeSimulator(object):
         # the reference scenario: eclipse + solar panel + battery + sink (:286-288, 326-345), Sun as a
         # third body (:227-232), exponential atmosphere + facet drag (:265-284)
         cfg.flags |= FLAG_POWER | FLAG_SUN_THIRD_BODY | FLAG_DRAG
+        if n_rw:
+            # action 2: momentum dumping with the Monarc-1 octet (:313-318, 452-478, 574-588)
+            cfg.flags |= FLAG_DESAT
+            cfg.hs_min = float(ic.get("hs_min"))
+            cfg.thr_max_counter = int(ic.get("maxCounterValue"))
+            cfg.thr_min_fire_time = float(ic.get("thrMinFireTime"))
         cfg.base_density = float(ic.get("baseDensity"))
         cfg.scale_height = float(ic.get("scaleHeight"))
         self.cfg = cfg

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BSK_ABI_VERSION 1u
+#define BSK_ABI_VERSION 2u
 #define BSK_MAX_RW 4
 #define BSK_MAX_THR 8
 #define BSK_MAX_SH_DEGREE 70
@@ -64,7 +64,12 @@ enum {
     BSK_T_LEXT = 0,    /* external disturbance torque L_B [N m] 3 fields (…Simulator.py:291-298)    */
     BSK_T_UCMD = 3,    /* held wheel motor torque u_s [N m]: BSK_MAX_RW fields (zero-order hold)    */
     BSK_T_CHARGE = 7,  /* battery stored charge [W s] 1 field (…Simulator.py:343)                   */
-    BSK_NF_TAIL = 8,
+    /* desaturation state (BSK_FLAG_DESAT; zero otherwise) */
+    BSK_T_THR_REM = 8,  /* thrMomentumDumping: on-time still owed per thruster [s], BSK_MAX_THR fields */
+    BSK_T_THR_LIM = 16, /* current burst: on-time per thruster in half dyn steps (integer-valued)     */
+    BSK_T_THR_T0 = 24,  /* RK4 tick at which the current burst started                               */
+    BSK_T_THR_CNT = 25, /* thrMomentumDumping counter (control periods until the next burst)         */
+    BSK_NF_TAIL = 26,
 };
 
 typedef struct bsk_config {
@@ -127,9 +132,10 @@ typedef struct bsk_config {
     int32_t thr_max_counter;
     double thr_pos[BSK_MAX_THR][3];
     double thr_dir[BSK_MAX_THR][3];
-    double thr_max_thrust;
-    double thr_min_fire_time;
-    double hs_min;
+    double thr_max_thrust;     /* N   (MOOG Monarc-1: 0.9)                                   */
+    double thr_min_fire_time;  /* s   thrMomentumDumping.thrMinFireTime (…Simulator.py:190)   */
+    double thr_min_on_time;    /* s   thruster MinOnTime (MOOG Monarc-1: 0.02)               */
+    double hs_min;             /* N m s  thrMomentumManagement.hs_min (…Simulator.py:183)     */
 
     /* drag (…Simulator.py:147-148, 272-281) */
     double base_density, scale_height;

@@ -139,6 +139,9 @@ typedef struct {
     int deg;
     const double *cbar, *sbar;     /* packed l(l+1)/2+m                                        */
     double *abar, *n1, *n2, *nq1, *nq2; /* (deg+2)x(deg+2) square, row l col m                 */
+    /* thrusters */
+    double thr_map[BSK_MAX_THR][3];  /* thrForceMapping: [D]^T ([D][D]^T)^-1, D_i = r_i x dir_i */
+    double thr_f[BSK_MAX_THR][3], thr_l[BSK_MAX_THR][3]; /* force / torque of thruster i at full thrust */
 } orc_ctx;
 
 #define SQ(l, m) ((l) * (ctx->deg + 2) + (m))
@@ -280,8 +283,13 @@ static void facet_drag(const bsk_config* c, const double sigma[3], const double 
     }
 }
 
+/* thrusterDynamicEffector (ideal thrusters, …Simulator.py:313-318): thruster i delivers its full
+ * thrust while the integrator's time lies within [burst start, burst start + on-time]; time is
+ * counted in half dyn steps so that the test is exact: e2 = 2 (tick - tick0) + {0,1,1,2}. */
+typedef struct { int active; int e2; const double* lim; } thr_state;
+
 static void eom(orc_ctx* ctx, const double x[NX], const double tq[BSK_MAX_RW], const double lext_in[3], double t,
-                const double sun[3], double rho, double dx[NX]) {
+                const double sun[3], double rho, const thr_state* th, double dx[NX]) {
     const bsk_config* c = ctx->c;
     const double *r = x, *v = x + 3, *sg = x + 6, *w = x + 9, *Om = x + 12;
     double lext[3];
@@ -296,6 +304,16 @@ static void eom(orc_ctx* ctx, const double x[NX], const double tq[BSK_MAX_RW], c
         for (int i = 0; i < 3; ++i) F_N[i] = bn[i] * F_B[0] + bn[3 + i] * F_B[1] + bn[6 + i] * F_B[2];
         for (int i = 0; i < 3; ++i) dx[3 + i] += F_N[i] / c->mass;
         v3add(lext, L_B, lext);
+    }
+    if (th && th->active) {
+        double F_B[3] = {0, 0, 0}, bn[9];
+        for (int i = 0; i < c->n_thr; ++i)
+            if (th->lim[i] > 0.0 && (double)th->e2 <= th->lim[i]) {
+                v3add(F_B, ctx->thr_f[i], F_B);
+                v3add(lext, ctx->thr_l[i], lext);
+            }
+        mrp2c(sg, bn);
+        for (int i = 0; i < 3; ++i) dx[3 + i] += (bn[i] * F_B[0] + bn[3 + i] * F_B[1] + bn[6 + i] * F_B[2]) / c->mass;
     }
     /* MRP kinematics: sigma' = 1/4 [(1 - s^2) I + 2 s~ + 2 s s^T] omega */
     double s2 = v3dot(sg, sg), sw = v3dot(sg, w), cx[3];
@@ -320,19 +338,22 @@ static void eom(orc_ctx* ctx, const double x[NX], const double tq[BSK_MAX_RW], c
 /* classic RK4 (Basilisk default integrator svIntegratorRK4; the reference never selects another,
  * …Simulator.py:213-214), then the MRP shadow-set switch once per completed step. */
 static void rk4_step(orc_ctx* ctx, double x[NX], const double ucmd[BSK_MAX_RW], const double lext[3], double t, double h,
-                     const double sun[3]) {
+                     const double sun[3], thr_state* th) {
     double k[NX], xt[NX], acc[NX], u[BSK_MAX_RW];
     /* exponentialAtmosphere: density at the spacecraft's position, refreshed once per dyn tick */
     double rho = 0.0;
     if (ctx->c->flags & BSK_FLAG_DRAG) rho = ctx->c->base_density * exp(-(v3norm(x) - ctx->c->req) / ctx->c->scale_height);
     wheel_torque(ctx, x, ucmd, u); /* motor + friction torque, held over the step */
-    eom(ctx, x, u, lext, t, sun, rho, k);
+    const int e2 = th ? th->e2 : 0;
+    eom(ctx, x, u, lext, t, sun, rho, th, k);
     for (int i = 0; i < NX; ++i) { acc[i] = x[i] + h / 6.0 * k[i]; xt[i] = x[i] + 0.5 * h * k[i]; }
-    eom(ctx, xt, u, lext, t + 0.5 * h, sun, rho, k);
+    if (th) th->e2 = e2 + 1;
+    eom(ctx, xt, u, lext, t + 0.5 * h, sun, rho, th, k);
     for (int i = 0; i < NX; ++i) { acc[i] += h / 3.0 * k[i]; xt[i] = x[i] + 0.5 * h * k[i]; }
-    eom(ctx, xt, u, lext, t + 0.5 * h, sun, rho, k);
+    eom(ctx, xt, u, lext, t + 0.5 * h, sun, rho, th, k);
     for (int i = 0; i < NX; ++i) { acc[i] += h / 3.0 * k[i]; xt[i] = x[i] + h * k[i]; }
-    eom(ctx, xt, u, lext, t + h, sun, rho, k);
+    if (th) th->e2 = e2 + 2;
+    eom(ctx, xt, u, lext, t + h, sun, rho, th, k);
     for (int i = 0; i < NX; ++i) x[i] = acc[i] + h / 6.0 * k[i];
     double s2 = v3dot(x + 6, x + 6);
     if (s2 > 1.0) v3scale(-1.0 / s2, x + 6, x + 6);
@@ -427,6 +448,18 @@ static int ctx_init(orc_ctx* ctx, const bsk_config* c, const double* cbar, const
                 ctx->map[i][b] = tmp[0] * c->ctrl_axes[b] + tmp[1] * c->ctrl_axes[3 + b] + tmp[2] * c->ctrl_axes[6 + b];
         }
     }
+    if (c->flags & BSK_FLAG_DESAT) {
+        double dd[9] = {0}, ddi[9], D[BSK_MAX_THR][3];
+        for (int i = 0; i < c->n_thr; ++i) {
+            v3cross(c->thr_pos[i], c->thr_dir[i], D[i]);
+            v3scale(c->thr_max_thrust, c->thr_dir[i], ctx->thr_f[i]);
+            v3scale(c->thr_max_thrust, D[i], ctx->thr_l[i]);
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) dd[3 * a + b] += D[i][a] * D[i][b];
+        }
+        if (m33inv(dd, ddi)) return -1;
+        for (int i = 0; i < c->n_thr; ++i) m33v3(ddi, D[i], ctx->thr_map[i]);   /* (DD^T)^-1 is symmetric */
+    }
     if (c->gravity_model == BSK_GRAV_SH) {
         if (!cbar || !sbar || c->sh_degree < 2 || c->sh_degree > BSK_MAX_SH_DEGREE) return -1;
         ctx->deg = c->sh_degree; ctx->cbar = cbar; ctx->sbar = sbar;
@@ -497,6 +530,11 @@ int orc_step(const bsk_config* c, int n, double* state, int32_t* steps, int32_t*
         for (int i = 0; i < BSK_MAX_RW; ++i) u[i] = S(tail + BSK_T_UCMD + i, e);
         double charge = S(tail + BSK_T_CHARGE, e), shadow = 1.0;
         int act = actions[e], tick = ticks[e];
+        /* desaturation state (row f2) */
+        const int desat = (c->flags & BSK_FLAG_DESAT) != 0;
+        double thr_rem[BSK_MAX_THR], thr_lim[BSK_MAX_THR];
+        for (int i = 0; i < BSK_MAX_THR; ++i) { thr_rem[i] = S(tail + BSK_T_THR_REM + i, e); thr_lim[i] = S(tail + BSK_T_THR_LIM + i, e); }
+        int thr_t0 = (int)S(tail + BSK_T_THR_T0, e), thr_cnt = (int)S(tail + BSK_T_THR_CNT, e), first_fsw = 1;
         /* Sun position: evaluated at the start of the env step from this spacecraft's own clock and
            held over the step, like the 180 s SPICE task (…Simulator.py:102,357) */
         double sun[3];
@@ -506,9 +544,50 @@ int orc_step(const bsk_config* c, int n, double* state, int32_t* steps, int32_t*
                 att_guid g;
                 guidance(&ctx, x, act, &g);
                 control(&ctx, &g, u);
+                if (desat && act == 2) {
+                    /* rwDesatTask (…Simulator.py:452-478, 488-490; enabled in mode 2 only, :574-588) */
+                    const double Tc = c->fsw_every * c->dt;
+                    if (first_fsw) {
+                        /* thrMomentumManagement: one request per mode entry (its Reset, :580).  Wheel
+                           momentum h_s = sum Js Om g; dump everything above hs_min (:183). */
+                        double hs[3] = {0, 0, 0};
+                        for (int i = 0; i < nrw; ++i)
+                            for (int k = 0; k < 3; ++k) hs[k] += c->js[i] * x[12 + i] * c->gs[i][k];
+                        double hm = v3norm(hs), dH[3] = {0, 0, 0};
+                        if (hm > c->hs_min) v3scale(-(hm - c->hs_min) / hm, hs, dH);
+                        /* thrForceMapping, on-pulsing (thrForceSign +1, :186): minimum-norm impulses
+                           F = D^T (D D^T)^-1 dH, then subtract the smallest so that all are >= 0 */
+                        double F[BSK_MAX_THR], fmin = 0.0;
+                        for (int i = 0; i < c->n_thr; ++i) { F[i] = v3dot(ctx.thr_map[i], dH); if (i == 0 || F[i] < fmin) fmin = F[i]; }
+                        /* thrMomentumDumping: a new request resets the schedule (Reset, :581) */
+                        for (int i = 0; i < c->n_thr; ++i) thr_rem[i] = (F[i] - fmin) / c->thr_max_thrust;
+                        thr_cnt = 0;
+                    }
+                    if (thr_cnt <= 0) {
+                        /* fire: each thruster for min(remaining, control period); pulses shorter than
+                           thrMinFireTime (:190) are dropped; the thruster stretches a pulse to its MinOnTime */
+                        for (int i = 0; i < c->n_thr; ++i) {
+                            double on = thr_rem[i] < Tc ? thr_rem[i] : Tc;
+                            if (on < c->thr_min_fire_time) { on = 0.0; thr_rem[i] = 0.0; thr_lim[i] = 0.0; continue; }
+                            thr_rem[i] -= on;
+                            if (on >= Tc) thr_lim[i] = 2.0 * c->fsw_every;
+                            else { if (on < c->thr_min_on_time) on = c->thr_min_on_time; thr_lim[i] = floor(on * (2.0 / c->dt)); }
+                        }
+                        thr_t0 = tick;
+                        thr_cnt = c->thr_max_counter;
+                    } else {
+                        thr_cnt -= 1;
+                    }
+                }
+                first_fsw = 0;
             }
             double t = tick * c->dt;
-            rk4_step(&ctx, x, u, lext, t, c->dt, sun);
+            thr_state th = {0, 0, thr_lim};
+            if (desat) {
+                th.e2 = 2 * (tick - thr_t0);
+                for (int i = 0; i < c->n_thr; ++i) if (thr_lim[i] > 0.0 && (double)th.e2 <= thr_lim[i]) th.active = 1;
+            }
+            rk4_step(&ctx, x, u, lext, t, c->dt, sun, desat ? &th : 0);
             if (c->flags & BSK_FLAG_POWER) {
                 /* EnvTask at the dyn rate (…Simulator.py:363-366): eclipse -> panel -> battery */
                 shadow = shadow_factor(c, x, sun);
@@ -551,6 +630,11 @@ int orc_step(const bsk_config* c, int n, double* state, int32_t* steps, int32_t*
         for (int f = 0; f < 12 + nrw; ++f) S(f, e) = x[f];
         for (int i = 0; i < BSK_MAX_RW; ++i) S(tail + BSK_T_UCMD + i, e) = u[i];
         S(tail + BSK_T_CHARGE, e) = charge;
+        if (desat) {
+            for (int i = 0; i < BSK_MAX_THR; ++i) { S(tail + BSK_T_THR_REM + i, e) = thr_rem[i]; S(tail + BSK_T_THR_LIM + i, e) = thr_lim[i]; }
+            S(tail + BSK_T_THR_T0, e) = (double)thr_t0;
+            S(tail + BSK_T_THR_CNT, e) = (double)thr_cnt;
+        }
         steps[e] += 1;
         ticks[e] = tick;
     }
@@ -589,7 +673,7 @@ int orc_eom(const bsk_config* c, const double* x, const double* u, const double*
     double sun[3];
     for (int k = 0; k < 3; ++k) sun[k] = c->sun_r0[k] + c->sun_v[k] * t;
     double rho = (c->flags & BSK_FLAG_DRAG) ? c->base_density * exp(-(v3norm(xx) - c->req) / c->scale_height) : 0.0;
-    eom(&ctx, xx, tq, lext, t, sun, rho, dd);
+    eom(&ctx, xx, tq, lext, t, sun, rho, 0, dd);
     memcpy(dx, dd, sizeof(double) * (12 + c->n_rw));
     ctx_free(&ctx);
     return 0;
