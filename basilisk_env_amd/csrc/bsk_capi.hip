@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -156,6 +157,8 @@ int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool&
     p.planet_rate = c.planet_rate;
     p.sh_tab = nullptr;
     p.sh_degree = 0;
+    p.sh_split = 1;
+    p.sh_form = 1;
     const bool full = (c.flags & (BSK_FLAG_SUN_THIRD_BODY | BSK_FLAG_DRAG | BSK_FLAG_DESAT)) != 0;
     p.ex.desat = (c.flags & BSK_FLAG_DESAT) ? 1 : 0;
     p.ex.pad_ = 0;
@@ -537,6 +540,16 @@ int bsk_set_gravity_sh(bsk_handle* h, int degree, const double* cbar, const doub
     HIP_TRY(hipMemcpy(h->d_sh_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
     h->sp.sh_tab = h->d_sh_tab;
     h->sp.sh_degree = degree;
+    {   // balance the two halves of the column walk by entry count
+        const int d1 = degree + 1, total = d1 * (d1 + 1) / 2;
+        int acc = 0, M = 1;
+        while (M <= d1 && acc + (d1 - M + 1) <= total / 2) { acc += d1 - M + 1; ++M; }
+        h->sp.sh_split = M;
+        // form of the harmonics kernel; BSKGPU_SH_FORM=1|2|3 overrides (measurement only)
+        h->sp.sh_form = 1;
+        if (const char* f = std::getenv("BSKGPU_SH_FORM")) h->sp.sh_form = std::atoi(f);
+        if (h->sp.sh_form < 1 || h->sp.sh_form > 3) h->sp.sh_form = 1;
+    }
     return BSK_OK;
 }
 

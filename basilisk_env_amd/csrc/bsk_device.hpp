@@ -106,6 +106,7 @@ struct HotCfg {
     double js[NRW > 0 ? NRW : 1], ijs[NRW > 0 ? NRW : 1];
     double fc;
     int32_t fsw_every, sh_degree;
+    int32_t sh_split, pad_;  // first column of the second wave's half (two-wave harmonics)
     // spherical harmonics (GRAV == BSK_GRAV_SH only; unused kernarg fields cost no SGPRs)
     const double* sh_tab;   // fused Pines stream, 8 doubles per (l, m) step, iteration order
     double mu_over_req, req, inv_req, planet_rate;
@@ -276,7 +277,18 @@ struct State {
 // sums are combined with (Re, Im)(s + i t)^(M-1) once per column: 10 fp64 ops per (L, M).
 typedef const double __attribute__((address_space(4))) * CTab;
 
-template <class Hot>
+// Column split for the two-wave form: wave `half` of a 128-thread workgroup walks columns
+// [m_lo, m_hi); the host balances the two halves by entry count (sh_split in HotCfg).
+__device__ __forceinline__ int sh_entries_before(int d1, int M) {   // entries of columns 1..M-1
+    return (M - 1) * d1 - ((M - 1) * (M - 2)) / 2;
+}
+
+// SPLIT: 1 = stream read with scalar loads, 2 = scalar loads with the column range split over two
+// cooperating waves, 3 = the whole stream resident in LDS (160 KiB, one 256-thread workgroup per
+// CU) and read with broadcast ds_reads.
+extern __shared__ double sh_lds_tab[];
+
+template <int SPLIT, class Hot>
 __device__ __forceinline__ V3 gravity_sh(const Hot& c, V3 p) {
     const double r2 = dot(p, p);
     const double ir = rsqrt_nr(r2);
@@ -285,13 +297,26 @@ __device__ __forceinline__ V3 gravity_sh(const Hot& c, V3 p) {
     const double irho = r2 * ir * c.inv_req;    // r / Re
     const double w0 = c.mu_over_req * ir * rho; // mu/(r Re) * (Re/r)
     const double ur = u * rho, rr = rho * rho;
-    double a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = -w0;
-    double cr = 1.0, ci = 0.0, wM = w0;
-    double B1 = 0.0, B2 = 0.0, X1 = 0.0, X2 = 0.0, Y1 = 0.0, Y2 = 0.0, Z1 = 0.0, Z2 = 0.0;
     const int d1 = c.sh_degree + 1;
+    int m_lo = 1, m_hi = d1 + 1;
+    int half = 0;
+    if constexpr (SPLIT == 2) {
+        half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform
+        if (half == 0) m_hi = c.sh_split; else m_lo = c.sh_split;
+    }
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = (half == 0) ? -w0 : 0.0;
+    // (Re, Im)(s + i t)^(m_lo - 1) and w_{m_lo - 1}
+    double cr = 1.0, ci = 0.0, wM = w0;
+    for (int M = 1; M < m_lo; ++M) {
+        const double ncr = fma(s, cr, -t * ci);
+        ci = fma(s, ci, t * cr);
+        cr = ncr;
+        wM *= rho;
+    }
+    double B1 = 0.0, B2 = 0.0, X1 = 0.0, X2 = 0.0, Y1 = 0.0, Y2 = 0.0, Z1 = 0.0, Z2 = 0.0;
 
     // recursion step A[L][M] <- A[L-1][M], A[L-2][M] and the six coefficient sums (10 fp64 ops)
-    auto rec = [&](CTab q) {
+    auto rec = [&](auto q) {
         const double B = fma(ur, q[0] * B1, -rr * (q[1] * B2));
         B2 = B1;
         B1 = B;
@@ -304,30 +329,46 @@ __device__ __forceinline__ V3 gravity_sh(const Hot& c, V3 p) {
     // wait, so one scalar-cache round trip is amortised over 40 fp64 ops.  (A two-tuple software
     // pipeline through inline-asm loads was tried: hipcc copies an in-flight tuple at the loop
     // back-edge before its wait, which reads SGPRs the load has not written yet.)
-    CTab e = (CTab)c.sh_tab;
-    for (int M = 1; M <= d1; ++M) {
-        wM *= rho;                               // column start: A[M][M] is the diagonal constant
-        B1 = wM * e[0];
-        B2 = 0.0;
-        X1 = B1 * e[2]; X2 = B1 * e[3]; Y1 = B1 * e[4]; Y2 = B1 * e[5]; Z1 = B1 * e[6]; Z2 = B1 * e[7];
-        e += 8;
-        int n = d1 - M;                          // entries left in this column
-        for (; n >= 4; n -= 4) {
-            rec(e); rec(e + 8); rec(e + 16); rec(e + 24);
-            e += 32;
-        }
-        for (; n > 0; --n) {
-            rec(e);
+    auto walk = [&](auto e) {
+        for (int M = m_lo; M < m_hi; ++M) {
+            wM *= rho;                               // column start: A[M][M] is the diagonal constant
+            B1 = wM * e[0];
+            B2 = 0.0;
+            X1 = B1 * e[2]; X2 = B1 * e[3]; Y1 = B1 * e[4]; Y2 = B1 * e[5]; Z1 = B1 * e[6]; Z2 = B1 * e[7];
             e += 8;
+            int n = d1 - M;                          // entries left in this column
+            for (; n >= 4; n -= 4) {
+                rec(e); rec(e + 8); rec(e + 16); rec(e + 24);
+                e += 32;
+            }
+            for (; n > 0; --n) {
+                rec(e);
+                e += 8;
+            }
+            // column end: combine with (Re, Im)(s + i t)^(M-1), advance to (s + i t)^M
+            a1 = fma(cr, X1, fma(ci, X2, a1));
+            a2 = fma(cr, X2, fma(-ci, X1, a2));
+            a3 = fma(cr, Y1, fma(ci, Y2, a3));
+            a4 = fma(-irho, fma(cr, Z1, ci * Z2), a4);
+            const double ncr = fma(s, cr, -t * ci);
+            ci = fma(s, ci, t * cr);
+            cr = ncr;
         }
-        // column end: combine with (Re, Im)(s + i t)^(M-1), advance to (s + i t)^M
-        a1 = fma(cr, X1, fma(ci, X2, a1));
-        a2 = fma(cr, X2, fma(-ci, X1, a2));
-        a3 = fma(cr, Y1, fma(ci, Y2, a3));
-        a4 = fma(-irho, fma(cr, Z1, ci * Z2), a4);
-        const double ncr = fma(s, cr, -t * ci);
-        ci = fma(s, ci, t * cr);
-        cr = ncr;
+    };
+    if constexpr (SPLIT == 3) walk((const double*)sh_lds_tab);
+    else walk((CTab)c.sh_tab + (int64_t)8 * sh_entries_before(d1, m_lo));
+    if constexpr (SPLIT == 2) {
+        // exchange the two halves' partial sums through LDS; both waves add them in the same order,
+        // so both continue with bit-identical accelerations
+        __shared__ double part[2][4][64];
+        const int lane = threadIdx.x & 63;
+        part[half][0][lane] = a1; part[half][1][lane] = a2; part[half][2][lane] = a3; part[half][3][lane] = a4;
+        __syncthreads();
+        a1 = part[0][0][lane] + part[1][0][lane];
+        a2 = part[0][1][lane] + part[1][1][lane];
+        a3 = part[0][2][lane] + part[1][2][lane];
+        a4 = part[0][3][lane] + part[1][3][lane];
+        __syncthreads();
     }
     return V3{fma(s, a4, a1), fma(t, a4, a2), fma(u, a4, a3)};
 }
@@ -346,13 +387,13 @@ __device__ __forceinline__ V3 third_body(const Sun3& s3, V3 r) {
     return (s3.mu * id * id * id) * d - s3.sun3;
 }
 
-template <int GRAV, class Hot>
+template <int GRAV, int SPLIT, class Hot>
 __device__ __forceinline__ V3 gravity(const Hot& c, V3 r, double tsim) {
     if constexpr (GRAV == BSK_GRAV_SH) {
         double sn, cs;
         sincos(c.planet_rate * tsim, &sn, &cs);
         const V3 pf = mk(fma(cs, r.x, sn * r.y), fma(cs, r.y, -sn * r.x), r.z);
-        const V3 af = gravity_sh(c, pf);
+        const V3 af = gravity_sh<SPLIT>(c, pf);
         return mk(fma(cs, af.x, -sn * af.y), fma(sn, af.x, cs * af.y), af.z);
     } else {
         double zz = r.z * r.z;
@@ -444,11 +485,11 @@ struct Core {
     V3 r, v, s, w, p;
 };
 
-template <int GRAV, int NRW, bool DIAG, int FEAT>
+template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT>
 __device__ __forceinline__ void eom(const HotCfg<NRW, DIAG>& c, const Core& x, V3 rhs0, V3 T, double tsim, const Env& ev,
                                     int de2, Core& d) {
     d.r = x.v;
-    d.v = gravity<GRAV>(c, x.r, tsim);
+    d.v = gravity<GRAV, SPLIT>(c, x.r, tsim);
     if constexpr (FEAT == FEAT_FULL) {
         if (ev.sun_on) d.v = d.v + third_body(ev.s3, x.r);
         if (ev.drag_on) {
@@ -500,7 +541,7 @@ __device__ __forceinline__ void core_axpy(double a, const Core& k, const Core& x
 // shadow-set switch once per completed step.  Motor torque and Coulomb friction are evaluated
 // from the wheel speeds at the start of the step and held through its four stages (the RW
 // effector updates both once per dyn tick, outside the equations of motion).
-template <int GRAV, int NRW, bool DIAG, int FEAT>
+template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT>
 __device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, const WheelV<NRW>& wv, State<NRW>& x,
                                          const double* u, V3 lext, double t0, const Env& ev) {
     Core y, k, yt, acc;
@@ -520,16 +561,16 @@ __device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, const Wheel
         tqj[i] = tq * wv.ijs[i];
     }
     const V3 rhs0 = lext - T;
-    eom<GRAV, NRW, DIAG, FEAT>(c, y, rhs0, T, t0, ev, 0, k);
+    eom<GRAV, NRW, DIAG, FEAT, SPLIT>(c, y, rhs0, T, t0, ev, 0, k);
     core_axpy<NRW>(c.h6, k, y, acc);
     core_axpy<NRW>(c.h2, k, y, yt);
-    eom<GRAV, NRW, DIAG, FEAT>(c, yt, rhs0, T, t0 + c.h2, ev, 1, k);
+    eom<GRAV, NRW, DIAG, FEAT, SPLIT>(c, yt, rhs0, T, t0 + c.h2, ev, 1, k);
     core_axpy<NRW>(c.h3, k, acc, acc);
     core_axpy<NRW>(c.h2, k, y, yt);
-    eom<GRAV, NRW, DIAG, FEAT>(c, yt, rhs0, T, t0 + c.h2, ev, 1, k);
+    eom<GRAV, NRW, DIAG, FEAT, SPLIT>(c, yt, rhs0, T, t0 + c.h2, ev, 1, k);
     core_axpy<NRW>(c.h3, k, acc, acc);
     core_axpy<NRW>(c.h, k, y, yt);
-    eom<GRAV, NRW, DIAG, FEAT>(c, yt, rhs0, T, t0 + c.h, ev, 2, k);
+    eom<GRAV, NRW, DIAG, FEAT, SPLIT>(c, yt, rhs0, T, t0 + c.h, ev, 2, k);
     core_axpy<NRW>(c.h6, k, acc, yt);
     const V3 dw = yt.w - y.w;
 #pragma unroll

@@ -27,12 +27,22 @@ __device__ __forceinline__ double wave_sum(double v) {
 #ifndef BSK_MIN_WAVES
 #define BSK_MIN_WAVES 1
 #endif
-template <int GRAV, int NRW, bool DIAG, int FEAT>
-__global__ __launch_bounds__(256, BSK_MIN_WAVES) void step_kernel(const StepArgs<NRW, DIAG> a) {
+// SPLIT = 2 (harmonics only): a 128-thread workgroup carries 64 spacecraft; both of its waves run the
+// cheap RK4 redundantly (bit-identical), each evaluates half of the Pines columns and they exchange
+// partial sums through LDS: twice the waves per SIMD at the same batch size, which is what hides the
+// scalar-load latency of the coefficient stream.  Only wave 0 stores.
+template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT>
+__global__ __launch_bounds__(SPLIT == 2 ? 128 : 256, SPLIT == 2 ? 2 : BSK_MIN_WAVES) void step_kernel(const StepArgs<NRW, DIAG> a) {
     const HotCfg<NRW, DIAG>& c = a.hot;
     const ColdCfg* __restrict__ cold = a.cold;
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gid = (SPLIT == 2) ? (int)(blockIdx.x * 64 + (threadIdx.x & 63)) : (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const bool valid = gid < a.n;
+    if constexpr (SPLIT == 3) {
+        // stage the fused Pines stream in LDS once per workgroup (coalesced 8-byte copies)
+        const int n_tab = 4 * (a.hot.sh_degree + 1) * (a.hot.sh_degree + 2);   // doubles
+        for (int k = threadIdx.x; k < n_tab; k += blockDim.x) sh_lds_tab[k] = a.hot.sh_tab[k];
+        __syncthreads();
+    }
     const int i = valid ? gid : a.n - 1;  // tail lanes shadow the last env; their stores are masked
     const int64_t S = a.stride;
     const double* __restrict__ st = a.st;
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(256, BSK_MIN_WAVES) void step_kernel(const StepArgs
                     ev.thr_on = on;
                 }
             }
-            rk4_step<GRAV, NRW, DIAG, FEAT>(c, wv, x, u, lext, (double)tick * c.h, ev);
+            rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT>(c, wv, x, u, lext, (double)tick * c.h, ev);
             if constexpr (POWER) power_step(a.power, sg, x.r, x.s, c.h, charge, shadow);
         }
     }
@@ -177,6 +187,9 @@ __global__ __launch_bounds__(256, BSK_MIN_WAVES) void step_kernel(const StepArgs
     if (o3 == 0.0) { why |= BSK_DONE_BATTERY; rew -= tp->obs_cfg.failure_penalty; }
     if (dot(x.r, x.r) < tp->obs_cfg.r_min2) why |= BSK_DONE_ORBIT;
 
+    if constexpr (SPLIT == 2) {
+        if (threadIdx.x >= 64) return;   // the second wave only helped with the harmonics
+    }
     // wavefront reductions (every lane of the wave participates; tail lanes contribute nothing)
     const unsigned long long dmask = __ballot(valid2 && why != 0);
     const double rsum = wave_sum(valid2 ? rew : 0.0);
@@ -312,6 +325,8 @@ static void fill_hot(const StepParams& p, HotCfg<NRW, DIAG>& h) {
     h.fc = p.f_coulomb;
     h.fsw_every = p.fsw_every;
     h.sh_degree = p.sh_degree;
+    h.sh_split = p.sh_split;
+    h.pad_ = 0;
     h.sh_tab = p.sh_tab;
     h.mu_over_req = p.mu / p.req;
     h.req = p.req;
@@ -319,7 +334,7 @@ static void fill_hot(const StepParams& p, HotCfg<NRW, DIAG>& h) {
     h.planet_rate = p.planet_rate;
 }
 
-template <int GRAV, int NRW, bool DIAG, int FEAT>
+template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT>
 static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block, hipStream_t s, hipEvent_t ev0,
                            hipEvent_t ev1) {
     StepArgs<NRW, DIAG> a;
@@ -333,10 +348,23 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     a.tail.stride = b.stride; a.tail.n = b.n; a.tail.substeps = b.substeps;
     a.tail.pool = b.pool; a.tail.term_obs = b.term_obs; a.tail.episodes = b.episodes;
     a.tail.n_pool = b.n_pool; a.tail.n_fields = b.n_fields;
-    const int grid = (b.n + block - 1) / block;
+    if (SPLIT == 2) block = 128;
+    if (SPLIT == 3) block = 256;
+    const int grid = SPLIT == 2 ? (b.n + 63) / 64 : (b.n + block - 1) / block;
+    size_t lds = 0;
+    if (SPLIT == 3) {
+        lds = (size_t)32 * (p.sh_degree + 1) * (p.sh_degree + 2);   // bytes of the stream
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)&step_kernel<GRAV, NRW, DIAG, FEAT, SPLIT>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+    }
     // hipExtLaunchKernelGGL stamps ev0/ev1 from the dispatch packet itself (no marker packets), so
     // their difference is the kernel's own duration, as rocprofv3 --kernel-trace reports it.
-    hipExtLaunchKernelGGL((step_kernel<GRAV, NRW, DIAG, FEAT>), dim3(grid), dim3(block), 0, s, ev0, ev1, 0, a);
+    hipExtLaunchKernelGGL((step_kernel<GRAV, NRW, DIAG, FEAT, SPLIT>), dim3(grid), dim3(block), lds, s, ev0, ev1, 0, a);
     return hipGetLastError();
 }
 
@@ -352,7 +380,11 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
 hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams& p, const StepBuffers& b, int block,
                        hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
 #define CASE(G, R, D, P) \
-    if (grav == G && nrw == R && diag == D && feat == P) return launch_t<G, R, D, P>(p, b, block, s, ev0, ev1);
+    if (grav == G && nrw == R && diag == D && feat == P) {                                                 \
+        if (G == BSK_GRAV_SH && p.sh_form == 2) return launch_t<G, R, D, P, (G == BSK_GRAV_SH ? 2 : 1)>(p, b, block, s, ev0, ev1); \
+        if (G == BSK_GRAV_SH && p.sh_form == 3) return launch_t<G, R, D, P, (G == BSK_GRAV_SH ? 3 : 1)>(p, b, block, s, ev0, ev1); \
+        return launch_t<G, R, D, P, 1>(p, b, block, s, ev0, ev1);                                           \
+    }
     BSK_VARIANTS(CASE)
 #undef CASE
     return hipErrorInvalidValue;
@@ -360,7 +392,7 @@ hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams&
 
 const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat) {
 #define CASE(G, R, D, P) \
-    if (grav == G && nrw == R && diag == D && feat == P) return (const void*)&step_kernel<G, R, D, P>;
+    if (grav == G && nrw == R && diag == D && feat == P) return (const void*)&step_kernel<G, R, D, P, 1>;
     BSK_VARIANTS(CASE)
 #undef CASE
     return nullptr;

@@ -59,6 +59,8 @@ struct StepParams {
     double req, planet_rate;
     const double* sh_tab;   // device
     int32_t sh_degree;
+    int32_t sh_split;       // first Pines column of the second wave's half
+    int sh_form;            // 1 scalar-load stream, 2 + two cooperating waves, 3 stream resident in LDS
     int feat;               // FEAT_BARE / FEAT_POWER / FEAT_FULL
     PowerCfg pc;
     ExtraCfg ex;
