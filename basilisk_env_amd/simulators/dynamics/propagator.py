@@ -183,7 +183,9 @@ class BatchedPropagator(object):
         check(self._lib.bsk_set_sim_time(self._handle(), float(t)))
 
     # ------------------------------------------------------------------ measurement
-    def profile_begin(self, capacity):
+    def profile_begin(self, capacity, stride=1):
+        """Arm dispatch-timestamp profiling of the step kernel for every ``stride``-th launch."""
+        check(self._lib.bsk_profile_set_stride(self._handle(), int(stride)))
         check(self._lib.bsk_profile_begin(self._handle(), int(capacity)))
 
     def profile_end(self):

@@ -220,6 +220,11 @@ int bsk_sync(bsk_handle* h);
  * each launch.  begin() arms it (capacity launches); end() synchronises and reports the mean
  * kernel duration in milliseconds over the launches seen since begin(). */
 int bsk_profile_begin(bsk_handle* h, int capacity);
+/* stride 1 (default): every launch is stamped.  stride > 1: a pair of launches is stamped every
+ * `stride` launches and only the second of the pair is counted (the first absorbs the transition
+ * from un-stamped back-to-back launches).  Stamping costs ~5 us of launch throughput per stamped
+ * launch on MI355X, so a timed region samples instead of stamping every launch. */
+int bsk_profile_set_stride(bsk_handle* h, int stride);
 int bsk_profile_end(bsk_handle* h, double* mean_kernel_ms, int* n_launches);
 
 /* Kernel resource facts for DESIGN.md / bench: name of the kernel variant selected for this
