@@ -251,7 +251,7 @@ struct bsk_handle {
     double* d_pool = nullptr;
     double* d_term_obs = nullptr;
     int* d_episodes = nullptr;
-    int n_pool = 0;
+    int n_pool = 0, pool_cap = 0;
     // profiling
     std::vector<hipEvent_t> ev;
     int ev_used = 0;
@@ -361,11 +361,12 @@ int do_step(bsk_handle* h, const int* d_actions, int substeps) {
         }
     }
     HIP_TRY(bsk::launch_step(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp.feat, h->sp, b, h->block, h->stream, e0, e1));
-    h->sim_time += substeps * h->cfg.dt;
     return BSK_OK;
 }
 
 }  // namespace
+
+static int ensure_pool_buffers(bsk_handle* h, int n_pool);
 
 extern "C" {
 
@@ -698,17 +699,57 @@ int bsk_set_ic_pool(bsk_handle* h, int n_pool, const double* ic_pool) {
     if (n_pool < 1) return fail(BSK_EINVAL, "n_pool must be >= 1");
     DeviceGuard guard(h->device);
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (h->d_pool) { (void)hipFree(h->d_pool); h->d_pool = nullptr; h->n_pool = 0; }
-    const size_t bytes = (size_t)h->nf * n_pool * sizeof(double);
-    HIP_TRY(hipMalloc(&h->d_pool, bytes));
-    HIP_TRY(hipMemcpy(h->d_pool, ic_pool, bytes, hipMemcpyHostToDevice));
+    int rc = ensure_pool_buffers(h, n_pool);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(h->d_pool, ic_pool, (size_t)h->nf * n_pool * sizeof(double), hipMemcpyHostToDevice));
+    h->n_pool = n_pool;
+    return BSK_OK;
+}
+
+static int ensure_pool_buffers(bsk_handle* h, int n_pool) {
+    if (h->d_pool && h->pool_cap < n_pool) { (void)hipFree(h->d_pool); h->d_pool = nullptr; h->n_pool = 0; h->pool_cap = 0; }
+    if (!h->d_pool) {
+        HIP_TRY(hipMalloc(&h->d_pool, (size_t)h->nf * n_pool * sizeof(double)));
+        h->pool_cap = n_pool;
+    }
     if (!h->d_term_obs) {
         HIP_TRY(hipMalloc(&h->d_term_obs, (size_t)5 * h->stride * sizeof(double)));
         HIP_TRY(hipMemset(h->d_term_obs, 0, (size_t)5 * h->stride * sizeof(double)));
         HIP_TRY(hipMalloc(&h->d_episodes, (size_t)h->stride * sizeof(int)));
         HIP_TRY(hipMemset(h->d_episodes, 0, (size_t)h->stride * sizeof(int)));
     }
+    return BSK_OK;
+}
+
+int bsk_sample_ic_pool(bsk_handle* h, int n_pool, uint64_t seed) {
+    if (!h) return fail(BSK_EINVAL, "handle is NULL");
+    if (!(h->cfg.flags & BSK_FLAG_AUTO_RESET)) return fail(BSK_EINVAL, "handle was not created with BSK_FLAG_AUTO_RESET");
+    if (n_pool < 1) return fail(BSK_EINVAL, "n_pool must be >= 1");
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    int rc = ensure_pool_buffers(h, n_pool);
+    if (rc) return rc;
+    HIP_TRY(bsk::launch_sample_pool(h->d_pool, n_pool, h->cfg.n_rw, (unsigned long long)seed, h->cfg.mu, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
     h->n_pool = n_pool;
+    return BSK_OK;
+}
+
+int bsk_reset_from_pool(bsk_handle* h, const uint8_t* mask) {
+    if (!h) return fail(BSK_EINVAL, "handle is NULL");
+    if (h->n_pool == 0) return fail(BSK_EINVAL, "no IC pool staged (bsk_set_ic_pool / bsk_sample_ic_pool)");
+    DeviceGuard guard(h->device);
+    unsigned char* d_mask = nullptr;
+    if (mask) {
+        HIP_TRY(hipMalloc(&d_mask, (size_t)h->n));
+        HIP_TRY(hipMemcpyAsync(d_mask, mask, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+    }
+    hipError_t e = bsk::launch_reset_from_pool(h->d_state, h->stride, h->nf, h->d_pool, h->n_pool, d_mask, h->n, h->d_cnt,
+                                               h->d_episodes, h->stream);
+    hipError_t e2 = hipStreamSynchronize(h->stream);
+    if (d_mask) (void)hipFree(d_mask);
+    HIP_TRY(e);
+    HIP_TRY(e2);
     return BSK_OK;
 }
 
@@ -727,6 +768,7 @@ int bsk_get_terminal_obs(bsk_handle* h, double* term_obs, int32_t* episodes) {
 int bsk_set_sim_time(bsk_handle* h, double t) {
     if (!h) return fail(BSK_EINVAL, "handle is NULL");
     h->sim_time = t;
+    for (int i = 0; i < 3; ++i) h->sp.pc.sun_r0[i] = h->cfg.sun_r0[i] + h->cfg.sun_v[i] * t;
     return BSK_OK;
 }
 

@@ -308,6 +308,90 @@ __global__ void scatter_reset_kernel(double* __restrict__ st, int64_t stride, in
     cnt[e] = make_int2(0, 0);
 }
 
+// ---------------------------------------------------------------------------------------------
+// On-device initial-condition sampler (row f4).  Philox4x32-10 (Salmon et al. 2011), written out by
+// hand: counter (slot, draw, 0, 0), key (seed_lo, seed_hi); every call yields four 32-bit words =
+// two 53-bit uniforms, so each pool slot is reproducible independently of every other slot.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned* out) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1,
+                       n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// two uniforms in [0, 1) with 53 random bits each (same bit recipe as numpy's random_double)
+__device__ __forceinline__ void philox_u2(unsigned slot, unsigned draw, unsigned k0, unsigned k1, double& a, double& b) {
+    unsigned w[4];
+    philox4x32_10(slot, draw, 0u, 0u, k0, k1, w);
+    a = (double)(((unsigned long long)(w[0] >> 5) << 26) | (w[1] >> 6)) * (1.0 / 9007199254740992.0);
+    b = (double)(((unsigned long long)(w[2] >> 5) << 26) | (w[3] >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+__global__ void sample_pool_kernel(double* __restrict__ pool, int n_pool, int n_rw, unsigned k0, unsigned k1, double mu) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_pool) return;
+    const double PI = 3.14159265358979323846, RPM = 2.0 * PI / 60.0;
+    double u[20];
+#pragma unroll
+    for (int d = 0; d < 10; ++d) philox_u2((unsigned)s, (unsigned)d, k0, k1, u[2 * d], u[2 * d + 1]);
+    // orbit: sampled_400km (leo_orbit.py:25-40) -> elem2rv
+    const double a = 6371.0 * 1000.0 + 500.0 * 1000.0;
+    const double e = 0.05 * u[0], inc = PI * u[1] - 0.5 * PI, Om = 2.0 * PI * u[2], om = 2.0 * PI * u[3], f = 2.0 * PI * u[4];
+    const double p = a * (1.0 - e * e), r = p / (1.0 + e * cos(f)), th = om + f;
+    const double ct = cos(th), st = sin(th), cO = cos(Om), sO = sin(Om), ci = cos(inc), si = sin(inc);
+    const double h = sqrt(mu * p), A = st + e * sin(om), B = ct + e * cos(om), mh = -mu / h;
+    auto put = [&](int fld, double v) { pool[(int64_t)fld * n_pool + s] = v; };
+    put(BSK_F_R + 0, r * (cO * ct - sO * st * ci)); put(BSK_F_R + 1, r * (sO * ct + cO * st * ci)); put(BSK_F_R + 2, r * (st * si));
+    put(BSK_F_V + 0, mh * (cO * A + sO * B * ci)); put(BSK_F_V + 1, mh * (sO * A - cO * B * ci)); put(BSK_F_V + 2, mh * (-B * si));
+    // attitude: random_tumble(maxSpinRate = 1e-5) (sc_attitudes.py:3-13, ...Simulator.py:124)
+    put(BSK_F_SIGMA + 0, u[5]); put(BSK_F_SIGMA + 1, u[6]); put(BSK_F_SIGMA + 2, u[7]);
+    put(BSK_F_OMEGA + 0, 1e-5 * (2.0 * u[8] - 1.0)); put(BSK_F_OMEGA + 1, 1e-5 * (2.0 * u[9] - 1.0));
+    put(BSK_F_OMEGA + 2, 1e-5 * (2.0 * u[10] - 1.0));
+    // wheel speeds U(-800, 800) RPM (...Simulator.py:155)
+    for (int k = 0; k < n_rw; ++k) put(BSK_NF_BASE + k, (1600.0 * u[11 + k] - 800.0) * RPM);
+    const int T = BSK_NF_BASE + n_rw;
+    // disturbance torque 2e-4 * N(0,1)^3 (...Simulator.py:151-152, 295): Box-Muller on (u15,u16), (u17,u18)
+    const double r1 = sqrt(-2.0 * log(1.0 - u[15])), r2 = sqrt(-2.0 * log(1.0 - u[17]));
+    put(T + BSK_T_LEXT + 0, 2e-4 * r1 * cos(2.0 * PI * u[16]));
+    put(T + BSK_T_LEXT + 1, 2e-4 * r1 * sin(2.0 * PI * u[16]));
+    put(T + BSK_T_LEXT + 2, 2e-4 * r2 * cos(2.0 * PI * u[18]));
+    for (int k = BSK_T_UCMD; k < BSK_NF_TAIL; ++k) put(T + k, 0.0);
+    // battery U(8, 20) W h (...Simulator.py:167)
+    put(T + BSK_T_CHARGE, (8.0 + 12.0 * u[19]) * 3600.0);
+}
+
+// (re)start envs from the pool with the slot rule of the step kernel's auto-reset
+__global__ void reset_from_pool_kernel(double* __restrict__ st, int64_t stride, int nf, const double* __restrict__ pool,
+                                       int n_pool, const unsigned char* __restrict__ mask, int n, int2* __restrict__ cnt,
+                                       int* __restrict__ episodes) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || (mask && !mask[i])) return;
+    const int ep = episodes[i];
+    episodes[i] = ep + 1;
+    const unsigned slot = ((unsigned)i * 2654435761u + (unsigned)ep * 40503u + 12345u) % (unsigned)n_pool;
+    for (int f = 0; f < nf; ++f) st[f * stride + i] = pool[(int64_t)f * n_pool + slot];
+    cnt[i] = make_int2(0, 0);
+}
+
+hipError_t launch_sample_pool(double* pool, int n_pool, int n_rw, unsigned long long seed, double mu, hipStream_t s) {
+    hipLaunchKernelGGL(sample_pool_kernel, dim3((n_pool + 255) / 256), dim3(256), 0, s, pool, n_pool, n_rw,
+                       (unsigned)(seed & 0xFFFFFFFFull), (unsigned)(seed >> 32), mu);
+    return hipGetLastError();
+}
+
+hipError_t launch_reset_from_pool(double* st, int64_t stride, int nf, const double* pool, int n_pool, const unsigned char* mask,
+                                  int n, int2* cnt, int* episodes, hipStream_t s) {
+    hipLaunchKernelGGL(reset_from_pool_kernel, dim3((n + 255) / 256), dim3(256), 0, s, st, stride, nf, pool, n_pool, mask, n, cnt,
+                       episodes);
+    return hipGetLastError();
+}
+
 template <int GRAV, int NRW, bool DIAG>
 static void fill_hot(const StepParams& p, HotCfg<NRW, DIAG>& h) {
     h.h = p.dt; h.h2 = 0.5 * p.dt; h.h3 = p.dt / 3.0; h.h6 = p.dt / 6.0;

@@ -21,10 +21,11 @@ _EMPTY = {}
 class LeoPowerAttVecEnv(object):
     def __init__(self, num_envs, n_rw=4, gravity_model=GRAV_PM_J2, step_duration=180., dynRate=0.1, fswRate=1.0,
                  seed=0, device=0, cfg=None, auto_reset=True, propagator_factory=None, power=True, sun_third_body=True, drag=True, desat=True,
-                 device_reset_pool=0):
+                 device_reset_pool=0, device_sampler=False):
         """``device_reset_pool`` > 0 stages that many random initial conditions on the device and lets
         the step kernel reset finished envs itself (no host round trip at episode boundaries); 0 keeps
-        the host-side masked reset with freshly sampled ICs."""
+        the host-side masked reset with freshly sampled ICs.  With ``device_sampler`` the pool itself is
+        drawn on the GPU (Philox4x32-10 keyed by ``seed``) and ``reset()`` restarts from it on the device."""
         self.num_envs = int(num_envs)
         self.observation_space = spaces.Box(-1e16, 1e16, shape=(5, 1))
         self.action_space = spaces.Discrete(3)
@@ -59,7 +60,13 @@ class LeoPowerAttVecEnv(object):
         self.device_reset = bool(cfg.flags & FLAG_AUTO_RESET)
         if self.device_reset:
             n_pool = int(device_reset_pool) or self.num_envs
-            self.propagator.set_ic_pool(sample_ic_batch(n_pool, self.n_rw, rng=self._rng))
+            self.device_sampler = bool(device_sampler)
+            if self.device_sampler:
+                self.propagator.sample_ic_pool(n_pool, seed)
+            else:
+                self.propagator.set_ic_pool(sample_ic_batch(n_pool, self.n_rw, rng=self._rng))
+        else:
+            self.device_sampler = False
         self.episode_returns = np.zeros(self.num_envs)
         self.episode_lengths = np.zeros(self.num_envs, dtype=np.int64)
 
@@ -84,8 +91,12 @@ class LeoPowerAttVecEnv(object):
 
     def reset(self, ic=None):
         """Reset every env (fresh random ICs unless ``ic`` [n_fields, N] is given) -> obs (N,5,1)."""
-        self._ic = sample_ic_batch(self.num_envs, self.n_rw, rng=self._rng) if ic is None else np.array(ic, dtype=np.float64)
-        self.propagator.reset(self._ic)
+        if ic is None and self.device_sampler:
+            self.propagator.reset_from_pool()           # no host data involved
+            self._ic = self.propagator.get_state()
+        else:
+            self._ic = sample_ic_batch(self.num_envs, self.n_rw, rng=self._rng) if ic is None else np.array(ic, dtype=np.float64)
+            self.propagator.reset(self._ic)
         self.episode_returns[:] = 0
         self.episode_lengths[:] = 0
         return self._initial_obs(self._ic).T.reshape(self.num_envs, 5, 1)

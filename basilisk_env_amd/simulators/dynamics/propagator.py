@@ -168,6 +168,18 @@ class BatchedPropagator(object):
             raise ValueError("ic_pool must have shape (%d, n_pool)" % self.n_fields)
         check(self._lib.bsk_set_ic_pool(self._handle(), pool.shape[1], pool.ctypes.data))
 
+    def sample_ic_pool(self, n_pool, seed):
+        """Draw ``n_pool`` initial conditions on the device (Philox4x32-10, reference distributions)."""
+        check(self._lib.bsk_sample_ic_pool(self._handle(), int(n_pool), int(seed) & 0xFFFFFFFFFFFFFFFF))
+
+    def reset_from_pool(self, mask=None):
+        """(Re)start all (or the masked) envs from the staged pool, entirely on the device."""
+        mp = None
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+            mp = mask.ctypes.data
+        check(self._lib.bsk_reset_from_pool(self._handle(), mp))
+
     def get_terminal_obs(self):
         """-> terminal observations (5, N) (valid where the last step reported done), finished-episode
         counts (N,) int32."""

@@ -207,11 +207,21 @@ int bsk_get_counters(bsk_handle* h, int32_t* steps, int32_t* ticks);
  * initial observation [|sigma_BN|, |omega|, |Omega|/limit, charge/3600/power_max, 1] to obs and keeps
  * the finished episode's last observation in the terminal-observation buffer. */
 int bsk_set_ic_pool(bsk_handle* h, int n_pool, const double* ic_pool);
+/* On-device IC sampler: fill the pool with `n_pool` initial conditions drawn on the GPU with the
+ * reference's distributions (set_ICs, …Simulator.py:119-193; leo_orbit.py:25-40; sc_attitudes.py:3-13):
+ * a = 6 871 km, e~U[0,.05), i~U[-90,90) deg, Omega, omega, f~U[0,360) deg -> elem2rv; sigma~U[0,1)^3;
+ * omega~U(+-1e-5)^3 rad/s; L_ext = 2e-4 N(0,1)^3 N m; wheel speeds U(-800,800) RPM; charge U(8,20) W h.
+ * Random numbers: Philox4x32-10, key = seed, counter = (slot, draw index): slot k is reproducible
+ * on its own.  Needs BSK_FLAG_AUTO_RESET.  bsk_reset_from_pool then (re)starts every env (mask NULL)
+ * or the masked envs from the pool with the slot rule above, without any host data. */
+int bsk_sample_ic_pool(bsk_handle* h, int n_pool, uint64_t seed);
+int bsk_reset_from_pool(bsk_handle* h, const uint8_t* mask);
 /* terminal observations f64[5][n_envs] (valid for envs whose done flag is set) and per-env
  * finished-episode counts int32[n_envs]; either pointer may be NULL.  Synchronises. */
 int bsk_get_terminal_obs(bsk_handle* h, double* term_obs, int32_t* episodes);
 
-/* Sun state override for the next steps (inertial, Earth-centred) — see sun_r0/sun_v. */
+/* Epoch offset [s] added to every spacecraft's own clock (ticks * dt) when the Sun position
+ * sun_r0 + sun_v * t is evaluated at the start of an env step (default 0). */
 int bsk_set_sim_time(bsk_handle* h, double t_seconds);
 
 int bsk_sync(bsk_handle* h);

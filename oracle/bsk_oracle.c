@@ -518,7 +518,6 @@ int orc_step(const bsk_config* c, int n, double* state, int32_t* steps, int32_t*
     orc_ctx ctx;
     if (ctx_init(&ctx, c, cbar, sbar)) return -1;
     const int nrw = c->n_rw, tail = BSK_NF_BASE + nrw;
-    (void)sim_time0;
 #define S(f, i) state[(size_t)(f) * n + (i)]
 #ifdef ORC_OMP
 #pragma omp parallel for schedule(static)
@@ -538,7 +537,7 @@ int orc_step(const bsk_config* c, int n, double* state, int32_t* steps, int32_t*
         /* Sun position: evaluated at the start of the env step from this spacecraft's own clock and
            held over the step, like the 180 s SPICE task (…Simulator.py:102,357) */
         double sun[3];
-        for (int k = 0; k < 3; ++k) sun[k] = c->sun_r0[k] + c->sun_v[k] * (tick * c->dt);
+        for (int k = 0; k < 3; ++k) sun[k] = (c->sun_r0[k] + c->sun_v[k] * sim_time0) + c->sun_v[k] * (tick * c->dt);
         for (int j = 0; j < substeps; ++j, ++tick) {
             if (nrw > 0 && tick % c->fsw_every == 0) {
                 att_guid g;

@@ -22,6 +22,7 @@ class OraclePropagator(object):
         self._out = None
         self._cbar = self._sbar = None
         self._pool = None
+        self._t0 = 0.0
         self.episodes = np.zeros(self.n_envs, np.int32)
         self._term_obs = np.zeros((5, self.n_envs))
 
@@ -56,12 +57,27 @@ class OraclePropagator(object):
 
     def step(self, actions, substeps):
         self._out = oracle.step(self.cfg, self.state, self.steps, self.ticks, np.asarray(actions, np.int32), substeps,
-                                cbar=self._cbar, sbar=self._sbar)
+                                sim_time0=self._t0, cbar=self._cbar, sbar=self._sbar)
         if self._pool is not None:
             self._auto_reset()
 
     def set_ic_pool(self, ic_pool):
         self._pool = np.array(ic_pool, dtype=np.float64)
+
+    def sample_ic_pool(self, n_pool, seed):
+        from _philox_ref import sample_pool
+        self._pool = sample_pool(n_pool, self.n_rw, seed & 0xFFFFFFFFFFFFFFFF, mu=self.cfg.mu)
+
+    def reset_from_pool(self, mask=None):
+        n_pool = self._pool.shape[1]
+        for i in range(self.n_envs):
+            if mask is not None and not mask[i]:
+                continue
+            slot = ((i * 2654435761 + int(self.episodes[i]) * 40503 + 12345) & 0xFFFFFFFF) % n_pool
+            self.episodes[i] += 1
+            self.state[:, i] = self._pool[:, slot]
+            self.steps[i] = 0
+            self.ticks[i] = 0
 
     def get_terminal_obs(self):
         return self._term_obs.copy(), self.episodes.copy()
@@ -92,3 +108,6 @@ class OraclePropagator(object):
 
     def sync(self):
         pass
+
+    def set_sim_time(self, t):
+        self._t0 = float(t)

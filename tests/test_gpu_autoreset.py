@@ -84,3 +84,83 @@ def test_vec_env_device_reset():
             assert np.abs(ig[i]["terminal_observation"] - ic[i]["terminal_observation"]).max() < 1e-8
     assert dg.any() or True
     g.close()
+
+
+def test_philox_known_answer():
+    """Philox4x32-10 known-answer vectors from the Random123 distribution (kat_vectors)."""
+    from _philox_ref import philox4x32_10
+    assert philox4x32_10(0, 0, 0, 0, 0, 0) == (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)
+    assert philox4x32_10(0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff) == \
+        (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)
+    assert philox4x32_10(0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0) == \
+        (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)
+
+
+@pytest.mark.parametrize("n_rw", [0, 3, 4])
+def test_device_sampler_matches_reference_and_distributions(n_rw):
+    from _philox_ref import sample_pool
+    cfg = default_config(n_rw, GRAV_PM)
+    cfg.flags |= FLAG_AUTO_RESET
+    n = 256
+    p = BatchedPropagator(cfg, n)
+    p.sample_ic_pool(500, seed=0x1234567890ABCDEF)
+    p.reset_from_pool()
+    st = p.get_state()
+    ref = sample_pool(500, n_rw, 0x1234567890ABCDEF)
+    for i in range(n):
+        slot = ((i * 2654435761 + 12345) & 0xFFFFFFFF) % 500
+        for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 12), slice(12, None)):   # per vector, not per component
+            scale = max(np.abs(ref[sl, slot]).max(), 1e-300)
+            assert np.abs(st[sl, i] - ref[sl, slot]).max() / scale < 1e-14, (i, sl)
+    # uniforms are bit-exact: sigma is a raw uniform
+    assert np.array_equal(st[6:9, 0], ref[6:9, ((0 * 2654435761 + 12345) & 0xFFFFFFFF) % 500])
+    _, eps = p.get_terminal_obs()
+    assert (eps == 1).all() and (p.get_counters()[0] == 0).all()
+    # distribution sanity on a large pool
+    p.sample_ic_pool(65536, seed=7)
+    p.reset_from_pool()                                   # episode 1 slots
+    big = BatchedPropagator(cfg, 65536)
+    big.sample_ic_pool(65536, seed=7)
+    big.reset_from_pool()
+    s = big.get_state()
+    r = np.linalg.norm(s[0:3], axis=0)
+    assert 6871e3 * 0.95 - 1 < r.min() and r.max() < 6871e3 * 1.05 + 1
+    assert 0 <= s[6:9].min() and s[6:9].max() < 1 and abs(s[6:9].mean() - 0.5) < 0.01
+    assert np.abs(s[9:12]).max() <= 1e-5
+    t = 12 + n_rw
+    assert abs(s[t:t + 3].std() - 2e-4) < 5e-6 and abs(s[t:t + 3].mean()) < 5e-6
+    assert 8 * 3600 <= s[t + 7].min() and s[t + 7].max() <= 20 * 3600
+    if n_rw:
+        assert np.abs(s[12:12 + n_rw]).max() <= 800 * 2 * np.pi / 60
+    # masked reset only touches the masked envs
+    before = p.get_state()
+    mask = np.zeros(n, np.uint8)
+    mask[::5] = 1
+    p.reset_from_pool(mask)
+    after = p.get_state()
+    assert np.array_equal(after[:, mask == 0], before[:, mask == 0]) and not np.array_equal(after[:, mask == 1], before[:, mask == 1])
+    p.close()
+    big.close()
+
+
+def test_vec_env_fully_on_device_episodes():
+    """device_sampler: ICs drawn on the GPU, resets on the GPU; the host only sends actions."""
+    n = 200
+    cfg = default_config(3, GRAV_PM)
+    cfg.flags |= FLAG_AUTO_RESET
+    cfg.max_length = 2
+    g = LeoPowerAttVecEnv(n, cfg=cfg, step_duration=1.0, seed=99, device_reset_pool=128, device_sampler=True)
+    c = LeoPowerAttVecEnv(n, cfg=cfg, step_duration=1.0, seed=99, device_reset_pool=128, device_sampler=True,
+                          propagator_factory=OraclePropagator)
+    og, oc = g.reset(), c.reset()
+    assert np.abs(og - oc).max() < 1e-13
+    rng = np.random.default_rng(1)
+    finished = 0
+    for _ in range(7):
+        a = rng.integers(0, 3, n)
+        og, rg, dg, _ = g.step(a)
+        oc, rc, dc, _ = c.step(a)
+        assert np.array_equal(dg, dc) and np.abs(og - oc).max() < 1e-10 and np.abs(rg - rc).max() < 1e-13
+        finished += int(dg.sum())
+    assert finished >= 2 * n
+    g.close()

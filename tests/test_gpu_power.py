@@ -75,3 +75,25 @@ def test_penumbra_values_match_oracle():
     assert ((obs[4] > 0.01) & (obs[4] < 0.99)).sum() > 20
     assert np.abs(obs[4] - o[0][4]).max() < 2e-8          # formula conditioning, see above
     prop.close()
+
+
+def test_sim_time_offset_moves_the_sun():
+    """bsk_set_sim_time shifts the Sun ephemeris epoch: half a year later the eclipse geometry flips."""
+    from _oracle_backend import OraclePropagator
+    n = 128
+    cfg = default_config(0, GRAV_PM)
+    cfg.flags |= FLAG_POWER
+    ic = sample_ic_batch(n, 0, seed=4)
+    act = np.ones(n, np.int32)
+    outs = []
+    for t0 in (0.0, 182.6 * 86400.0):
+        g, c = BatchedPropagator(cfg, n), OraclePropagator(cfg, n)
+        for p in (g, c):
+            p.set_sim_time(t0)
+            p.reset(ic)
+            p.step(act, 50)
+        og, oc = g.get_obs()[0], c.get_obs()[0]
+        assert np.abs(og[:4] - oc[:4]).max() < 1e-11 and np.abs(og[4] - oc[4]).max() < 2e-8
+        outs.append(og[4].copy())
+        g.close()
+    assert (outs[0] != outs[1]).sum() > n // 4         # a different set of spacecraft is in shadow
