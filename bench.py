@@ -189,7 +189,7 @@ def main():
     kernel_s = kernel_ms * 1e-3
     achieved = BYTES_PER_ENV_STEP * n / kernel_s / 1e9 if kernel_s > 0 else 0.0
     out = {
-        "metric": "env steps/sec at 65k parallel spacecraft per GPU",
+        "metric": "env steps/sec at 65k parallel spacecraft, 1/2/4/8 MI355X; HBM GB/s vs roofline",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
