@@ -43,19 +43,22 @@ def parse():
     p.add_argument("--substeps", type=int, default=1, help="RK4 sub-steps per env step")
     p.add_argument("--gravity", choices=["j2", "sh"], default="j2",
                    help="j2 = BASELINE configs[2] (headline); sh = configs[4], degree-70 spherical harmonics")
+    p.add_argument("--stamp-every-launch", action="store_true",
+                   help="dispatch-timestamp every launch of the timed region (lower throughput, every kernel isolated; "
+                        "used for the rocprofv3 kernel-trace passes so that both report the same thing)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true")
     return p.parse_args()
 
 
-def timed_run(prop, d_act_ptr, substeps, steps, warmup, barrier, torch):
+def timed_run(prop, d_act_ptr, substeps, steps, warmup, barrier, torch, stamp_all=False):
     for _ in range(warmup):
         prop.step_device(d_act_ptr, substeps)
     prop.sync()
     # dispatch timestamps on a sample of the timed launches: stamping costs ~5 us of launch throughput
     # per stamped launch, so a pair is stamped every 16 launches and its second launch counted (every
     # launch for short runs); see bsk_profile_set_stride
-    stride = 16 if steps >= 64 else 1
+    stride = 16 if (steps >= 64 and not stamp_all) else 1
     prop.profile_begin(steps, stride=stride)
     barrier()
     torch.cuda.synchronize()
@@ -163,7 +166,8 @@ def main():
     d_act = torch.zeros(n, dtype=torch.int32, device="cuda")  # action 0 = nadir pointing (reward mode)
     torch.cuda.synchronize()
 
-    el, kernel_ms, n_launch = timed_run(prop, d_act.data_ptr(), a.substeps, a.steps, a.warmup, barrier, torch)
+    el, kernel_ms, n_launch = timed_run(prop, d_act.data_ptr(), a.substeps, a.steps, a.warmup, barrier, torch,
+                                        stamp_all=a.stamp_every_launch)
     el_t = torch.tensor([el], dtype=torch.float64, device="cuda")
     if dist is not None:
         dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
@@ -203,6 +207,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_bytes, "traffic_unit": "bytes/launch",
                      "traffic_source": traffic_src, "algorithmic_bytes": BYTES_PER_ENV_STEP * n,
                      "kernel": info["name"], "kernel_us": kernel_ms * 1e3, "launches_timed": n_launch,
+                     "stamping": "every launch" if (a.stamp_every_launch or a.steps < 64) else "pairs every 16 launches, second counted",
                      "bytes_per_env_step": BYTES_PER_ENV_STEP, "vgprs": info["vgprs"], "block": info["block"],
                      "grid": info["grid"]},
         "rk4_substeps_per_s": value * a.substeps,
