@@ -86,3 +86,23 @@ def test_abi_rejects_bad_config():
     assert lib.bsk_create(ctypes.byref(c), 0, 0, None, ctypes.byref(h)) == -1
     assert lib.bsk_step(None, None, 1) == -1 and lib.bsk_get_obs(None, None, None, None, None) == -1
     assert lib.bsk_version().startswith(b"bskgpu")
+
+
+def test_header_is_valid_c99():
+    """include/bskgpu.h compiles as C (not only as C++): it is the contract a cgo/JNI/ctypes binding reads."""
+    import subprocess
+    src = '#include "bskgpu.h"\nint main(void){bsk_config c; (void)c; return (int)sizeof(bsk_config) == 0;}\n'
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
+                        "-x", "c", "-"], input=src.encode(), capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+
+
+def test_c_consumer_links_against_the_library(tmp_path):
+    """A plain C program builds and links against libbskgpu.so through the header alone."""
+    import subprocess
+    exe = tmp_path / "c_abi_smoke"
+    libdir = os.path.dirname(_lib.lib_path())
+    r = subprocess.run(["gcc", "-std=c99", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_abi", "c_abi_smoke.c"),
+                        "-L", libdir, "-lbskgpu", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)],
+                       capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
