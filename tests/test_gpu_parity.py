@@ -284,3 +284,29 @@ def test_long_horizon_error_growth():
         assert np.abs(prop.get_obs()[0] - o[0]).max() < 1e-9
     assert worst < 1e-9, worst
     prop.close()
+
+
+def test_large_ragged_batch_block256():
+    """>= 2^20 envs switch to 256-thread workgroups; a ragged size there (last workgroup and last
+    wave partial) against the oracle on a sample of envs including the very last ones."""
+    n, n_rw = (1 << 20) + 77, 4
+    cfg = default_config(n_rw, GRAV_PM_J2)
+    ic = sample_ic_batch(n, n_rw, seed=12)
+    prop = BatchedPropagator(cfg, n)
+    assert prop.kernel_info()["block"] == 256
+    prop.reset(ic)
+    act = (np.arange(n) % 3).astype(np.int32)
+    prop.step(act, 12)
+    obs, rew, done, why = prop.get_obs()
+    st = prop.get_state()
+    idx = np.concatenate([np.arange(0, 70), np.arange(n - 130, n), np.linspace(1000, n - 1000, 100).astype(int)])
+    sub = np.ascontiguousarray(ic[:, idx])
+    steps, ticks = np.zeros(idx.size, np.int32), np.zeros(idx.size, np.int32)
+    o = oracle.step(cfg, sub, steps, ticks, act[idx], 12)
+    errs = max_group_err(st[:, idx], sub, n_rw)
+    assert max(errs.values()) < TOL, errs
+    assert np.abs(obs[:, idx] - o[0]).max() < TOL
+    rsum, ndone = prop.batch_stats()
+    assert abs(rsum - rew.sum()) < 1e-8 and ndone == int(done.sum())
+    assert np.isfinite(st).all()
+    prop.close()
