@@ -497,6 +497,10 @@ int bsk_create(const bsk_config* cfg, int n_envs, int device_id, void* stream, b
     // 64-lane workgroups spread a small batch over more CUs (65 536 envs = 1 024 waves = 4 per CU);
     // large batches use 256 so the dispatcher has fewer workgroups to place.
     h->block = n_envs >= (1 << 20) ? 256 : 64;
+    if (const char* b = std::getenv("BSKGPU_BLOCK")) {   // measurement override: 64, 128 or 256
+        const int v = std::atoi(b);
+        if (v == 64 || v == 128 || v == 256) h->block = v;
+    }
     if (stream) { h->stream = (hipStream_t)stream; h->own_stream = false; }
     else {
         hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);

