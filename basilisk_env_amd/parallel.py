@@ -48,6 +48,8 @@ def gather_observations(prop, dist, dst=None, group=None):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     local = local_obs_tensor(prop)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        local = local.cpu()   # gloo moves bytes through the host (CPU tests, single-GPU rehearsals)
     n_local = local.shape[1]
     sizes = [None] * world
     dist.all_gather_object(sizes, n_local, group=group)

@@ -37,8 +37,8 @@ FLOP_PER_RK4 = 4 * 330 + 110  # SURVEY.md §8(d) algorithmic flops per RK4 sub-s
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=200)
-    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--steps", type=int, default=1000)
+    p.add_argument("--warmup", type=int, default=50)
     p.add_argument("--envs", type=int, default=65536, help="spacecraft per GPU")
     p.add_argument("--substeps", type=int, default=1, help="RK4 sub-steps per env step")
     p.add_argument("--gravity", choices=["j2", "sh"], default="j2",
@@ -66,8 +66,8 @@ def timed_run(prop, d_act_ptr, substeps, steps, warmup, barrier, torch, stamp_al
     for _ in range(steps):
         prop.step_device(d_act_ptr, substeps)
     torch.cuda.synchronize()
+    t1 = time.perf_counter()   # this rank's K steps are done; the MAX over ranks is taken by the caller
     barrier()
-    t1 = time.perf_counter()
     kernel_ms, n_launch = prop.profile_end()
     return t1 - t0, kernel_ms, n_launch
 
@@ -138,11 +138,19 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: no HIP device visible (there is no CPU path to measure)")
+    # BENCH_REHEARSAL=1: exercise the N > 1 control flow on a box with a single GPU (every rank on
+    # device 0, gloo instead of RCCL).  Never set by the driver; numbers from it mean nothing.
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     def barrier():
         if dist is not None:
@@ -168,7 +176,7 @@ def main():
 
     el, kernel_ms, n_launch = timed_run(prop, d_act.data_ptr(), a.substeps, a.steps, a.warmup, barrier, torch,
                                         stamp_all=a.stamp_every_launch)
-    el_t = torch.tensor([el], dtype=torch.float64, device="cuda")
+    el_t = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
     if dist is not None:
         dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
     el = float(el_t.item())
