@@ -190,6 +190,18 @@ int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool&
     p.ex.inv_mass = c.mass > 0.0 ? 1.0 / c.mass : 0.0;
     p.ex.rho_skip = 1e-25;
     k.n_facets = c.n_facets;
+    k.facet_axis = 1;
+    for (int i = 0; i < c.n_facets && i < 8; ++i) {
+        // axis-aligned normal: exactly one component is +-1, the others exactly 0
+        int axis = -1, nz = 0;
+        for (int j = 0; j < 3; ++j)
+            if (c.facet_normal[i][j] != 0.0) { ++nz; axis = j; }
+        if (nz != 1 || std::fabs(c.facet_normal[i][axis]) != 1.0) { k.facet_axis = 0; break; }
+        const int sgn = c.facet_normal[i][axis] > 0.0 ? 0 : 1;
+        const double acd = c.facet_area[i] * c.facet_cd[i];
+        k.fa_c[sgn][axis] += acd;
+        for (int j = 0; j < 3; ++j) k.fa_r[sgn][axis][j] += acd * c.facet_pos[i][j];
+    }
     for (int i = 0; i < 8; ++i) {
         k.facet_acd[i] = c.facet_area[i] * c.facet_cd[i];
         for (int j = 0; j < 3; ++j) { k.facet_n[i][j] = c.facet_normal[i][j]; k.facet_r[i][j] = c.facet_pos[i][j]; }

@@ -126,7 +126,12 @@ struct ColdCfg {
     // facetDragDynamicEffector geometry (read only inside the drag branch)
     double facet_acd[8];        // area * Cd
     double facet_n[8][3], facet_r[8][3];
+    // facets whose normals are +-body axes (all eight of the reference's): per axis k and sign,
+    // sum of area*Cd and sum of area*Cd*r (facet_axis = 1 when every facet is of that kind)
+    double fa_c[2][3];       // [0]: normal +e_k, [1]: normal -e_k
+    double fa_r[2][3][3];
     int32_t n_facets, n_thr;
+    int32_t facet_axis, pad2_;
     // desaturation chain (FEAT_FULL + BSK_FLAG_DESAT)
     double thr_map[BSK_MAX_THR][3];   // thrForceMapping: [D]^T ([D][D]^T)^-1, D_i = r_i x dir_i
     double thr_f[BSK_MAX_THR][3], thr_l[BSK_MAX_THR][3];  // force / torque of thruster i at full thrust, body frame
@@ -238,7 +243,8 @@ __device__ __forceinline__ double shadow_factor(const PowerCfg& pc, const SunGeo
     const double c1 = s0 + g.re_sf1, c2 = s0 - g.re_sf2;
     const double l2v = fma(-s0, s0, r2);                 // squared distance from the shadow axis
     const double l1 = c1 * g.tf1, l2 = c2 * g.tf2;
-    if (l2v < l2 * l2 || l2v < l1 * l1) return percent_shadow(pc, g.sun - r, r, r2);
+    if (l2v < l2 * l2 && c2 < 0.0) return 0.0;          // inside the umbra cone: the disc is fully covered
+    if (l2v < l2 * l2 || l2v < l1 * l1) return percent_shadow(pc, g.sun - r, r, r2);   // penumbra / antumbra band
     return 1.0;
 }
 
@@ -433,6 +439,10 @@ struct Env {
     // thrusterDynamicEffector: current burst, on-time per thruster in half dyn steps, elapsed e2
     double thr_lim[BSK_MAX_THR];
     int e2;
+    // axis-aligned facet tables (registers; loaded once per launch when drag is enabled)
+    bool facet_axis;
+    double fa_c[2][3];
+    V3 fa_r[2][3];
 };
 
 // thrust of the active thrusters at integrator time e2 (half dyn steps since the burst started)
@@ -462,17 +472,34 @@ __device__ __forceinline__ void facet_drag(const Env& ev, V3 sig, V3 vN, V3& aN,
     const V3 vB = vN + ka * t2 - kb * t1;                 // [BN] v
     const double v2 = dot(vB, vB), iv = rsqrt_nr(v2);
     const V3 vh = iv * vB;
-    V3 FB = mk(0, 0, 0);
-    LB = mk(0, 0, 0);
-    const ColdCfg* cc = ev.cold;
-    for (int i = 0; i < cc->n_facets; ++i) {
-        const double proj = fma(cc->facet_n[i][0], vh.x, fma(cc->facet_n[i][1], vh.y, cc->facet_n[i][2] * vh.z));
-        if (proj > 0.0) {
-            const V3 f = (-0.5 * v2 * cc->facet_acd[i] * proj * ev.rho) * vh;
-            FB = FB + f;
-            LB = LB + cross(mk(cc->facet_r[i][0], cc->facet_r[i][1], cc->facet_r[i][2]), f);
+    V3 FB, Rc;          // F_B = -1/2 rho v^2 S v_hat,  L_B = Rc x (-1/2 rho v^2 v_hat),  S = sum c_i, Rc = sum c_i r_i
+    double S = 0.0;
+    Rc = mk(0, 0, 0);
+    if (ev.facet_axis) {
+        // normals are +-e_k: n_i . v_hat = +-v_hat_k, so only the facets facing the flow on each axis count
+        const double vk[3] = {vh.x, vh.y, vh.z};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const bool pos = vk[k] > 0.0;
+            const double a = fabs(vk[k]);
+            S = fma(a, pos ? ev.fa_c[0][k] : ev.fa_c[1][k], S);
+            const V3 rk = pos ? ev.fa_r[0][k] : ev.fa_r[1][k];
+            Rc = axpy(a, rk, Rc);
+        }
+    } else {
+        const ColdCfg* cc = ev.cold;
+        for (int i = 0; i < cc->n_facets; ++i) {
+            const double proj = fma(cc->facet_n[i][0], vh.x, fma(cc->facet_n[i][1], vh.y, cc->facet_n[i][2] * vh.z));
+            if (proj > 0.0) {
+                const double ci = cc->facet_acd[i] * proj;
+                S += ci;
+                Rc = axpy(ci, mk(cc->facet_r[i][0], cc->facet_r[i][1], cc->facet_r[i][2]), Rc);
+            }
         }
     }
+    const V3 q = (-0.5 * v2 * ev.rho) * vh;
+    FB = S * q;
+    LB = cross(Rc, q);
     // a_N = [BN]^T F_B / m  (transpose: flip the sign of the odd term)
     const V3 u1 = cross(sig, FB), u2 = cross(sig, u1);
     aN = ev.inv_mass * (FB + ka * u2 + kb * u1);

@@ -43,6 +43,9 @@ def parse():
     p.add_argument("--substeps", type=int, default=1, help="RK4 sub-steps per env step")
     p.add_argument("--gravity", choices=["j2", "sh"], default="j2",
                    help="j2 = BASELINE configs[2] (headline); sh = configs[4], degree-70 spherical harmonics")
+    p.add_argument("--scenario", choices=["bare", "power", "full"], default="bare",
+                   help="bare = BASELINE configs[2] as named (headline); power / full add the reference scenario's "
+                        "power system / + Sun third body, drag and desaturation (what the drop-in env runs)")
     p.add_argument("--stamp-every-launch", action="store_true",
                    help="dispatch-timestamp every launch of the timed region (lower throughput, every kernel isolated; "
                         "used for the rocprofv3 kernel-trace passes so that both report the same thing)")
@@ -164,6 +167,9 @@ def main():
     n_rw = 4
     sh = a.gravity == "sh"
     cfg = default_config(n_rw=n_rw, gravity_model=GRAV_SH if sh else GRAV_PM_J2)
+    if a.scenario != "bare":
+        from basilisk_env_amd._lib import FLAG_DESAT, FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY
+        cfg.flags |= FLAG_POWER | ((FLAG_SUN_THIRD_BODY | FLAG_DRAG | FLAG_DESAT) if a.scenario == "full" else 0)
     n = a.envs
     ic = sample_ic_batch(n, n_rw, seed=rank)       # rank r owns env indices [r*n, (r+1)*n)
     prop = BatchedPropagator(cfg if not sh else _with_degree(cfg, 70), n, device=local)
@@ -210,7 +216,8 @@ def main():
                                "sub-steps, synthetic random-orbit batch PCG64(rank)"
                                % ("4" if sh else "2", n, "degree-70 spherical-harmonic (synthetic Kaula field)" if sh else "J2",
                                   a.substeps),
-                   "envs_per_gpu": n, "substeps": a.substeps, "sharding": "env ranges, no step-path collective"},
+                   "envs_per_gpu": n, "substeps": a.substeps, "scenario": a.scenario,
+                   "sharding": "env ranges, no step-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_bytes, "traffic_unit": "bytes/launch",
                      "traffic_source": traffic_src, "algorithmic_bytes": BYTES_PER_ENV_STEP * n,
