@@ -23,7 +23,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
-from basilisk_env_amd._lib import GRAV_PM, GRAV_PM_J2, n_fields  # noqa: E402
+from basilisk_env_amd._lib import GRAV_PM, GRAV_PM_J2, GRAV_SH, n_fields  # noqa: E402
+from basilisk_env_amd.simulators.dynamics.gravity_sh import sh_index, synthetic_sh_coefficients  # noqa: E402
 from basilisk_env_amd.simulators.dynamics.config import config_to_dict, default_config  # noqa: E402
 from basilisk_env_amd.simulators.initial_conditions.batch import sample_ic_batch  # noqa: E402
 
@@ -160,7 +161,77 @@ class Model(object):
         self.reward_mult, self.failure_penalty = M(float(c["reward_mult"])), M(float(c["failure_penalty"]))
         self.r_min, self.max_length = M(float(c["r_min"])), int(c["max_length"])
 
-    def gravity(self, r):
+    def set_sh(self, degree, cbar, sbar, planet_rate):
+        """Pines' normalised recursion, row-major tables as Basilisk documents them."""
+        self.deg = degree
+        self.C = {(l, m): M(float(cbar[sh_index(l, m)])) for l in range(degree + 1) for m in range(l + 1)}
+        self.S = {(l, m): M(float(sbar[sh_index(l, m)])) for l in range(degree + 1) for m in range(l + 1)}
+        self.planet_rate = M(float(planet_rate))
+        K = lambda i: 1 if i == 0 else 2  # noqa: E731
+        d = degree
+        self.diag = {0: M(1)}
+        for l in range(1, d + 2):
+            self.diag[l] = mp.sqrt(M((2 * l + 1) * K(l)) / (2 * l * K(l - 1))) * self.diag[l - 1]
+        self.n1, self.n2, self.nq1, self.nq2 = {}, {}, {}, {}
+        for l in range(d + 2):
+            for m in range(l + 1):
+                if l >= m + 2:
+                    self.n1[l, m] = mp.sqrt(M((2 * l + 1) * (2 * l - 1)) / ((l - m) * (l + m)))
+                    self.n2[l, m] = mp.sqrt(M((l + m - 1) * (2 * l + 1) * (l - m - 1)) / ((l + m) * (l - m) * (2 * l - 3)))
+        for l in range(d + 1):
+            for m in range(l + 1):
+                if m < l:
+                    self.nq1[l, m] = mp.sqrt(M((l - m) * K(m) * (l + m + 1)) / K(m + 1))
+                self.nq2[l, m] = mp.sqrt(M((l + m + 2) * (l + m + 1) * (2 * l + 1) * K(m)) / ((2 * l + 3) * K(m + 1)))
+        self.kfac = K
+
+    def sh_field(self, p):
+        d, K = self.deg, self.kfac
+        r = norm(p)
+        s, t, u = p[0] / r, p[1] / r, p[2] / r
+        A = {}
+        for l in range(d + 2):
+            A[l, l] = self.diag[l]
+        for l in range(1, d + 2):
+            A[l, l - 1] = mp.sqrt(M(2 * l * K(l - 1)) / K(l)) * A[l, l] * u
+        rE, iM = [M(1)], [M(0)]
+        for m in range(d + 2):
+            for l in range(m + 2, d + 2):
+                A[l, m] = u * self.n1[l, m] * A[l - 1, m] - self.n2[l, m] * A[l - 2, m]
+            if m > 0:
+                rE.append(s * rE[m - 1] - t * iM[m - 1])
+                iM.append(s * iM[m - 1] + t * rE[m - 1])
+        rho = self.req / r
+        rhol = [self.mu / r, self.mu / r * rho]
+        a1 = a2 = a3 = M(0)
+        a4 = -rhol[1] / self.req
+        for l in range(1, d + 1):
+            rhol.append(rho * rhol[l])
+            s1 = s2 = s3 = s4 = M(0)
+            for m in range(l + 1):
+                cb, sb = self.C[l, m], self.S[l, m]
+                D = cb * rE[m] + sb * iM[m]
+                E = cb * rE[m - 1] + sb * iM[m - 1] if m > 0 else M(0)
+                F = sb * rE[m - 1] - cb * iM[m - 1] if m > 0 else M(0)
+                s1 += m * A[l, m] * E
+                s2 += m * A[l, m] * F
+                if m < l:
+                    s3 += self.nq1[l, m] * A[l, m + 1] * D
+                s4 += self.nq2[l, m] * A[l + 1, m + 1] * D
+            w = rhol[l + 1] / self.req
+            a1 += w * s1
+            a2 += w * s2
+            a3 += w * s3
+            a4 -= w * s4
+        return [a1 + s * a4, a2 + t * a4, a3 + u * a4]
+
+    def gravity(self, r, t=None):
+        if self.grav == GRAV_SH:
+            th = self.planet_rate * t
+            ct, st = mp.cos(th), mp.sin(th)
+            p = [ct * r[0] + st * r[1], -st * r[0] + ct * r[1], r[2]]
+            ap = self.sh_field(p)
+            return [ct * ap[0] - st * ap[1], st * ap[0] + ct * ap[1], ap[2]]
         rm = norm(r)
         a = scale(-self.mu / rm ** 3, r)
         if self.grav == GRAV_PM_J2:
@@ -178,9 +249,9 @@ class Model(object):
             tq.append(u[i] + fr)
         return tq
 
-    def eom(self, x, tq, lext):
+    def eom(self, x, tq, lext, t=None):
         r, v, s, w, Om = x[0:3], x[3:6], x[6:9], x[9:12], x[12:]
-        dv = self.gravity(r)
+        dv = self.gravity(r, t)
         s2, sw, sxw = dot(s, s), dot(s, w), cross(s, w)
         ds = [((1 - s2) * w[k] + 2 * sxw[k] + 2 * sw * s[k]) / 4 for k in range(3)]
         rhs = add(scale(-1, cross(w, matvec(self.I, w))), lext)
@@ -191,14 +262,15 @@ class Model(object):
         dOm = [tq[i] / self.js[i] - dot(self.gs[i], dw) for i in range(self.n_rw)]
         return list(v) + dv + ds + dw + dOm
 
-    def rk4(self, x, u, lext):
+    def rk4(self, x, u, lext, t=None):
         h = self.dt
         ax = lambda a, k, y: [yi + a * ki for yi, ki in zip(y, k)]  # noqa: E731
         u = self.wheel_torque(x, u)   # held over the four stages
-        k1 = self.eom(x, u, lext)
-        k2 = self.eom(ax(h / 2, k1, x), u, lext)
-        k3 = self.eom(ax(h / 2, k2, x), u, lext)
-        k4 = self.eom(ax(h, k3, x), u, lext)
+        t = M(0) if t is None else t
+        k1 = self.eom(x, u, lext, t)
+        k2 = self.eom(ax(h / 2, k1, x), u, lext, t + h / 2)
+        k3 = self.eom(ax(h / 2, k2, x), u, lext, t + h / 2)
+        k4 = self.eom(ax(h, k3, x), u, lext, t + h)
         x = [x[i] + h / 6 * k1[i] + h / 3 * k2[i] + h / 3 * k3[i] + h / 6 * k4[i] for i in range(len(x))]
         s2 = dot(x[6:9], x[6:9])
         if s2 > 1:
@@ -247,7 +319,7 @@ class Model(object):
         for _ in range(substeps):
             if self.n_rw and env["ticks"] % self.fsw_every == 0:
                 u = self.control(self.guidance(x, action))
-            x = self.rk4(x, u, env["lext"])
+            x = self.rk4(x, u, env["lext"], env["ticks"] * self.dt)
             env["ticks"] += 1
         env["x"], env["u"] = x, u
         sBR = self.guidance(x, action)[0]
@@ -270,11 +342,13 @@ class Model(object):
         return [o0, o1, o2, o3, M(1)], rew, why
 
 
-def run_case(name, n_rw, grav, n_envs, seed, schedule, cfg_edit=None):
+def run_case(name, n_rw, grav, n_envs, seed, schedule, cfg_edit=None, sh=None):
     cfg = default_config(n_rw=n_rw, gravity_model=grav)
     if cfg_edit:
         cfg_edit(cfg)
     model = Model(cfg)
+    if sh is not None:
+        model.set_sh(sh[0], sh[1], sh[2], cfg.planet_rate)
     ic = sample_ic_batch(n_envs, n_rw, seed=seed)
     nf = n_fields(n_rw)
     t = 12 + n_rw
@@ -300,22 +374,53 @@ def run_case(name, n_rw, grav, n_envs, seed, schedule, cfg_edit=None):
         calls.append({"actions": [int(a) for a in actions], "substeps": int(substeps), "state": state.tolist(),
                       "obs": np.array(obs).T.tolist(), "reward": rews, "reason": whys})
         print("  %s call %d/%d done" % (name, ci + 1, len(schedule)), flush=True)
-    return {"name": name, "n_rw": n_rw, "gravity_model": grav, "n_envs": n_envs, "seed": seed, "ic": ic.tolist(),
-            "calls": calls}
+    out = {"name": name, "n_rw": n_rw, "gravity_model": grav, "n_envs": n_envs, "seed": seed, "ic": ic.tolist(),
+           "calls": calls}
+    if sh is not None:
+        out["sh_degree"], out["cbar"], out["sbar"] = sh[0], [float(v) for v in sh[1]], [float(v) for v in sh[2]]
+    return out
 
 
 def main():
+    """No arguments: regenerate every case.  `--only NAME [NAME..]`: regenerate just those cases and merge
+    them into the existing trajectories.json (the others are kept byte for byte)."""
+    only = sys.argv[sys.argv.index("--only") + 1:] if "--only" in sys.argv else None
     n = 8
     rng = np.random.Generator(np.random.PCG64(99))
-    cases = []
-    # config-2 shape: point mass + MRP attitude, no wheels; checkpoints at 1, 10, 100, 1000 RK4 steps
-    cases.append(run_case("pm_norw", 0, GRAV_PM, n, 11, [(np.zeros(n, int), k) for k in (1, 9, 90, 900)]))
-    # config-3 shape: J2 + 4-wheel pyramid; nadir/sun-point per env; u is held across the calls
-    cases.append(run_case("j2_rw4", 4, GRAV_PM_J2, n, 12, [(np.arange(n) % 2, k) for k in (1, 9, 90, 900)]))
-    # reference wiring: point mass + 3-wheel triad, mode switches between calls, odd call lengths
     sched = [(rng.integers(0, 3, n), int(k)) for k in (50, 37, 3, 110, 50, 50, 25, 75)]
-    cases.append(run_case("pm_rw3_modes", 3, GRAV_PM, n, 13, sched))
+    # config-5 shape at low degree: degree-8 synthetic field (harmonics exaggerated x100 so that a wrong
+    # term shows), rotating planet, 3 wheels, one mode per env; 4 envs, checkpoints at 1, 10, 100, 400 steps
+    cb, sb = synthetic_sh_coefficients(8, seed=8)
+    cb[3:] *= 100.0
+    sb[3:] *= 100.0
+
+    def sh_edit(cfg):
+        cfg.sh_degree = 8
+
+    recipes = [
+        # config-2 shape: point mass + MRP attitude, no wheels; checkpoints at 1, 10, 100, 1000 RK4 steps
+        ("pm_norw", lambda: run_case("pm_norw", 0, GRAV_PM, n, 11, [(np.zeros(n, int), k) for k in (1, 9, 90, 900)])),
+        # config-3 shape: J2 + 4-wheel pyramid; nadir/sun-point per env; u is held across the calls
+        ("j2_rw4", lambda: run_case("j2_rw4", 4, GRAV_PM_J2, n, 12, [(np.arange(n) % 2, k) for k in (1, 9, 90, 900)])),
+        # reference wiring: point mass + 3-wheel triad, mode switches between calls, odd call lengths
+        ("pm_rw3_modes", lambda: run_case("pm_rw3_modes", 3, GRAV_PM, n, 13, sched)),
+        ("sh8_rw3", lambda: run_case("sh8_rw3", 3, GRAV_SH, 4, 14, [(np.array([0, 1, 2, 0]), k) for k in (1, 9, 90, 300)],
+                                     cfg_edit=sh_edit, sh=(8, cb, sb))),
+    ]
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "trajectories.json")
+    cases = []
+    if only is not None:
+        with open(out) as f:
+            cases = json.load(f)["cases"]
+    for name, make in recipes:
+        if only is not None and name not in only:
+            continue
+        case = make()
+        idx = [i for i, c in enumerate(cases) if c["name"] == name]
+        if idx:
+            cases[idx[0]] = case
+        else:
+            cases.append(case)
     with open(out, "w") as f:
         json.dump({"dps": mp.mp.dps, "generator": "tests/golden/make_golden.py", "cases": cases}, f)
     print("wrote", out, os.path.getsize(out), "bytes")

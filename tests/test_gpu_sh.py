@@ -40,6 +40,24 @@ def test_sh_matches_oracle(degree, n_rw, n):
     prop.close()
 
 
+def test_sh_matches_golden(golden):
+    """Harmonics kernel against the 50-digit golden trajectory (degree 8, rotating planet, 3 wheels)."""
+    case = [c for c in golden["cases"] if c["name"] == "sh8_rw3"][0]
+    cfg = sh_cfg(case["n_rw"], case["sh_degree"])
+    ic = np.array(case["ic"])
+    prop = BatchedPropagator(cfg, ic.shape[1])
+    prop.set_gravity_sh(case["sh_degree"], np.array(case["cbar"]), np.array(case["sbar"]))
+    prop.reset(ic)
+    for call in case["calls"]:
+        prop.step(np.array(call["actions"], np.int32), call["substeps"])
+        obs, rew, done, why = prop.get_obs()
+        errs = max_group_err(prop.get_state(), np.array(call["state"]), case["n_rw"])
+        assert max(errs.values()) < 1e-11, (call["substeps"], errs)
+        assert np.abs(obs - np.array(call["obs"])).max() < 1e-11
+        assert (why == np.array(call["reason"])).all()
+    prop.close()
+
+
 def test_sh_degree2_equals_j2_kernel():
     """The harmonics kernel with only C20 reproduces the closed-form J2 kernel (different code
     paths on the device) to rounding."""
