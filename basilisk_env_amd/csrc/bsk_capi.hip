@@ -105,6 +105,60 @@ void build_sh_table(int d, const double* cbar, const double* sbar, std::vector<d
     tab.insert(tab.end(), 16, 0.0);   // spare entries: the kernel's software pipeline reads ahead
 }
 
+// Stream of the DPP-broadcast form (bsk_device.hpp: gravity_sh_dpp): same iteration order, 8 doubles
+// per entry, but (i) the recursion is rescaled column by column, Bt_L = B_L / alpha_L with
+// alpha_M = alpha_(M+1) = 1, alpha_L = n2(L, M) alpha_(L-2), so entry[0] = n1 alpha_(L-1) / alpha_L is
+// the only recursion constant and the six coefficient products carry alpha_L; (ii) every column is
+// padded to an even number of entries (a 128-byte chunk = 2 entries never straddles a column);
+// (iii) the stream is padded to whole four-chunk bodies plus four chunks of read-ahead slack.
+// Returns the number of four-chunk bodies.
+int build_sh_table_dpp(int d, const double* cbar, const double* sbar, std::vector<double>& tab) {
+    auto K = [](int i) { return i == 0 ? 1.0L : 2.0L; };
+    auto idx = [](int l, int m) { return l * (l + 1) / 2 + m; };
+    std::vector<long double> diag(d + 2), sd(d + 2), alpha(d + 3);
+    diag[0] = 1.0L;
+    for (int l = 1; l <= d + 1; ++l) diag[l] = sqrtl((long double)(2 * l + 1) * K(l) / ((long double)(2 * l) * K(l - 1))) * diag[l - 1];
+    for (int l = 1; l <= d + 1; ++l) sd[l] = sqrtl((long double)(2 * l) * K(l - 1) / K(l)) * diag[l];
+    auto n1 = [](int l, int m) { return sqrtl((long double)(2 * l + 1) * (long double)(2 * l - 1) / ((long double)(l - m) * (long double)(l + m))); };
+    auto n2 = [](int l, int m) {
+        return sqrtl((long double)(l + m - 1) * (long double)(2 * l + 1) * (long double)(l - m - 1) /
+                     ((long double)(l + m) * (long double)(l - m) * (long double)(2 * l - 3)));
+    };
+    auto nq1 = [&](int l, int m) { return sqrtl((long double)(l - m) * K(m) * (long double)(l + m + 1) / K(m + 1)); };
+    auto nq2 = [&](int l, int m) {
+        return sqrtl((long double)(l + m + 2) * (long double)(l + m + 1) * (long double)(2 * l + 1) * K(m) /
+                     ((long double)(2 * l + 3) * K(m + 1)));
+    };
+    tab.clear();
+    for (int M = 1; M <= d + 1; ++M) {
+        for (int L = M; L <= d + 1; ++L) {
+            long double e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            alpha[L] = (L <= M + 1) ? 1.0L : n2(L, M) * alpha[L - 2];
+            if (L == M) e[0] = diag[M];
+            else if (L == M + 1) e[0] = sd[M + 1] / diag[M];
+            else e[0] = n1(L, M) * alpha[L - 1] / alpha[L];
+            if (L <= d) {
+                e[2] = M * (long double)cbar[idx(L, M)];
+                e[3] = M * (long double)sbar[idx(L, M)];
+                const long double q = nq1(L, M - 1);
+                e[4] = q * cbar[idx(L, M - 1)];
+                e[5] = q * sbar[idx(L, M - 1)];
+            }
+            if (L >= 2) {
+                const long double q = nq2(L - 1, M - 1);
+                e[6] = q * cbar[idx(L - 1, M - 1)];
+                e[7] = q * sbar[idx(L - 1, M - 1)];
+            }
+            for (int k = 0; k < 8; ++k) tab.push_back((double)(k >= 2 ? e[k] * alpha[L] : e[k]));
+        }
+        if ((d + 1 - M + 1) & 1) tab.insert(tab.end(), 8, 0.0);   // odd column: one all-zero entry
+    }
+    const size_t chunks = tab.size() / 16;
+    const size_t bodies = (chunks + 3) / 4;
+    tab.resize((bodies * 4 + 4) * 16, 0.0);
+    return (int)bodies;
+}
+
 int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool& diag) {
     std::memset(&p, 0, sizeof p);
     std::memset(&k, 0, sizeof k);
@@ -259,7 +313,9 @@ struct bsk_handle {
     double* d_ic_stage = nullptr;
     int* d_idx_stage = nullptr;
     size_t stage_cap = 0;
-    double* d_sh_tab = nullptr;
+    double* d_sh_tab = nullptr;    // scalar-load stream (forms 1-3)
+    double* d_sh_tab4 = nullptr;   // DPP-broadcast stream (form 4, default)
+    int sh_split2 = 1, sh_bodies = 0;
     double* d_pool = nullptr;
     double* d_term_obs = nullptr;
     int* d_episodes = nullptr;
@@ -556,7 +612,7 @@ void bsk_destroy(bsk_handle* h) {
     for (hipEvent_t ev : h->ev_warm)
         if (ev) (void)hipEventDestroy(ev);
     void* bufs[] = {h->d_state, h->d_cnt, h->d_act, h->d_obs, h->d_reward, h->d_done_mask, h->d_reason,
-                    h->d_wave_reward, h->d_stat_sum, h->d_stat_done, h->d_ic_stage, h->d_idx_stage, h->d_cold, h->d_sh_tab, h->d_pool, h->d_term_obs, h->d_episodes};
+                    h->d_wave_reward, h->d_stat_sum, h->d_stat_done, h->d_ic_stage, h->d_idx_stage, h->d_cold, h->d_sh_tab, h->d_sh_tab4, h->d_pool, h->d_term_obs, h->d_episodes};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -569,24 +625,30 @@ int bsk_set_gravity_sh(bsk_handle* h, int degree, const double* cbar, const doub
     if (degree != h->cfg.sh_degree) return fail(BSK_EINVAL, "degree differs from bsk_config.sh_degree");
     if (cbar[0] != 1.0) return fail(BSK_EINVAL, "Cbar[0][0] must be 1 (normalised coefficients)");
     DeviceGuard guard(h->device);
-    std::vector<double> tab;
+    std::vector<double> tab, tab4;
     build_sh_table(degree, cbar, sbar, tab);
+    h->sh_bodies = build_sh_table_dpp(degree, cbar, sbar, tab4);
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->d_sh_tab) { (void)hipFree(h->d_sh_tab); h->d_sh_tab = nullptr; }
+    if (h->d_sh_tab4) { (void)hipFree(h->d_sh_tab4); h->d_sh_tab4 = nullptr; }
     HIP_TRY(hipMalloc(&h->d_sh_tab, tab.size() * sizeof(double)));
     HIP_TRY(hipMemcpy(h->d_sh_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
-    h->sp.sh_tab = h->d_sh_tab;
+    HIP_TRY(hipMalloc(&h->d_sh_tab4, tab4.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(h->d_sh_tab4, tab4.data(), tab4.size() * sizeof(double), hipMemcpyHostToDevice));
     h->sp.sh_degree = degree;
-    {   // balance the two halves of the column walk by entry count
+    {   // forms 2: balance the two halves of the column walk by entry count
         const int d1 = degree + 1, total = d1 * (d1 + 1) / 2;
         int acc = 0, M = 1;
         while (M <= d1 && acc + (d1 - M + 1) <= total / 2) { acc += d1 - M + 1; ++M; }
-        h->sp.sh_split = M;
-        // form of the harmonics kernel; BSKGPU_SH_FORM=1|2|3 overrides (measurement only)
-        h->sp.sh_form = 1;
-        if (const char* f = std::getenv("BSKGPU_SH_FORM")) h->sp.sh_form = std::atoi(f);
-        if (h->sp.sh_form < 1 || h->sp.sh_form > 3) h->sp.sh_form = 1;
+        h->sh_split2 = M;
     }
+    // form of the harmonics kernel: 4 (vector loads + DPP broadcast) unless BSKGPU_SH_FORM=1|2|3 asks for
+    // one of the measured-and-kept scalar-stream / LDS forms
+    h->sp.sh_form = 4;
+    if (const char* f = std::getenv("BSKGPU_SH_FORM")) h->sp.sh_form = std::atoi(f);
+    if (h->sp.sh_form < 1 || h->sp.sh_form > 4) h->sp.sh_form = 4;
+    h->sp.sh_tab = h->sp.sh_form == 4 ? h->d_sh_tab4 : h->d_sh_tab;
+    h->sp.sh_split = h->sp.sh_form == 4 ? h->sh_bodies : h->sh_split2;
     return BSK_OK;
 }
 

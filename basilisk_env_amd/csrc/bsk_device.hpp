@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/bskgpu.h"
 
 namespace bsk {
@@ -295,8 +297,108 @@ __device__ __forceinline__ int sh_entries_before(int d1, int M) {   // entries o
 
 // SPLIT: 1 = stream read with scalar loads, 2 = scalar loads with the column range split over two
 // cooperating waves, 3 = the whole stream resident in LDS (160 KiB, one 256-thread workgroup per
-// CU) and read with broadcast ds_reads.
+// CU) and read with broadcast ds_reads, 4 = stream read with coalesced VECTOR loads and fed to the
+// VALU through the DPP row broadcast (gravity_sh_dpp below; the default).
 extern __shared__ double sh_lds_tab[];
+
+// acc += (lane L of each 16-lane row of `tab`) * b: v_fmac_f64 taking its first factor through the
+// DPP row_newbcast control, i.e. a wave-uniform table value costs the VALU nothing beyond the FMA
+// itself and needs neither SGPRs nor the scalar cache.  Every lane of the wave must be active (the
+// broadcast reads a register of another lane): callers keep control flow wave-uniform.
+template <int L>
+__device__ __forceinline__ double fmac_bc(double acc, double tab, double b) {
+    static_assert(L >= 0 && L < 16, "row lane");
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tab), "v"(b), "n"(L));
+    return acc;
+}
+
+// Form 4 of the harmonics evaluation.  The fused stream (bsk_capi.hip: build_sh_table_dpp) holds 8
+// doubles per (L, M) entry in iteration order, every column padded to an even number of entries, so a
+// 128-byte chunk = 2 entries = the 16 doubles one 16-lane row holds in ONE VGPR pair: lane l of every
+// row loads double (l & 15) of the chunk (a single global_load_dwordx2, one cache line per wave), and
+// the FMAs pick their table operand with row_newbcast.  Chunks are prefetched four ahead in a ring of
+// four registers (the loop body is four chunks, so the ring needs no register moves); the stream is a
+// plain linear walk, column boundaries are wave-uniform scalar branches.
+// The three-term recursion runs on Bt = B / alpha_L with alpha_L = n2_L alpha_(L-2) folded into the
+// table (entry[0] = n1_L alpha_(L-1) / alpha_L, coefficient products carry alpha_L), which leaves
+//   Bt_L = entry[0] (u rho) Bt_(L-1) - rho^2 Bt_(L-2)                     3 fp64 ops
+// plus the six coefficient sums = 9 fp64 ops per (L, M) entry, no SGPR operands.
+template <class Hot>
+__device__ __forceinline__ V3 gravity_sh_dpp(const Hot& c, V3 p) {
+    const double r2 = dot(p, p);
+    const double ir = rsqrt_nr(r2);
+    const double s = p.x * ir, t = p.y * ir, u = p.z * ir;
+    const double rho = c.req * ir;              // Re / r
+    const double irho = r2 * ir * c.inv_req;    // r / Re
+    const double w0 = c.mu_over_req * ir * rho; // mu/(r Re) * (Re/r)
+    const double ur = u * rho, nrr = -(rho * rho);
+    const int d1 = c.sh_degree + 1;
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = -w0;
+    double cr = 1.0, ci = 0.0, wM = w0 * rho;
+    // recursion state: P = Bt_(L-1), PP = Bt_(L-2), m1 = (u rho) Bt_(L-1).  A column starts from
+    // P = PP = 0 and m1 = w_M, which makes the generic step produce Bt_M = entry[0] w_M (the diagonal
+    // constant) and Bt_(M+1) = entry[0] (u rho) Bt_M with no special case: the only branch of the walk
+    // is the (rare, wave-uniform) column end.
+    double P = 0.0, PP = 0.0, m1 = wM;
+    double X1 = 0.0, X2 = 0.0, Y1 = 0.0, Y2 = 0.0, Z1 = 0.0, Z2 = 0.0;
+
+    const uint32_t lo = (threadIdx.x & 15u) * 8u;
+    const double* tb = c.sh_tab;
+    // the four ring loads must be issued in ring order and before the loop (the scheduler would otherwise
+    // reverse them and sink the last one into the loop, and the merged vmcnt state then over-waits on
+    // every iteration): a compiler barrier after each
+    double q0 = ldf(tb, lo);
+    asm volatile("" ::: "memory");
+    double q1 = ldf(tb + 16, lo);
+    asm volatile("" ::: "memory");
+    double q2 = ldf(tb + 32, lo);
+    asm volatile("" ::: "memory");
+    double q3 = ldf(tb + 48, lo);
+    asm volatile("" ::: "memory");
+    tb += 64;
+    int M = 1, rem = (d1 + 1) >> 1;   // chunks of column M: (d1 - M + 2) / 2
+
+    auto rec = [&](double q, auto O) {
+        constexpr int o = decltype(O)::value;
+        double B = nrr * PP;
+        B = fmac_bc<o + 0>(B, q, m1);
+        PP = P;
+        P = B;
+        m1 = ur * B;
+        X1 = fmac_bc<o + 2>(X1, q, B); X2 = fmac_bc<o + 3>(X2, q, B);
+        Y1 = fmac_bc<o + 4>(Y1, q, B); Y2 = fmac_bc<o + 5>(Y2, q, B);
+        Z1 = fmac_bc<o + 6>(Z1, q, B); Z2 = fmac_bc<o + 7>(Z2, q, B);
+    };
+    auto chunk = [&](double q) {
+        rec(q, std::integral_constant<int, 0>{});
+        rec(q, std::integral_constant<int, 8>{});
+        if (__builtin_expect(--rem == 0, 0)) {
+            // column end: combine with (Re, Im)(s + i t)^(M-1), advance to (s + i t)^M, restart
+            a1 = fma(cr, X1, fma(ci, X2, a1));
+            a2 = fma(cr, X2, fma(-ci, X1, a2));
+            a3 = fma(cr, Y1, fma(ci, Y2, a3));
+            a4 = fma(-irho, fma(cr, Z1, ci * Z2), a4);
+            const double ncr = fma(s, cr, -t * ci);
+            ci = fma(s, ci, t * cr);
+            cr = ncr;
+            wM *= rho;
+            m1 = wM;
+            P = 0.0; PP = 0.0;
+            X1 = 0.0; X2 = 0.0; Y1 = 0.0; Y2 = 0.0; Z1 = 0.0; Z2 = 0.0;
+            ++M;
+            rem = (d1 - M + 2) >> 1;                 // 0 after the last column: no further column ends
+        }
+    };
+    // sh_split carries the number of four-chunk bodies of the padded stream in this form
+    for (int body = c.sh_split; body > 0; --body) {
+        chunk(q0); q0 = ldf(tb, lo);
+        chunk(q1); q1 = ldf(tb + 16, lo);
+        chunk(q2); q2 = ldf(tb + 32, lo);
+        chunk(q3); q3 = ldf(tb + 48, lo);
+        tb += 64;
+    }
+    return V3{fma(s, a4, a1), fma(t, a4, a2), fma(u, a4, a3)};
+}
 
 template <int SPLIT, class Hot>
 __device__ __forceinline__ V3 gravity_sh(const Hot& c, V3 p) {
@@ -403,7 +505,9 @@ __device__ __forceinline__ V3 gravity(const Hot& c, V3 r, double tsim) {
         double sn, cs;
         sincos(c.planet_rate * tsim, &sn, &cs);
         const V3 pf = mk(fma(cs, r.x, sn * r.y), fma(cs, r.y, -sn * r.x), r.z);
-        const V3 af = gravity_sh<SPLIT>(c, pf);
+        V3 af;
+        if constexpr (SPLIT == 4) af = gravity_sh_dpp(c, pf);
+        else af = gravity_sh<SPLIT>(c, pf);
         return mk(fma(cs, af.x, -sn * af.y), fma(sn, af.x, cs * af.y), af.z);
     } else {
         double zz = r.z * r.z;

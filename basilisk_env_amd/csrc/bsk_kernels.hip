@@ -29,6 +29,12 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+__device__ __forceinline__ int wave_min_uniform(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
 #ifndef BSK_MIN_WAVES
 #define BSK_MIN_WAVES 1
 #endif
@@ -156,6 +162,10 @@ __global__ __launch_bounds__(SPLIT == 2 ? 128 : 256, SPLIT == 2 ? 2 : BSK_MIN_WA
                 first_fsw = false;
             }
             m = min(m, fsw_every - phase);
+            // The DPP-broadcast harmonics need every lane active inside the RK4 loop, so the trip count is
+            // made wave-uniform: envs of one wave that sit at different FSW phases (after a masked reset)
+            // advance together to the nearest FSW tick of any of them.
+            if constexpr (GRAV == BSK_GRAV_SH) m = wave_min_uniform(m);
             phase = (phase + m == fsw_every) ? 0 : phase + m;
         }
         j += m;
@@ -491,6 +501,7 @@ hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams&
     if (grav == G && nrw == R && diag == D && feat == P) {                                                 \
         if (G == BSK_GRAV_SH && p.sh_form == 2) return launch_t<G, R, D, P, (G == BSK_GRAV_SH ? 2 : 1)>(p, b, block, s, ev0, ev1); \
         if (G == BSK_GRAV_SH && p.sh_form == 3) return launch_t<G, R, D, P, (G == BSK_GRAV_SH ? 3 : 1)>(p, b, block, s, ev0, ev1); \
+        if (G == BSK_GRAV_SH && p.sh_form == 4) return launch_t<G, R, D, P, (G == BSK_GRAV_SH ? 4 : 1)>(p, b, block, s, ev0, ev1); \
         return launch_t<G, R, D, P, 1>(p, b, block, s, ev0, ev1);                                           \
     }
     BSK_VARIANTS(CASE)
@@ -500,7 +511,7 @@ hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams&
 
 const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat) {
 #define CASE(G, R, D, P) \
-    if (grav == G && nrw == R && diag == D && feat == P) return (const void*)&step_kernel<G, R, D, P, 1>;
+    if (grav == G && nrw == R && diag == D && feat == P) return (const void*)&step_kernel<G, R, D, P, (G == BSK_GRAV_SH ? 4 : 1)>;
     BSK_VARIANTS(CASE)
 #undef CASE
     return nullptr;
