@@ -110,9 +110,14 @@ void build_sh_table(int d, const double* cbar, const double* sbar, std::vector<d
 // alpha_M = alpha_(M+1) = 1, alpha_L = n2(L, M) alpha_(L-2), so entry[0] = n1 alpha_(L-1) / alpha_L is
 // the only recursion constant and the six coefficient products carry alpha_L; (ii) every column is
 // padded to an even number of entries (a 128-byte chunk = 2 entries never straddles a column);
-// (iii) the stream is padded to whole four-chunk bodies plus four chunks of read-ahead slack.
-// Returns the number of four-chunk bodies.
-int build_sh_table_dpp(int d, const double* cbar, const double* sbar, std::vector<double>& tab) {
+// (iii) the stream is padded to whole SH_RING-chunk bodies plus two bodies of read-ahead slack.
+// The walk is cut into two halves of (nearly) equal entry count at a column boundary: `split` is the first
+// column of the second half, `chunk1` its first chunk; the kernels add the halves' partial sums in a fixed
+// order whether one wave or two walk them.
+struct ShLayout {
+    int split, chunk1, bodies, bodies0, bodies1;
+};
+ShLayout build_sh_table_dpp(int d, const double* cbar, const double* sbar, std::vector<double>& tab) {
     auto K = [](int i) { return i == 0 ? 1.0L : 2.0L; };
     auto idx = [](int l, int m) { return l * (l + 1) / 2 + m; };
     std::vector<long double> diag(d + 2), sd(d + 2), alpha(d + 3);
@@ -130,7 +135,9 @@ int build_sh_table_dpp(int d, const double* cbar, const double* sbar, std::vecto
                      ((long double)(2 * l + 3) * K(m + 1)));
     };
     tab.clear();
+    std::vector<size_t> col_chunk(d + 3, 0);   // first chunk of column M
     for (int M = 1; M <= d + 1; ++M) {
+        col_chunk[M] = tab.size() / 16;
         for (int L = M; L <= d + 1; ++L) {
             long double e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             alpha[L] = (L <= M + 1) ? 1.0L : n2(L, M) * alpha[L - 2];
@@ -153,10 +160,22 @@ int build_sh_table_dpp(int d, const double* cbar, const double* sbar, std::vecto
         }
         if ((d + 1 - M + 1) & 1) tab.insert(tab.end(), 8, 0.0);   // odd column: one all-zero entry
     }
-    const size_t chunks = tab.size() / 16;
-    const size_t bodies = (chunks + 3) / 4;
-    tab.resize((bodies * 4 + 4) * 16, 0.0);
-    return (int)bodies;
+    const size_t chunks = tab.size() / 16, R = bsk::SH_RING;
+    col_chunk[d + 2] = chunks;
+    ShLayout lay;
+    // Balance the halves by issue slots, not by chunks: a column end costs about two chunks' worth (flush,
+    // combine, restart, two taken branches) and the second half has many short columns; it also raises
+    // (s + i t) to its first column's power first (about a third of a chunk per column skipped).
+    auto cost0 = [&](int sp) { return (double)col_chunk[sp] + 2.0 * (sp - 1); };
+    auto cost1 = [&](int sp) { return (double)(chunks - col_chunk[sp]) + 2.0 * (d + 2 - sp) + 0.33 * (sp - 1); };
+    lay.split = 2;                                   // 1 < split <= d + 1: both halves own at least one column
+    while (lay.split < d + 1 && cost0(lay.split + 1) <= cost1(lay.split + 1)) ++lay.split;
+    lay.chunk1 = (int)col_chunk[lay.split];
+    lay.bodies = (int)((chunks + R - 1) / R);
+    lay.bodies0 = (int)((col_chunk[lay.split] + R - 1) / R);
+    lay.bodies1 = (int)((chunks - col_chunk[lay.split] + R - 1) / R);
+    tab.resize(((size_t)lay.bodies * R + 2 * R) * 16, 0.0);
+    return lay;
 }
 
 int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool& diag) {
@@ -211,8 +230,9 @@ int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool&
     p.planet_rate = c.planet_rate;
     p.sh_tab = nullptr;
     p.sh_degree = 0;
-    p.sh_split = 1;
-    p.sh_form = 1;
+    p.sh_split = 2;
+    p.sh_bodies = p.sh_bodies0 = p.sh_bodies1 = p.sh_chunk1 = 0;
+    p.sh_form = 4;
     const bool full = (c.flags & (BSK_FLAG_SUN_THIRD_BODY | BSK_FLAG_DRAG | BSK_FLAG_DESAT)) != 0;
     p.ex.desat = (c.flags & BSK_FLAG_DESAT) ? 1 : 0;
     p.ex.pad_ = 0;
@@ -313,9 +333,8 @@ struct bsk_handle {
     double* d_ic_stage = nullptr;
     int* d_idx_stage = nullptr;
     size_t stage_cap = 0;
-    double* d_sh_tab = nullptr;    // scalar-load stream (forms 1-3)
-    double* d_sh_tab4 = nullptr;   // DPP-broadcast stream (form 4, default)
-    int sh_split2 = 1, sh_bodies = 0;
+    double* d_sh_tab = nullptr;    // scalar-load stream (form 1)
+    double* d_sh_tab4 = nullptr;   // DPP-broadcast stream (forms 4 and 5, default)
     double* d_pool = nullptr;
     double* d_term_obs = nullptr;
     int* d_episodes = nullptr;
@@ -627,7 +646,7 @@ int bsk_set_gravity_sh(bsk_handle* h, int degree, const double* cbar, const doub
     DeviceGuard guard(h->device);
     std::vector<double> tab, tab4;
     build_sh_table(degree, cbar, sbar, tab);
-    h->sh_bodies = build_sh_table_dpp(degree, cbar, sbar, tab4);
+    const ShLayout lay = build_sh_table_dpp(degree, cbar, sbar, tab4);
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->d_sh_tab) { (void)hipFree(h->d_sh_tab); h->d_sh_tab = nullptr; }
     if (h->d_sh_tab4) { (void)hipFree(h->d_sh_tab4); h->d_sh_tab4 = nullptr; }
@@ -636,19 +655,20 @@ int bsk_set_gravity_sh(bsk_handle* h, int degree, const double* cbar, const doub
     HIP_TRY(hipMalloc(&h->d_sh_tab4, tab4.size() * sizeof(double)));
     HIP_TRY(hipMemcpy(h->d_sh_tab4, tab4.data(), tab4.size() * sizeof(double), hipMemcpyHostToDevice));
     h->sp.sh_degree = degree;
-    {   // forms 2: balance the two halves of the column walk by entry count
-        const int d1 = degree + 1, total = d1 * (d1 + 1) / 2;
-        int acc = 0, M = 1;
-        while (M <= d1 && acc + (d1 - M + 1) <= total / 2) { acc += d1 - M + 1; ++M; }
-        h->sh_split2 = M;
+    h->sp.sh_split = lay.split;
+    h->sp.sh_chunk1 = lay.chunk1;
+    h->sp.sh_bodies = lay.bodies;
+    h->sp.sh_bodies0 = lay.bodies0;
+    h->sp.sh_bodies1 = lay.bodies1;
+    // Form of the harmonics kernel.  Below two 64-lane waves per SIMD (1 024 SIMDs on MI355X) each
+    // spacecraft's walk is split over two cooperating waves (form 5), above that one wave walks it
+    // (form 4); the two give bit-identical results.  BSKGPU_SH_FORM=1|4|5 forces a form (measurement).
+    h->sp.sh_form = (h->n < 2 * 1024 * 64) ? 5 : 4;
+    if (const char* f = std::getenv("BSKGPU_SH_FORM")) {
+        const int v = std::atoi(f);
+        if (v == 1 || v == 4 || v == 5) h->sp.sh_form = v;
     }
-    // form of the harmonics kernel: 4 (vector loads + DPP broadcast) unless BSKGPU_SH_FORM=1|2|3 asks for
-    // one of the measured-and-kept scalar-stream / LDS forms
-    h->sp.sh_form = 4;
-    if (const char* f = std::getenv("BSKGPU_SH_FORM")) h->sp.sh_form = std::atoi(f);
-    if (h->sp.sh_form < 1 || h->sp.sh_form > 4) h->sp.sh_form = 4;
-    h->sp.sh_tab = h->sp.sh_form == 4 ? h->d_sh_tab4 : h->d_sh_tab;
-    h->sp.sh_split = h->sp.sh_form == 4 ? h->sh_bodies : h->sh_split2;
+    h->sp.sh_tab = h->sp.sh_form == 1 ? h->d_sh_tab : h->d_sh_tab4;
     return BSK_OK;
 }
 
@@ -898,19 +918,22 @@ int bsk_profile_end(bsk_handle* h, double* mean_kernel_ms, int* n_launches) {
 int bsk_kernel_info(bsk_handle* h, char* name, int name_cap, int* vgprs, int* lds_bytes, int* block, int* grid) {
     if (!h) return fail(BSK_EINVAL, "handle is NULL");
     DeviceGuard guard(h->device);
-    const void* fp = bsk::step_kernel_ptr(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp.feat);
+    const bool sh = h->cfg.gravity_model == BSK_GRAV_SH;
+    const void* fp = bsk::step_kernel_ptr(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp.feat, h->sp.sh_form);
     if (!fp) return fail(BSK_EINVAL, "no kernel variant for this config");
     hipFuncAttributes at;
     HIP_TRY(hipFuncGetAttributes(&at, fp));
     if (name && name_cap > 0)
         std::snprintf(name, name_cap, "step_kernel<%s,%d,%s>",
-                      h->cfg.gravity_model == BSK_GRAV_PM ? "PM" : (h->cfg.gravity_model == BSK_GRAV_PM_J2 ? "PM_J2" : "SH"), h->cfg.n_rw,
+                      h->cfg.gravity_model == BSK_GRAV_PM ? "PM" : (h->cfg.gravity_model == BSK_GRAV_PM_J2 ? "PM_J2" : (h->sp.sh_form == 5 ? "SH/dpp2" : (h->sp.sh_form == 4 ? "SH/dpp" : "SH/scalar"))), h->cfg.n_rw,
                       h->sp.feat == 2 ? (h->diag ? "diag,scenario" : "full,scenario")
                                       : (h->sp.feat == 1 ? (h->diag ? "diag,power" : "full,power") : (h->diag ? "diag" : "full")));
     if (vgprs) *vgprs = at.numRegs;
     if (lds_bytes) *lds_bytes = (int)at.sharedSizeBytes;
-    if (block) *block = h->block;
-    if (grid) *grid = (h->n + h->block - 1) / h->block;
+    // the two-wave harmonics form launches 256-thread workgroups of 2 x 64 spacecraft x 2 halves
+    const int blk = (sh && h->sp.sh_form == 5) ? 256 : h->block;
+    if (block) *block = blk;
+    if (grid) *grid = (sh && h->sp.sh_form == 5) ? (h->n + 127) / 128 : (h->n + blk - 1) / blk;
     return BSK_OK;
 }
 

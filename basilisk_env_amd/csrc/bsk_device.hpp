@@ -112,7 +112,10 @@ struct HotCfg {
     double js[NRW > 0 ? NRW : 1], ijs[NRW > 0 ? NRW : 1];
     double fc;
     int32_t fsw_every, sh_degree;
-    int32_t sh_split, pad_;  // first column of the second wave's half (two-wave harmonics)
+    // harmonics walk (bsk_capi.hip: bsk_set_gravity_sh): first column of the second half; bodies of the
+    // whole padded stream; bodies of each half and first chunk of the second half (two-wave form)
+    int32_t sh_split, sh_bodies;
+    int32_t sh_bodies0, sh_bodies1, sh_chunk1, pad_;
     // spherical harmonics (GRAV == BSK_GRAV_SH only; unused kernarg fields cost no SGPRs)
     const double* sh_tab;   // fused Pines stream, 8 doubles per (l, m) step, iteration order
     double mu_over_req, req, inv_req, planet_rate;
@@ -289,41 +292,51 @@ struct State {
 // sums are combined with (Re, Im)(s + i t)^(M-1) once per column: 10 fp64 ops per (L, M).
 typedef const double __attribute__((address_space(4))) * CTab;
 
-// Column split for the two-wave form: wave `half` of a 128-thread workgroup walks columns
-// [m_lo, m_hi); the host balances the two halves by entry count (sh_split in HotCfg).
-__device__ __forceinline__ int sh_entries_before(int d1, int M) {   // entries of columns 1..M-1
-    return (M - 1) * d1 - ((M - 1) * (M - 2)) / 2;
-}
-
-// SPLIT: 1 = stream read with scalar loads, 2 = scalar loads with the column range split over two
-// cooperating waves, 3 = the whole stream resident in LDS (160 KiB, one 256-thread workgroup per
-// CU) and read with broadcast ds_reads, 4 = stream read with coalesced VECTOR loads and fed to the
-// VALU through the DPP row broadcast (gravity_sh_dpp below; the default).
-extern __shared__ double sh_lds_tab[];
+// SPLIT (form of the harmonics evaluation): 1 = stream read with scalar loads (the first version, kept
+// for comparison), 4 = stream read with coalesced VECTOR loads and fed to the VALU through the DPP row
+// broadcast (gravity_sh_dpp), 5 = the same with each spacecraft's columns split over two cooperating
+// waves (two waves per SIMD at 65 536 spacecraft).  Two further forms were measured and dropped
+// (scalar stream split over two waves, whole stream resident in LDS; code at commit 28b481e).
 
 // acc += (lane L of each 16-lane row of `tab`) * b: v_fmac_f64 taking its first factor through the
 // DPP row_newbcast control, i.e. a wave-uniform table value costs the VALU nothing beyond the FMA
 // itself and needs neither SGPRs nor the scalar cache.  Every lane of the wave must be active (the
 // broadcast reads a register of another lane): callers keep control flow wave-uniform.
+// asm volatile pins the instruction in program order: the harmonics walk fixes its own order (dependent
+// fp64 ops kept apart by independent ones), which the scheduler would undo.
 template <int L>
 __device__ __forceinline__ double fmac_bc(double acc, double tab, double b) {
     static_assert(L >= 0 && L < 16, "row lane");
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tab), "v"(b), "n"(L));
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tab), "v"(b), "n"(L));
     return acc;
 }
+__device__ __forceinline__ double mul_o(double a, double b) {
+    double r;
+    asm volatile("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
-// Form 4 of the harmonics evaluation.  The fused stream (bsk_capi.hip: build_sh_table_dpp) holds 8
+// chunks in flight = chunks per loop body (the host pads the stream to whole bodies + slack)
+constexpr int SH_RING = 8;
+
+// Forms 4 / 5 of the harmonics evaluation.  The fused stream (bsk_capi.hip: build_sh_table_dpp) holds 8
 // doubles per (L, M) entry in iteration order, every column padded to an even number of entries, so a
 // 128-byte chunk = 2 entries = the 16 doubles one 16-lane row holds in ONE VGPR pair: lane l of every
 // row loads double (l & 15) of the chunk (a single global_load_dwordx2, one cache line per wave), and
-// the FMAs pick their table operand with row_newbcast.  Chunks are prefetched four ahead in a ring of
-// four registers (the loop body is four chunks, so the ring needs no register moves); the stream is a
-// plain linear walk, column boundaries are wave-uniform scalar branches.
+// the FMAs pick their table operand with row_newbcast.  Chunks are prefetched SH_RING ahead in a ring of
+// SH_RING registers (the loop body is SH_RING chunks, so the ring needs no register moves); the stream is
+// a plain linear walk, the only branch per chunk is the (rare, wave-uniform) column end.
 // The three-term recursion runs on Bt = B / alpha_L with alpha_L = n2_L alpha_(L-2) folded into the
 // table (entry[0] = n1_L alpha_(L-1) / alpha_L, coefficient products carry alpha_L), which leaves
 //   Bt_L = entry[0] (u rho) Bt_(L-1) - rho^2 Bt_(L-2)                     3 fp64 ops
 // plus the six coefficient sums = 9 fp64 ops per (L, M) entry, no SGPR operands.
-template <class Hot>
+// With one wave per SIMD every instruction of any kind costs the wave a full issue slot (measured: 18
+// VALU + 7 other instructions per chunk = 60 % VALU-active), so at small batches the columns of each
+// spacecraft are split over two waves (TWO; a 256-thread workgroup = 2 x 64 spacecraft x 2 halves, so that
+// its four waves land on the four SIMDs of a CU): both waves of a pair carry the same 64 spacecraft, each walks half of the entries, they exchange four partial sums through LDS, and the SIMD
+// overlaps one wave's loads / scalar instructions with the other's FMAs.  Both forms add the two halves'
+// partial sums in the same order, so their results are bit-identical.
+template <bool TWO, class Hot>
 __device__ __forceinline__ V3 gravity_sh_dpp(const Hot& c, V3 p) {
     const double r2 = dot(p, p);
     const double ir = rsqrt_nr(r2);
@@ -333,74 +346,123 @@ __device__ __forceinline__ V3 gravity_sh_dpp(const Hot& c, V3 p) {
     const double w0 = c.mu_over_req * ir * rho; // mu/(r Re) * (Re/r)
     const double ur = u * rho, nrr = -(rho * rho);
     const int d1 = c.sh_degree + 1;
-    double a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = -w0;
+    const int split = c.sh_split;
+    int half = 0;
+    if constexpr (TWO) half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) & 1);   // wave-uniform
+    const int m_lo = (TWO && half) ? split : 1;
+    const int m_hi = (TWO && !half) ? split : d1 + 1;
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = (half == 0) ? -w0 : 0.0;
+    double b1 = 0.0, b2 = 0.0, b3 = 0.0, b4 = 0.0;   // first half's partial sums (one-wave form)
+    // (Re, Im)(s + i t)^(m_lo - 1) and w_(m_lo)
     double cr = 1.0, ci = 0.0, wM = w0 * rho;
+    for (int M = 1; M < m_lo; ++M) {
+        const double ncr = fma(s, cr, -t * ci);
+        ci = fma(s, ci, t * cr);
+        cr = ncr;
+        wM *= rho;
+    }
     // recursion state: P = Bt_(L-1), PP = Bt_(L-2), m1 = (u rho) Bt_(L-1).  A column starts from
     // P = PP = 0 and m1 = w_M, which makes the generic step produce Bt_M = entry[0] w_M (the diagonal
-    // constant) and Bt_(M+1) = entry[0] (u rho) Bt_M with no special case: the only branch of the walk
-    // is the (rare, wave-uniform) column end.
+    // constant) and Bt_(M+1) = entry[0] (u rho) Bt_M with no special case.
     double P = 0.0, PP = 0.0, m1 = wM;
     double X1 = 0.0, X2 = 0.0, Y1 = 0.0, Y2 = 0.0, Z1 = 0.0, Z2 = 0.0;
 
     const uint32_t lo = (threadIdx.x & 15u) * 8u;
-    const double* tb = c.sh_tab;
-    // the four ring loads must be issued in ring order and before the loop (the scheduler would otherwise
-    // reverse them and sink the last one into the loop, and the merged vmcnt state then over-waits on
-    // every iteration): a compiler barrier after each
-    double q0 = ldf(tb, lo);
-    asm volatile("" ::: "memory");
-    double q1 = ldf(tb + 16, lo);
-    asm volatile("" ::: "memory");
-    double q2 = ldf(tb + 32, lo);
-    asm volatile("" ::: "memory");
-    double q3 = ldf(tb + 48, lo);
-    asm volatile("" ::: "memory");
-    tb += 64;
-    int M = 1, rem = (d1 + 1) >> 1;   // chunks of column M: (d1 - M + 2) / 2
+    const double* tb = c.sh_tab + ((TWO && half) ? (int64_t)16 * c.sh_chunk1 : 0);
+    // the ring loads must be issued in the loop's refill order and before the loop (the scheduler would
+    // otherwise reverse them and sink the last one into the loop, and the vmcnt state merged from the loop
+    // entry and the back edge then over-waits on every iteration): a compiler barrier after each
+    double q[SH_RING];
+    q[SH_RING - 1] = ldf(tb, lo);    // only read with a zero factor before its first refill; issued first
+    asm volatile("" ::: "memory");   // so that the ring order at loop entry equals the order in the loop
+#pragma unroll
+    for (int k = 0; k < SH_RING - 1; ++k) {
+        q[k] = ldf(tb + 16 * k, lo);
+        asm volatile("" ::: "memory");
+    }
+    tb += 16 * SH_RING;
+    int M = m_lo, rem = (d1 - m_lo + 2) >> 1;   // chunks of column M: (d1 - M + 2) / 2
 
-    auto rec = [&](double q, auto O) {
-        constexpr int o = decltype(O)::value;
-        double B = nrr * PP;
-        B = fmac_bc<o + 0>(B, q, m1);
+    // One entry = the recursion step (two dependent ops: fmac -> mul -> next entry's fmac) interleaved with
+    // the six coefficient sums of the PREVIOUS entry, so that no fp64 op waits on its predecessor's result.
+    // Bp = the previous entry's Bt (its sums are still pending), (qp, OP) = where its coefficients sit.
+    double Bp = 0.0;
+    auto entry = [&](double qc, auto OC, double qp, auto OP) {
+        constexpr int oc = decltype(OC)::value, op = decltype(OP)::value;
+        double B = mul_o(nrr, PP);
+        X1 = fmac_bc<op + 2>(X1, qp, Bp);
+        B = fmac_bc<oc + 0>(B, qc, m1);
+        X2 = fmac_bc<op + 3>(X2, qp, Bp); Y1 = fmac_bc<op + 4>(Y1, qp, Bp);
+        m1 = mul_o(ur, B);
+        Y2 = fmac_bc<op + 5>(Y2, qp, Bp); Z1 = fmac_bc<op + 6>(Z1, qp, Bp); Z2 = fmac_bc<op + 7>(Z2, qp, Bp);
         PP = P;
         P = B;
-        m1 = ur * B;
-        X1 = fmac_bc<o + 2>(X1, q, B); X2 = fmac_bc<o + 3>(X2, q, B);
-        Y1 = fmac_bc<o + 4>(Y1, q, B); Y2 = fmac_bc<o + 5>(Y2, q, B);
-        Z1 = fmac_bc<o + 6>(Z1, q, B); Z2 = fmac_bc<o + 7>(Z2, q, B);
+        Bp = B;
     };
-    auto chunk = [&](double q) {
-        rec(q, std::integral_constant<int, 0>{});
-        rec(q, std::integral_constant<int, 8>{});
-        if (__builtin_expect(--rem == 0, 0)) {
-            // column end: combine with (Re, Im)(s + i t)^(M-1), advance to (s + i t)^M, restart
-            a1 = fma(cr, X1, fma(ci, X2, a1));
-            a2 = fma(cr, X2, fma(-ci, X1, a2));
-            a3 = fma(cr, Y1, fma(ci, Y2, a3));
-            a4 = fma(-irho, fma(cr, Z1, ci * Z2), a4);
-            const double ncr = fma(s, cr, -t * ci);
-            ci = fma(s, ci, t * cr);
-            cr = ncr;
-            wM *= rho;
-            m1 = wM;
-            P = 0.0; PP = 0.0;
-            X1 = 0.0; X2 = 0.0; Y1 = 0.0; Y2 = 0.0; Z1 = 0.0; Z2 = 0.0;
-            ++M;
-            rem = (d1 - M + 2) >> 1;                 // 0 after the last column: no further column ends
+    using I0 = std::integral_constant<int, 0>;
+    using I8 = std::integral_constant<int, 8>;
+    auto column_end = [&](double qc) {
+        // flush the last entry's sums, combine with (Re, Im)(s + i t)^(M-1), advance to (s + i t)^M, restart
+        X1 = fmac_bc<10>(X1, qc, Bp); X2 = fmac_bc<11>(X2, qc, Bp); Y1 = fmac_bc<12>(Y1, qc, Bp);
+        Y2 = fmac_bc<13>(Y2, qc, Bp); Z1 = fmac_bc<14>(Z1, qc, Bp); Z2 = fmac_bc<15>(Z2, qc, Bp);
+        a1 = fma(cr, X1, fma(ci, X2, a1));
+        a2 = fma(cr, X2, fma(-ci, X1, a2));
+        a3 = fma(cr, Y1, fma(ci, Y2, a3));
+        a4 = fma(-irho, fma(cr, Z1, ci * Z2), a4);
+        const double ncr = fma(s, cr, -t * ci);
+        ci = fma(s, ci, t * cr);
+        cr = ncr;
+        wM *= rho;
+        m1 = wM;
+        P = 0.0; PP = 0.0; Bp = 0.0;
+        X1 = 0.0; X2 = 0.0; Y1 = 0.0; Y2 = 0.0; Z1 = 0.0; Z2 = 0.0;
+        ++M;
+        if constexpr (!TWO) {
+            if (M == split) {   // the second half's sums start from zero, as in the two-wave form
+                b1 = a1; b2 = a2; b3 = a3; b4 = a4;
+                a1 = 0.0; a2 = 0.0; a3 = 0.0; a4 = 0.0;
+            }
         }
+        // 0 after the last column of this walk: no further column end fires (the chunks that pad the walk
+        // to a whole body then only feed sums that are never combined)
+        rem = (M < m_hi) ? (d1 - M + 2) >> 1 : 0;
     };
-    // sh_split carries the number of four-chunk bodies of the padded stream in this form
-    for (int body = c.sh_split; body > 0; --body) {
-        chunk(q0); q0 = ldf(tb, lo);
-        chunk(q1); q1 = ldf(tb + 16, lo);
-        chunk(q2); q2 = ldf(tb + 32, lo);
-        chunk(q3); q3 = ldf(tb + 48, lo);
-        tb += 64;
+    // tb points at the body after the current one
+    const int bodies = TWO ? (half ? c.sh_bodies1 : c.sh_bodies0) : c.sh_bodies;
+    for (int body = bodies; body > 0; --body) {
+#pragma unroll
+        for (int k = 0; k < SH_RING; ++k) {
+            constexpr int R = SH_RING;
+            const int kp = (k + R - 1) % R;
+            entry(q[k], I0{}, q[kp], I8{});
+            // the previous chunk's register is free now: refill it (chunk kp of the next body; for k == 0
+            // the last chunk of this body)
+            q[kp] = ldf(tb + (k == 0 ? -16 : 16 * kp), lo);
+            entry(q[k], I8{}, q[k], I0{});
+            if (__builtin_expect(--rem == 0, 0)) column_end(q[k]);
+        }
+        tb += 16 * SH_RING;
+    }
+    if constexpr (TWO) {
+        // exchange the two halves' partial sums through LDS; both waves add them in the same order, so
+        // both continue with bit-identical accelerations
+        __shared__ double part[2][2][4][64];
+        const int lane = threadIdx.x & 63, grp = threadIdx.x >> 7;
+        part[grp][half][0][lane] = a1; part[grp][half][1][lane] = a2; part[grp][half][2][lane] = a3; part[grp][half][3][lane] = a4;
+        __syncthreads();
+        a1 = part[grp][0][0][lane] + part[grp][1][0][lane];
+        a2 = part[grp][0][1][lane] + part[grp][1][1][lane];
+        a3 = part[grp][0][2][lane] + part[grp][1][2][lane];
+        a4 = part[grp][0][3][lane] + part[grp][1][3][lane];
+        __syncthreads();
+    } else {
+        a1 = b1 + a1; a2 = b2 + a2; a3 = b3 + a3; a4 = b4 + a4;
     }
     return V3{fma(s, a4, a1), fma(t, a4, a2), fma(u, a4, a3)};
 }
 
-template <int SPLIT, class Hot>
+// Form 1: the scalar-load stream (first version; kept selectable for comparison, BSKGPU_SH_FORM=1).
+template <class Hot>
 __device__ __forceinline__ V3 gravity_sh(const Hot& c, V3 p) {
     const double r2 = dot(p, p);
     const double ir = rsqrt_nr(r2);
@@ -410,21 +472,8 @@ __device__ __forceinline__ V3 gravity_sh(const Hot& c, V3 p) {
     const double w0 = c.mu_over_req * ir * rho; // mu/(r Re) * (Re/r)
     const double ur = u * rho, rr = rho * rho;
     const int d1 = c.sh_degree + 1;
-    int m_lo = 1, m_hi = d1 + 1;
-    int half = 0;
-    if constexpr (SPLIT == 2) {
-        half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform
-        if (half == 0) m_hi = c.sh_split; else m_lo = c.sh_split;
-    }
-    double a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = (half == 0) ? -w0 : 0.0;
-    // (Re, Im)(s + i t)^(m_lo - 1) and w_{m_lo - 1}
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = -w0;
     double cr = 1.0, ci = 0.0, wM = w0;
-    for (int M = 1; M < m_lo; ++M) {
-        const double ncr = fma(s, cr, -t * ci);
-        ci = fma(s, ci, t * cr);
-        cr = ncr;
-        wM *= rho;
-    }
     double B1 = 0.0, B2 = 0.0, X1 = 0.0, X2 = 0.0, Y1 = 0.0, Y2 = 0.0, Z1 = 0.0, Z2 = 0.0;
 
     // recursion step A[L][M] <- A[L-1][M], A[L-2][M] and the six coefficient sums (10 fp64 ops)
@@ -441,46 +490,30 @@ __device__ __forceinline__ V3 gravity_sh(const Hot& c, V3 p) {
     // wait, so one scalar-cache round trip is amortised over 40 fp64 ops.  (A two-tuple software
     // pipeline through inline-asm loads was tried: hipcc copies an in-flight tuple at the loop
     // back-edge before its wait, which reads SGPRs the load has not written yet.)
-    auto walk = [&](auto e) {
-        for (int M = m_lo; M < m_hi; ++M) {
-            wM *= rho;                               // column start: A[M][M] is the diagonal constant
-            B1 = wM * e[0];
-            B2 = 0.0;
-            X1 = B1 * e[2]; X2 = B1 * e[3]; Y1 = B1 * e[4]; Y2 = B1 * e[5]; Z1 = B1 * e[6]; Z2 = B1 * e[7];
-            e += 8;
-            int n = d1 - M;                          // entries left in this column
-            for (; n >= 4; n -= 4) {
-                rec(e); rec(e + 8); rec(e + 16); rec(e + 24);
-                e += 32;
-            }
-            for (; n > 0; --n) {
-                rec(e);
-                e += 8;
-            }
-            // column end: combine with (Re, Im)(s + i t)^(M-1), advance to (s + i t)^M
-            a1 = fma(cr, X1, fma(ci, X2, a1));
-            a2 = fma(cr, X2, fma(-ci, X1, a2));
-            a3 = fma(cr, Y1, fma(ci, Y2, a3));
-            a4 = fma(-irho, fma(cr, Z1, ci * Z2), a4);
-            const double ncr = fma(s, cr, -t * ci);
-            ci = fma(s, ci, t * cr);
-            cr = ncr;
+    CTab e = (CTab)c.sh_tab;
+    for (int M = 1; M <= d1; ++M) {
+        wM *= rho;                               // column start: A[M][M] is the diagonal constant
+        B1 = wM * e[0];
+        B2 = 0.0;
+        X1 = B1 * e[2]; X2 = B1 * e[3]; Y1 = B1 * e[4]; Y2 = B1 * e[5]; Z1 = B1 * e[6]; Z2 = B1 * e[7];
+        e += 8;
+        int n = d1 - M;                          // entries left in this column
+        for (; n >= 4; n -= 4) {
+            rec(e); rec(e + 8); rec(e + 16); rec(e + 24);
+            e += 32;
         }
-    };
-    if constexpr (SPLIT == 3) walk((const double*)sh_lds_tab);
-    else walk((CTab)c.sh_tab + (int64_t)8 * sh_entries_before(d1, m_lo));
-    if constexpr (SPLIT == 2) {
-        // exchange the two halves' partial sums through LDS; both waves add them in the same order,
-        // so both continue with bit-identical accelerations
-        __shared__ double part[2][4][64];
-        const int lane = threadIdx.x & 63;
-        part[half][0][lane] = a1; part[half][1][lane] = a2; part[half][2][lane] = a3; part[half][3][lane] = a4;
-        __syncthreads();
-        a1 = part[0][0][lane] + part[1][0][lane];
-        a2 = part[0][1][lane] + part[1][1][lane];
-        a3 = part[0][2][lane] + part[1][2][lane];
-        a4 = part[0][3][lane] + part[1][3][lane];
-        __syncthreads();
+        for (; n > 0; --n) {
+            rec(e);
+            e += 8;
+        }
+        // column end: combine with (Re, Im)(s + i t)^(M-1), advance to (s + i t)^M
+        a1 = fma(cr, X1, fma(ci, X2, a1));
+        a2 = fma(cr, X2, fma(-ci, X1, a2));
+        a3 = fma(cr, Y1, fma(ci, Y2, a3));
+        a4 = fma(-irho, fma(cr, Z1, ci * Z2), a4);
+        const double ncr = fma(s, cr, -t * ci);
+        ci = fma(s, ci, t * cr);
+        cr = ncr;
     }
     return V3{fma(s, a4, a1), fma(t, a4, a2), fma(u, a4, a3)};
 }
@@ -506,8 +539,9 @@ __device__ __forceinline__ V3 gravity(const Hot& c, V3 r, double tsim) {
         sincos(c.planet_rate * tsim, &sn, &cs);
         const V3 pf = mk(fma(cs, r.x, sn * r.y), fma(cs, r.y, -sn * r.x), r.z);
         V3 af;
-        if constexpr (SPLIT == 4) af = gravity_sh_dpp(c, pf);
-        else af = gravity_sh<SPLIT>(c, pf);
+        if constexpr (SPLIT == 4) af = gravity_sh_dpp<false>(c, pf);
+        else if constexpr (SPLIT == 5) af = gravity_sh_dpp<true>(c, pf);
+        else af = gravity_sh(c, pf);
         return mk(fma(cs, af.x, -sn * af.y), fma(sn, af.x, cs * af.y), af.z);
     } else {
         double zz = r.z * r.z;

@@ -3,7 +3,7 @@
 // step_kernel<GRAV, NRW, DIAG, FEAT, SPLIT>: one spacecraft per lane, 64-lane wavefronts.
 //   GRAV  point mass / + J2 / spherical harmonics       NRW   0, 3 or 4 reaction wheels
 //   DIAG  inertia and back-substitution matrix diagonal  FEAT  0 bare, 1 + power, 2 full scenario
-//   SPLIT form of the harmonics evaluation (1 default; 2, 3 measurement forms)
+//   SPLIT form of the harmonics evaluation (bsk_device.hpp: 1 scalar stream, 4 / 5 DPP broadcast with one / two waves)
 //   HBM layout: structure-of-arrays fp64, field f of env i at st[f*stride + i]; a wave reads 512
 //   contiguous bytes per field (global_load_dwordx2 per lane, fully coalesced), state lives in
 //   VGPRs for all `substeps` RK4 steps, and is written back once.  Reward / done are reduced per
@@ -38,25 +38,21 @@ __device__ __forceinline__ int wave_min_uniform(int v) {
 #ifndef BSK_MIN_WAVES
 #define BSK_MIN_WAVES 1
 #endif
-// SPLIT = 2 (harmonics only): a 128-thread workgroup carries 64 spacecraft; both of its waves run the
-// cheap RK4 redundantly (bit-identical), each evaluates half of the Pines columns and they exchange
-// partial sums through LDS: twice the waves per SIMD at the same batch size, which is what hides the
-// scalar-load latency of the coefficient stream.  Only wave 0 stores.
+// SPLIT = 5 (harmonics only): a 256-thread workgroup carries 2 x 64 spacecraft; the two waves of a pair run the
+// cheap RK4 redundantly (bit-identical), each walks half of the Pines entries and they exchange partial
+// sums through LDS: twice the waves per SIMD at the same batch size, so one wave's loads and scalar
+// instructions overlap with the other's FMAs.  Only wave 0 stores.
 template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT>
-__global__ __launch_bounds__(SPLIT == 2 ? 128 : 256, SPLIT == 2 ? 2 : BSK_MIN_WAVES) void step_kernel(const StepArgs<NRW, DIAG> a) {
+__global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : BSK_MIN_WAVES) void step_kernel(const StepArgs<NRW, DIAG> a) {
     const HotCfg<NRW, DIAG>& c = a.hot;
     const ColdCfg* __restrict__ cold = a.cold;
 #if defined(BSK_ABLATE) && BSK_ABLATE == 1
     return;   // launch + exit only
 #endif
-    const int gid = (SPLIT == 2) ? (int)(blockIdx.x * 64 + (threadIdx.x & 63)) : (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    // SPLIT == 5: waves 0/1 of the workgroup carry spacecraft group 0 (halves 0/1 of the walk), waves 2/3 group 1
+    const int gid = (SPLIT == 5) ? (int)(blockIdx.x * 128 + (threadIdx.x >> 7) * 64 + (threadIdx.x & 63))
+                                 : (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const bool valid = gid < a.n;
-    if constexpr (SPLIT == 3) {
-        // stage the fused Pines stream in LDS once per workgroup (coalesced 8-byte copies)
-        const int n_tab = 4 * (a.hot.sh_degree + 1) * (a.hot.sh_degree + 2);   // doubles
-        for (int k = threadIdx.x; k < n_tab; k += blockDim.x) sh_lds_tab[k] = a.hot.sh_tab[k];
-        __syncthreads();
-    }
     const int i = valid ? gid : a.n - 1;  // tail lanes shadow the last env; their stores are masked
     const int64_t S = a.stride;
     const double* __restrict__ st = a.st;
@@ -221,8 +217,8 @@ __global__ __launch_bounds__(SPLIT == 2 ? 128 : 256, SPLIT == 2 ? 2 : BSK_MIN_WA
     if (o3 == 0.0) { why |= BSK_DONE_BATTERY; rew -= tp->obs_cfg.failure_penalty; }
     if (dot(x.r, x.r) < tp->obs_cfg.r_min2) why |= BSK_DONE_ORBIT;
 
-    if constexpr (SPLIT == 2) {
-        if (threadIdx.x >= 64) return;   // the second wave only helped with the harmonics
+    if constexpr (SPLIT == 5) {
+        if (threadIdx.x & 64) return;    // the second wave of each pair only helped with the harmonics
     }
     // wavefront reductions (every lane of the wave participates; tail lanes contribute nothing)
     const unsigned long long dmask = __ballot(valid2 && why != 0);
@@ -444,6 +440,7 @@ static void fill_hot(const StepParams& p, HotCfg<NRW, DIAG>& h) {
     h.fsw_every = p.fsw_every;
     h.sh_degree = p.sh_degree;
     h.sh_split = p.sh_split;
+    h.sh_bodies = p.sh_bodies; h.sh_bodies0 = p.sh_bodies0; h.sh_bodies1 = p.sh_bodies1; h.sh_chunk1 = p.sh_chunk1;
     h.pad_ = 0;
     h.sh_tab = p.sh_tab;
     h.mu_over_req = p.mu / p.req;
@@ -466,20 +463,9 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     a.tail.stride = b.stride; a.tail.n = b.n; a.tail.substeps = b.substeps;
     a.tail.pool = b.pool; a.tail.term_obs = b.term_obs; a.tail.episodes = b.episodes;
     a.tail.n_pool = b.n_pool; a.tail.n_fields = b.n_fields;
-    if (SPLIT == 2) block = 128;
-    if (SPLIT == 3) block = 256;
-    const int grid = SPLIT == 2 ? (b.n + 63) / 64 : (b.n + block - 1) / block;
-    size_t lds = 0;
-    if (SPLIT == 3) {
-        lds = (size_t)32 * (p.sh_degree + 1) * (p.sh_degree + 2);   // bytes of the stream
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)&step_kernel<GRAV, NRW, DIAG, FEAT, SPLIT>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-            if (e != hipSuccess) return e;
-            attr_set = true;
-        }
-    }
+    if (SPLIT == 5) block = 256;
+    const int grid = SPLIT == 5 ? (b.n + 127) / 128 : (b.n + block - 1) / block;
+    const size_t lds = 0;
     // hipExtLaunchKernelGGL stamps ev0/ev1 from the dispatch packet itself (no marker packets), so
     // their difference is the kernel's own duration, as rocprofv3 --kernel-trace reports it.
     hipExtLaunchKernelGGL((step_kernel<GRAV, NRW, DIAG, FEAT, SPLIT>), dim3(grid), dim3(block), lds, s, ev0, ev1, 0, a);
@@ -499,9 +485,8 @@ hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams&
                        hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
 #define CASE(G, R, D, P) \
     if (grav == G && nrw == R && diag == D && feat == P) {                                                 \
-        if (G == BSK_GRAV_SH && p.sh_form == 2) return launch_t<G, R, D, P, (G == BSK_GRAV_SH ? 2 : 1)>(p, b, block, s, ev0, ev1); \
-        if (G == BSK_GRAV_SH && p.sh_form == 3) return launch_t<G, R, D, P, (G == BSK_GRAV_SH ? 3 : 1)>(p, b, block, s, ev0, ev1); \
         if (G == BSK_GRAV_SH && p.sh_form == 4) return launch_t<G, R, D, P, (G == BSK_GRAV_SH ? 4 : 1)>(p, b, block, s, ev0, ev1); \
+        if (G == BSK_GRAV_SH && p.sh_form == 5) return launch_t<G, R, D, P, (G == BSK_GRAV_SH ? 5 : 1)>(p, b, block, s, ev0, ev1); \
         return launch_t<G, R, D, P, 1>(p, b, block, s, ev0, ev1);                                           \
     }
     BSK_VARIANTS(CASE)
@@ -509,9 +494,13 @@ hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams&
     return hipErrorInvalidValue;
 }
 
-const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat) {
+const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat, int sh_form) {
 #define CASE(G, R, D, P) \
-    if (grav == G && nrw == R && diag == D && feat == P) return (const void*)&step_kernel<G, R, D, P, (G == BSK_GRAV_SH ? 4 : 1)>;
+    if (grav == G && nrw == R && diag == D && feat == P) {                                                                     \
+        if (G == BSK_GRAV_SH && sh_form == 4) return (const void*)&step_kernel<G, R, D, P, (G == BSK_GRAV_SH ? 4 : 1)>;        \
+        if (G == BSK_GRAV_SH && sh_form == 5) return (const void*)&step_kernel<G, R, D, P, (G == BSK_GRAV_SH ? 5 : 1)>;        \
+        return (const void*)&step_kernel<G, R, D, P, 1>;                                                                       \
+    }
     BSK_VARIANTS(CASE)
 #undef CASE
     return nullptr;

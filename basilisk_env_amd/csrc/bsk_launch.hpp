@@ -59,8 +59,9 @@ struct StepParams {
     double req, planet_rate;
     const double* sh_tab;   // device
     int32_t sh_degree;
-    int32_t sh_split;       // first Pines column of the second wave's half
-    int sh_form;            // 1 scalar-load stream, 2 + two cooperating waves, 3 stream resident in LDS
+    int32_t sh_split;       // first Pines column of the second half of the walk
+    int32_t sh_bodies, sh_bodies0, sh_bodies1, sh_chunk1;   // DPP stream: bodies (whole / per half), first chunk of half 1
+    int sh_form;            // 1 scalar-load stream, 4 DPP broadcast, 5 DPP broadcast over two cooperating waves
     int feat;               // FEAT_BARE / FEAT_POWER / FEAT_FULL
     PowerCfg pc;
     ExtraCfg ex;
@@ -88,7 +89,7 @@ struct StepBuffers {
 
 hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams& p, const StepBuffers& b, int block,
                        hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
-const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat);
+const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat, int sh_form);
 hipError_t launch_sample_pool(double* pool, int n_pool, int n_rw, unsigned long long seed, double mu, hipStream_t s);
 hipError_t launch_reset_from_pool(double* st, int64_t stride, int nf, const double* pool, int n_pool, const unsigned char* mask,
                                   int n, int2* cnt, int* episodes, hipStream_t s);

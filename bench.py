@@ -231,9 +231,13 @@ def main():
         out["gather_ms"] = gather_ms
 
     if sh:
-        # config 5 is fp64-VALU bound: ~10 fp64 ops per (l, m) step, 2 556 steps per field evaluation
-        flop = 4 * (2556 * 19 + 400) * a.substeps
-        out["sh"] = {"degree": 70, "fp64_tflops_algorithmic": n * world * a.steps * flop / el / 1e12,
+        # config 5 is fp64-VALU bound, not HBM bound: 9 fp64 instructions (7 FMA + 2 MUL = 16 flop) per
+        # (l, m) entry of the padded Pines stream (2 592 entries at degree 70), four field evaluations per RK4
+        # step, + ~450 fp64 instructions for the rest of the step; peak = MI355X fp64 vector 78.6 TFLOP/s
+        flop = (4 * 2592 * 16 + 2 * 450) * a.substeps
+        tf = n * world * a.steps * flop / el / 1e12
+        out["sh"] = {"degree": 70, "fp64_tflops_executed": tf, "fp64_peak_tflops": 78.6 * world,
+                     "frac_of_fp64_peak": tf / (78.6 * world),
                      "field_evals_per_s": n * world * a.steps * a.substeps * 4 / el}
     if rank == 0 and world == 1 and not a.no_extra and not sh:
         extra = {}

@@ -58,6 +58,71 @@ def test_sh_matches_golden(golden):
     prop.close()
 
 
+def _run_form(form, degree, n, n_rw, cbar, sbar, ic, schedule, monkeypatch):
+    monkeypatch.setenv("BSKGPU_SH_FORM", str(form))
+    prop = BatchedPropagator(sh_cfg(n_rw, degree), n)
+    prop.set_gravity_sh(degree, cbar, sbar)       # the form is chosen here
+    prop.reset(ic)
+    for act, k in schedule:
+        prop.step(act, k)
+    out = prop.get_state(), prop.get_obs()[0]
+    prop.close()
+    return out
+
+
+@pytest.mark.parametrize("degree,n", [(70, 200), (9, 65), (2, 64)])
+def test_sh_forms_agree(degree, n, monkeypatch):
+    """The one-wave and the two-wave DPP walks add the same partial sums in the same order: bit-identical;
+    the scalar-stream form (different recursion scaling) agrees to rounding."""
+    n_rw = 4
+    cbar, sbar = synthetic_sh_coefficients(degree, seed=degree + 1)
+    ic = sample_ic_batch(n, n_rw, seed=degree)
+    rng = np.random.default_rng(degree)
+    schedule = [(rng.integers(0, 3, n).astype(np.int32), k) for k in (3, 10, 8)]
+    s4, o4 = _run_form(4, degree, n, n_rw, cbar, sbar, ic, schedule, monkeypatch)
+    s5, o5 = _run_form(5, degree, n, n_rw, cbar, sbar, ic, schedule, monkeypatch)
+    s1, o1 = _run_form(1, degree, n, n_rw, cbar, sbar, ic, schedule, monkeypatch)
+    assert np.array_equal(s4, s5) and np.array_equal(o4, o5)
+    errs = max_group_err(s4, s1, n_rw)
+    assert max(errs.values()) < 1e-12, errs
+
+
+@pytest.mark.parametrize("form", [4, 5])
+def test_sh_staggered_fsw_phases(form, monkeypatch):
+    """Envs of one wave at different FSW phases (after a masked reset): the harmonics walk needs every
+    lane active, so the kernel advances the wave to the nearest FSW tick of any of its envs."""
+    monkeypatch.setenv("BSKGPU_SH_FORM", str(form))
+    degree, n, n_rw = 12, 150, 3
+    cbar, sbar = synthetic_sh_coefficients(degree, seed=3)
+    cfg = sh_cfg(n_rw, degree)
+    ic = sample_ic_batch(n, n_rw, seed=21)
+    prop = BatchedPropagator(cfg, n)
+    prop.set_gravity_sh(degree, cbar, sbar)
+    prop.reset(ic)
+    st = ic.copy()
+    steps, ticks = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    act = (np.arange(n) % 3).astype(np.int32)
+    oracle.step(cfg, st, steps, ticks, act, 7, cbar=cbar, sbar=sbar)
+    prop.step(act, 7)
+    mask = np.zeros(n, np.uint8)
+    mask[[1, 2, 40, 63, 64, 100, 149]] = 1
+    fresh = sample_ic_batch(n, n_rw, seed=22)
+    prop.reset(fresh, mask=mask)
+    m = mask.astype(bool)
+    st[:, m] = fresh[:, m]
+    steps[m] = 0
+    ticks[m] = 0
+    for k in (5, 13, 10):
+        o = oracle.step(cfg, st, steps, ticks, act, k, cbar=cbar, sbar=sbar)
+        prop.step(act, k)
+        errs = max_group_err(prop.get_state(), st, n_rw)
+        assert max(errs.values()) < 1e-11, (k, errs)
+        assert np.abs(prop.get_obs()[0] - o[0]).max() < 1e-11
+    gs, gt = prop.get_counters()
+    assert np.array_equal(gs, steps) and np.array_equal(gt, ticks)
+    prop.close()
+
+
 def test_sh_degree2_equals_j2_kernel():
     """The harmonics kernel with only C20 reproduces the closed-form J2 kernel (different code
     paths on the device) to rounding."""

@@ -35,21 +35,21 @@ __global__ __launch_bounds__(64) void k(double* out, int iters, double seed) {
 }
 
 template <int MODE>
-void run(const char* name, int ops_per_iter) {
+void run(const char* name, int ops_per_iter, int grid = 1024) {
     double* out;
-    hipMalloc(&out, 1024 * 64 * 8);
+    hipMalloc(&out, 4096 * 64 * 8);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    const int iters = 20000;
-    k<MODE><<<1024, 64>>>(out, 100, 1e-9);
+    const int iters = 100000;
+    k<MODE><<<grid, 64>>>(out, 100, 1e-9);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    k<MODE><<<1024, 64>>>(out, iters, 1e-9);
+    k<MODE><<<grid, 64>>>(out, iters, 1e-9);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
-    printf("%-28s %8.3f ms  %.2f ns per VALU op per wave (x clock GHz = cycles)\n", name, ms, ms * 1e6 / ((double)iters * ops_per_iter));
+    printf("%-28s grid %4d  %8.3f ms  %.2f ns per VALU op per SIMD\n", name, grid, ms, ms * 1e6 / ((double)iters * ops_per_iter * (grid / 1024.0)));
     hipFree(out);
 }
 
@@ -57,5 +57,9 @@ int main() {
     run<1>("v_fmac_f64 plain", 16);
     run<0>("v_fmac_f64_dpp row_newbcast", 16);
     run<2>("recursion pattern (18 ops)", 18);
+    run<1>("v_fmac_f64 plain", 16, 2048);
+    run<0>("v_fmac_f64_dpp row_newbcast", 16, 2048);
+    run<2>("recursion pattern (18 ops)", 18, 2048);
+    run<2>("recursion pattern (18 ops)", 18, 4096);
     return 0;
 }
