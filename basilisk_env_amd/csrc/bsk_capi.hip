@@ -276,6 +276,17 @@ int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool&
         k.fa_c[sgn][axis] += acd;
         for (int j = 0; j < 3; ++j) k.fa_r[sgn][axis][j] += acd * c.facet_pos[i][j];
     }
+    // half sums / half differences of the +e_k and -e_k tables (bsk_device.hpp: facet_drag)
+    for (int axis = 0; axis < 3; ++axis) {
+        const double cp = k.fa_c[0][axis], cm = k.fa_c[1][axis];
+        k.fa_c[0][axis] = 0.5 * (cp + cm);
+        k.fa_c[1][axis] = 0.5 * (cp - cm);
+        for (int j = 0; j < 3; ++j) {
+            const double rp = k.fa_r[0][axis][j], rm = k.fa_r[1][axis][j];
+            k.fa_r[0][axis][j] = 0.5 * (rp + rm);
+            k.fa_r[1][axis][j] = 0.5 * (rp - rm);
+        }
+    }
     for (int i = 0; i < 8; ++i) {
         k.facet_acd[i] = c.facet_area[i] * c.facet_cd[i];
         for (int j = 0; j < 3; ++j) { k.facet_n[i][j] = c.facet_normal[i][j]; k.facet_r[i][j] = c.facet_pos[i][j]; }

@@ -131,9 +131,10 @@ struct ColdCfg {
     // facetDragDynamicEffector geometry (read only inside the drag branch)
     double facet_acd[8];        // area * Cd
     double facet_n[8][3], facet_r[8][3];
-    // facets whose normals are +-body axes (all eight of the reference's): per axis k and sign,
-    // sum of area*Cd and sum of area*Cd*r (facet_axis = 1 when every facet is of that kind)
-    double fa_c[2][3];       // [0]: normal +e_k, [1]: normal -e_k
+    // facets whose normals are +-body axes (all eight of the reference's): per axis k, half sum [0] and
+    // half difference [1] of the +e_k and -e_k facets' area*Cd and area*Cd*r (facet_axis = 1 when every
+    // facet is of that kind)
+    double fa_c[2][3];
     double fa_r[2][3][3];
     int32_t n_facets, n_thr;
     int32_t facet_axis, pad2_;
@@ -576,6 +577,7 @@ struct Env {
     const ColdCfg* cold;
     // thrusterDynamicEffector: current burst, on-time per thruster in half dyn steps, elapsed e2
     double thr_lim[BSK_MAX_THR];
+    double thr_max;   // max over thrusters of thr_lim (0 = no burst pending): one compare per tick decides thr_on
     int e2;
     // axis-aligned facet tables (registers; loaded once per launch when drag is enabled)
     bool facet_axis;
@@ -601,28 +603,29 @@ __device__ __forceinline__ void thrusters(const Env& ev, int e2, V3 sig, V3& aN,
     aN = ev.inv_mass * (FB + (8.0 * iop2) * u2 + (4.0 * (1.0 - q2) * iop2) * u1);   // [BN]^T F_B / m
 }
 
-// facet drag in the body frame: F = -1/2 rho |v|^2 sum_i Cd_i A_i max(0, n_i . v_hat) v_hat,
-// L = sum_i r_i x F_i; v = inertial velocity expressed in the body frame
+// facet drag: F = -1/2 rho |v|^2 sum_i Cd_i A_i max(0, n_i . v_hat) v_hat,  L = sum_i r_i x F_i, with v
+// the inertial velocity.  Only the projected-area sum S = sum c_i (n_i . v_hat)+ and its moment
+// Rc = sum c_i (n_i . v_hat)+ r_i need the body frame; the force is along -v_hat in ANY frame, so the
+// inertial acceleration is -(1/2 rho |v| S / m) v_N with no rotation back, and L_B = Rc x (-1/2 rho |v| v_B).
 __device__ __forceinline__ void facet_drag(const Env& ev, V3 sig, V3 vN, V3& aN, V3& LB) {
     const double q2 = dot(sig, sig), op = 1.0 + q2, iop2 = rcp_nr(op * op);
     const double ka = 8.0 * iop2, kb = 4.0 * (1.0 - q2) * iop2;
     const V3 t1 = cross(sig, vN), t2 = cross(sig, t1);
     const V3 vB = vN + ka * t2 - kb * t1;                 // [BN] v
-    const double v2 = dot(vB, vB), iv = rsqrt_nr(v2);
+    const double v2 = dot(vN, vN), iv = rsqrt_nr(v2);
     const V3 vh = iv * vB;
-    V3 FB, Rc;          // F_B = -1/2 rho v^2 S v_hat,  L_B = Rc x (-1/2 rho v^2 v_hat),  S = sum c_i, Rc = sum c_i r_i
     double S = 0.0;
-    Rc = mk(0, 0, 0);
+    V3 Rc = mk(0, 0, 0);
     if (ev.facet_axis) {
-        // normals are +-e_k: n_i . v_hat = +-v_hat_k, so only the facets facing the flow on each axis count
+        // normals are +-e_k: the facets facing the flow on axis k are the +e_k ones when v_hat_k > 0, the
+        // -e_k ones otherwise, and |x| sel(x > 0, p, m) = |x| (p + m)/2 + x (p - m)/2 needs no select
+        // (fa_c / fa_r hold the half sums [0] and half differences [1]; |x| is a free source modifier)
         const double vk[3] = {vh.x, vh.y, vh.z};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const bool pos = vk[k] > 0.0;
             const double a = fabs(vk[k]);
-            S = fma(a, pos ? ev.fa_c[0][k] : ev.fa_c[1][k], S);
-            const V3 rk = pos ? ev.fa_r[0][k] : ev.fa_r[1][k];
-            Rc = axpy(a, rk, Rc);
+            S = fma(a, ev.fa_c[0][k], fma(vk[k], ev.fa_c[1][k], S));
+            Rc = axpy(a, ev.fa_r[0][k], axpy(vk[k], ev.fa_r[1][k], Rc));
         }
     } else {
         const ColdCfg* cc = ev.cold;
@@ -635,12 +638,9 @@ __device__ __forceinline__ void facet_drag(const Env& ev, V3 sig, V3 vN, V3& aN,
             }
         }
     }
-    const V3 q = (-0.5 * v2 * ev.rho) * vh;
-    FB = S * q;
-    LB = cross(Rc, q);
-    // a_N = [BN]^T F_B / m  (transpose: flip the sign of the odd term)
-    const V3 u1 = cross(sig, FB), u2 = cross(sig, u1);
-    aN = ev.inv_mass * (FB + ka * u2 + kb * u1);
+    const double kq = -0.5 * ev.rho * (v2 * iv);          // -1/2 rho |v|
+    LB = cross(Rc, kq * vB);
+    aN = (ev.inv_mass * S * kq) * vN;
 }
 
 // Integration state inside one RK4 step.  The hub sees the wheels only through their total

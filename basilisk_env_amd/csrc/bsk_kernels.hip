@@ -141,6 +141,9 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : BSK_MIN_WAVES
             thr_t0 = (int)ldf(st + (int64_t)(TAIL + BSK_T_THR_T0) * S, bo);
             thr_cnt = (int)ldf(st + (int64_t)(TAIL + BSK_T_THR_CNT) * S, bo);
         }
+        ev.thr_max = 0.0;
+#pragma unroll
+        for (int k = 0; k < BSK_MAX_THR; ++k) ev.thr_max = fmax(ev.thr_max, ev.thr_lim[k]);
     }
     bool first_fsw = true;
     while (j < substeps_eff) {
@@ -151,9 +154,13 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : BSK_MIN_WAVES
                 control<NRW>(cold, g, u);
                 fsw_ran = true;
                 if constexpr (FEAT == FEAT_FULL) {
-                    if (desat && action == 2)
+                    if (desat && action == 2) {
                         desat_tick<NRW>(cold, x.Om, first_fsw, fsw_every * c.h, 2.0 / c.h, fsw_every, tick, thr_rem, ev.thr_lim,
                                         thr_t0, thr_cnt);
+                        ev.thr_max = 0.0;
+#pragma unroll
+                        for (int k = 0; k < BSK_MAX_THR; ++k) ev.thr_max = fmax(ev.thr_max, ev.thr_lim[k]);
+                    }
                 }
                 first_fsw = false;
             }
@@ -176,10 +183,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : BSK_MIN_WAVES
             if constexpr (FEAT == FEAT_FULL) {
                 if (desat) {
                     ev.e2 = 2 * (tick - thr_t0);
-                    bool on = false;
-#pragma unroll
-                    for (int k = 0; k < BSK_MAX_THR; ++k) on |= (ev.thr_lim[k] > 0.0 && (double)ev.e2 <= ev.thr_lim[k]);
-                    ev.thr_on = on;
+                    ev.thr_on = ev.thr_max > 0.0 && (double)ev.e2 <= ev.thr_max;   // some thruster still inside its burst
                 }
             }
             rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT>(c, wv, x, u, lext, (double)tick * c.h, ev);
