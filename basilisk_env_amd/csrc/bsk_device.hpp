@@ -225,8 +225,22 @@ __device__ __forceinline__ SunGeom sun_setup(const PowerCfg& pc, double t0) {
     return g;
 }
 
+// asin(s) for |s| <= 1/32 (series to s^9: truncation < 1e-18 relative)
+__device__ __forceinline__ double asin_small(double s) {
+    const double z = s * s;
+    return s * fma(z, fma(z, fma(z, fma(z, 35.0 / 1152.0, 15.0 / 336.0), 3.0 / 40.0), 1.0 / 6.0), 1.0);
+}
+
 // visible fraction of the solar disc inside the shadow cones: total eclipse is decided on cosines
-// (no inverse trigonometry); only partial / annular phases take the asin/acos path.
+// (no inverse trigonometry); only partial / annular phases reach the inverse functions.
+// The reference's lens-area formula is  1 - [a^2 acos(x/a) + b^2 acos((c-x)/b) - c y] / (pi a^2),
+// x = (c^2 + a^2 - b^2)/2c, y = sqrt(a^2 - x^2), with the apparent radii a = asin(sa), b = asin(sb) and
+// the separation c = acos(cc).  When the solar disc is small against the planet's (always in LEO:
+// sa ~ 4.7e-3, sb ~ 0.93) the same quantities follow from two library calls instead of five, and
+// without the formula's cancellations: a and theta2 = acos((c-x)/b) = asin(y/b) by series,
+// delta = c - b from sin(delta) = sin c cos b - cos c sin b by series, theta1 = acos(x/a) = atan2(y, x),
+// and b^2 theta2 - c y = b^2 (theta2 - y/b) - delta y.  (The wave executes this path whenever one of its
+// 64 spacecraft is in the penumbra, and with one wave per SIMD the slowest wave sets the kernel time.)
 __device__ __forceinline__ double percent_shadow(const PowerCfg& pc, V3 r_HB, V3 r, double r2) {
     const double nh2 = dot(r_HB, r_HB);
     const double inh = rsqrt_nr(nh2), ins = rsqrt_nr(r2);
@@ -235,11 +249,25 @@ __device__ __forceinline__ double percent_shadow(const PowerCfg& pc, V3 r_HB, V3
     const double ca = sqrt_nr(fma(-sa, sa, 1.0)), cb = sqrt_nr(fma(-sb, sb, 1.0));
     if (sb > sa && cc > fma(cb, ca, sb * sa)) return 0.0;                       // c < b - a : total
     if (cc <= fma(cb, ca, -(sb * sa))) return 1.0;                              // c >= a + b : none
+    const double PI = 3.14159265358979323846;
+    if (sa < 0.03125 * sb) {
+        const double a = asin_small(sa), b = asin(sb);
+        const double sc = sqrt_nr(fma(-cc, cc, 1.0));
+        const double d = asin_small(fma(sc, cb, -(cc * sb)));                   // c - b, |d| <= a
+        const double c = b + d, a2 = a * a;
+        const double x = fma(d, fma(2.0, b, d), a2) * rcp_nr(2.0 * c);
+        const double y = sqrt_nr(fmax(fma(-x, x, a2), 0.0));
+        const double th1 = atan2(y, x);
+        const double w = y * rcp_nr(b), z = w * w;                              // theta2 - y/b = w^3 (1/6 + ...)
+        const double t2 = w * z * fma(z, fma(z, fma(z, 35.0 / 1152.0, 15.0 / 336.0), 3.0 / 40.0), 1.0 / 6.0);
+        const double area = fma(a2, th1, fma(b * b, t2, -(d * y)));
+        return 1.0 - area * rcp_nr(PI * a2);
+    }
     const double a = asin(sa), b = asin(sb), c = acos(cc);
     if (c < a - b) return 1.0 - (b * b) / (a * a);                              // annular
     const double x = (c * c + a * a - b * b) / (2.0 * c), y = sqrt(fmax(a * a - x * x, 0.0));
     const double area = a * a * acos(x / a) + b * b * acos((c - x) / b) - c * y;
-    return 1.0 - area / (3.14159265358979323846 * a * a);
+    return 1.0 - area / (PI * a * a);
 }
 
 __device__ __forceinline__ double shadow_factor(const PowerCfg& pc, const SunGeom& g, V3 r) {
