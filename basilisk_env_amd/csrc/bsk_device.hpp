@@ -390,10 +390,10 @@ __device__ __forceinline__ V3 gravity_sh_dpp(const Hot& c, V3 p) {
         cr = ncr;
         wM *= rho;
     }
-    // recursion state: P = Bt_(L-1), PP = Bt_(L-2), m1 = (u rho) Bt_(L-1).  A column starts from
-    // P = PP = 0 and m1 = w_M, which makes the generic step produce Bt_M = entry[0] w_M (the diagonal
+    // recursion state: P = Bt_(L-1), Bn = -rho^2 Bt_(L-2), m1 = (u rho) Bt_(L-1).  A column starts from
+    // P = Bn = 0 and m1 = w_M, which makes the generic step produce Bt_M = entry[0] w_M (the diagonal
     // constant) and Bt_(M+1) = entry[0] (u rho) Bt_M with no special case.
-    double P = 0.0, PP = 0.0, m1 = wM;
+    double P = 0.0, m1 = wM;
     double X1 = 0.0, X2 = 0.0, Y1 = 0.0, Y2 = 0.0, Z1 = 0.0, Z2 = 0.0;
 
     const uint32_t lo = (threadIdx.x & 15u) * 8u;
@@ -413,18 +413,21 @@ __device__ __forceinline__ V3 gravity_sh_dpp(const Hot& c, V3 p) {
     int M = m_lo, rem = (d1 - m_lo + 2) >> 1;   // chunks of column M: (d1 - M + 2) / 2
 
     // One entry = the recursion step (two dependent ops: fmac -> mul -> next entry's fmac) interleaved with
-    // the six coefficient sums of the PREVIOUS entry, so that no fp64 op waits on its predecessor's result.
+    // the six coefficient sums of the PREVIOUS entry, so that no fp64 op waits on its predecessor's result
+    // and the compiler has no hazard to pad with s_nop (a DPP FMA must not read a VGPR written by one of the
+    // two preceding instructions, a plain VALU read of a DPP-FMA result wants five in between).  Bn = -rho^2 Bt_(L-2) is prepared one entry ahead; the entry opens with
+    // the instruction that needs the chunk just loaded, so one s_waitcnt serves the whole chunk.
     // Bp = the previous entry's Bt (its sums are still pending), (qp, OP) = where its coefficients sit.
-    double Bp = 0.0;
+    double Bp = 0.0, Bn = 0.0;
     auto entry = [&](double qc, auto OC, double qp, auto OP) {
         constexpr int oc = decltype(OC)::value, op = decltype(OP)::value;
-        double B = mul_o(nrr, PP);
-        X1 = fmac_bc<op + 2>(X1, qp, Bp);
-        B = fmac_bc<oc + 0>(B, qc, m1);
-        X2 = fmac_bc<op + 3>(X2, qp, Bp); Y1 = fmac_bc<op + 4>(Y1, qp, Bp);
-        m1 = mul_o(ur, B);
-        Y2 = fmac_bc<op + 5>(Y2, qp, Bp); Z1 = fmac_bc<op + 6>(Z1, qp, Bp); Z2 = fmac_bc<op + 7>(Z2, qp, Bp);
-        PP = P;
+        const double Pold = P;
+        const double B = fmac_bc<oc + 0>(Bn, qc, m1);
+        X1 = fmac_bc<op + 2>(X1, qp, Bp); X2 = fmac_bc<op + 3>(X2, qp, Bp);
+        Bn = mul_o(nrr, Pold);
+        Y1 = fmac_bc<op + 4>(Y1, qp, Bp); Y2 = fmac_bc<op + 5>(Y2, qp, Bp);
+        m1 = mul_o(ur, B);      // five instructions after B (a VALU read of a DPP-FMA result needs that distance)
+        Z1 = fmac_bc<op + 6>(Z1, qp, Bp); Z2 = fmac_bc<op + 7>(Z2, qp, Bp);   // two before the next entry reads m1
         P = B;
         Bp = B;
     };
@@ -443,7 +446,7 @@ __device__ __forceinline__ V3 gravity_sh_dpp(const Hot& c, V3 p) {
         cr = ncr;
         wM *= rho;
         m1 = wM;
-        P = 0.0; PP = 0.0; Bp = 0.0;
+        P = 0.0; Bn = 0.0; Bp = 0.0;
         X1 = 0.0; X2 = 0.0; Y1 = 0.0; Y2 = 0.0; Z1 = 0.0; Z2 = 0.0;
         ++M;
         if constexpr (!TWO) {
