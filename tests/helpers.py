@@ -17,3 +17,16 @@ def rel_err(a, b, sl):
 
 def max_group_err(a, b, n_rw):
     return {k: rel_err(a, b, sl) for k, sl in field_groups(n_rw).items()}
+
+
+def cfg_for_case(case):
+    """bsk_config of a golden case (tests/golden/make_golden.py: the recipes' cfg_edit functions)."""
+    from basilisk_env_amd._lib import FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY
+    from basilisk_env_amd.simulators.dynamics.config import default_config
+    cfg = default_config(case["n_rw"], case["gravity_model"])
+    if case.get("cfg_edit") == "scenario_edit":
+        cfg.flags |= FLAG_POWER | FLAG_SUN_THIRD_BODY | FLAG_DRAG
+        cfg.base_density, cfg.scale_height = 1e-9, 100e3
+    if "sh_degree" in case:
+        cfg.sh_degree = case["sh_degree"]
+    return cfg
