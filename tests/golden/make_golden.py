@@ -179,8 +179,23 @@ class Model(object):
         self.rho0, self.H, self.mass = M(float(c["base_density"])), M(float(c["scale_height"])), M(float(c["mass"]))
         self.facets = [(M(float(c["facet_area"][i])), M(float(c["facet_cd"][i])), [M(float(v)) for v in c["facet_normal"][i]],
                         [M(float(v)) for v in c["facet_pos"][i]]) for i in range(int(c["n_facets"]))]
+        # rwDesatTask (row f2): thrMomentumManagement -> thrForceMapping -> thrMomentumDumping -> ideal thrusters
+        from basilisk_env_amd._lib import FLAG_DESAT
+        self.desat = bool(fl & FLAG_DESAT)
+        self.n_thr = int(c["n_thr"])
+        pos = [[M(float(v)) for v in c["thr_pos"][i]] for i in range(self.n_thr)]
+        dirs = [[M(float(v)) for v in c["thr_dir"][i]] for i in range(self.n_thr)]
+        self.fmax = M(float(c["thr_max_thrust"]))
+        self.hs_min, self.min_fire, self.min_on = M(float(c["hs_min"])), M(float(c["thr_min_fire_time"])), M(float(c["thr_min_on_time"]))
+        self.max_counter = int(c["thr_max_counter"])
+        D = [cross(pos[i], dirs[i]) for i in range(self.n_thr)]                    # torque per unit thrust
+        self.thr_f = [scale(self.fmax, dirs[i]) for i in range(self.n_thr)]
+        self.thr_l = [scale(self.fmax, D[i]) for i in range(self.n_thr)]
+        if self.desat:
+            DDi = inv3([[sum(D[i][a] * D[i][b] for i in range(self.n_thr)) for b in range(3)] for a in range(3)])
+            self.thr_map = [matvec(DDi, D[i]) for i in range(self.n_thr)]         # rows of D^T (D D^T)^-1
 
-    power = sun3 = drag = False
+    power = sun3 = drag = desat = False
 
     def sun_at(self, tick):
         t = tick * self.dt
@@ -238,6 +253,28 @@ class Model(object):
                 F, L = add(F, f), add(L, cross(pos, f))
         FN = [sum(BN[j][i] * F[j] for j in range(3)) for i in range(3)]     # [BN]^T F_B
         return scale(1 / self.mass, FN), L
+
+    def desat_tick(self, env, x, first):
+        Tc = self.fsw_every * self.dt
+        if first:   # one momentum request per mode entry: dump what exceeds hs_min, on-pulsing minimum-norm impulses
+            hs = [sum(self.js[i] * x[12 + i] * self.gs[i][k] for i in range(self.n_rw)) for k in range(3)]
+            hm = norm(hs)
+            dH = scale(-(hm - self.hs_min) / hm, hs) if hm > self.hs_min else [M(0)] * 3
+            F = [dot(self.thr_map[i], dH) for i in range(self.n_thr)]
+            fmin = min(F)
+            env["thr_rem"] = [(F[i] - fmin) / self.fmax for i in range(self.n_thr)] + [M(0)] * (8 - self.n_thr)
+            env["thr_cnt"] = 0
+        if env["thr_cnt"] <= 0:   # fire: at most one control period per burst, short pulses dropped / stretched
+            for i in range(self.n_thr):
+                on = min(env["thr_rem"][i], Tc)
+                if on < self.min_fire:
+                    env["thr_rem"][i], env["thr_lim"][i] = M(0), M(0)
+                    continue
+                env["thr_rem"][i] -= on
+                env["thr_lim"][i] = M(2 * self.fsw_every) if on >= Tc else mp.floor(max(on, self.min_on) * 2 / self.dt)
+            env["thr_t0"], env["thr_cnt"] = env["ticks"], self.max_counter
+        else:
+            env["thr_cnt"] -= 1
 
     def set_sh(self, degree, cbar, sbar, planet_rate):
         """Pines' normalised recursion, row-major tables as Basilisk documents them."""
@@ -327,7 +364,7 @@ class Model(object):
             tq.append(u[i] + fr)
         return tq
 
-    def eom(self, x, tq, lext, t=None, sun=None, rho=None):
+    def eom(self, x, tq, lext, t=None, sun=None, rho=None, thr=None):
         r, v, s, w, Om = x[0:3], x[3:6], x[6:9], x[9:12], x[12:]
         dv = self.gravity(r, t)
         if self.sun3:
@@ -336,6 +373,14 @@ class Model(object):
         if self.drag:
             aN, LB = self.drag_force(s, v, rho)
             dv, lext = add(dv, aN), add(lext, LB)
+        if thr is not None:
+            lim, e2 = thr
+            FB = [M(0)] * 3
+            for i in range(self.n_thr):
+                if lim[i] > 0 and e2 <= lim[i]:      # inside its burst (time counted in half dyn steps)
+                    FB, lext = add(FB, self.thr_f[i]), add(lext, self.thr_l[i])
+            BN = mrp2c(s)
+            dv = add(dv, scale(1 / self.mass, [sum(BN[j][i] * FB[j] for j in range(3)) for i in range(3)]))
         s2, sw, sxw = dot(s, s), dot(s, w), cross(s, w)
         ds = [((1 - s2) * w[k] + 2 * sxw[k] + 2 * sw * s[k]) / 4 for k in range(3)]
         rhs = add(scale(-1, cross(w, matvec(self.I, w))), lext)
@@ -346,16 +391,17 @@ class Model(object):
         dOm = [tq[i] / self.js[i] - dot(self.gs[i], dw) for i in range(self.n_rw)]
         return list(v) + dv + ds + dw + dOm
 
-    def rk4(self, x, u, lext, t=None, sun=None):
+    def rk4(self, x, u, lext, t=None, sun=None, thr=None):
         h = self.dt
         ax = lambda a, k, y: [yi + a * ki for yi, ki in zip(y, k)]  # noqa: E731
         u = self.wheel_torque(x, u)   # held over the four stages
         t = M(0) if t is None else t
         rho = self.rho0 * mp.exp(-(norm(x[0:3]) - self.req) / self.H) if self.drag else None   # once per dyn tick
-        k1 = self.eom(x, u, lext, t, sun, rho)
-        k2 = self.eom(ax(h / 2, k1, x), u, lext, t + h / 2, sun, rho)
-        k3 = self.eom(ax(h / 2, k2, x), u, lext, t + h / 2, sun, rho)
-        k4 = self.eom(ax(h, k3, x), u, lext, t + h, sun, rho)
+        th = (lambda de: None) if thr is None else (lambda de: (thr[0], thr[1] + de))
+        k1 = self.eom(x, u, lext, t, sun, rho, th(0))
+        k2 = self.eom(ax(h / 2, k1, x), u, lext, t + h / 2, sun, rho, th(1))
+        k3 = self.eom(ax(h / 2, k2, x), u, lext, t + h / 2, sun, rho, th(1))
+        k4 = self.eom(ax(h, k3, x), u, lext, t + h, sun, rho, th(2))
         x = [x[i] + h / 6 * k1[i] + h / 3 * k2[i] + h / 3 * k3[i] + h / 6 * k4[i] for i in range(len(x))]
         s2 = dot(x[6:9], x[6:9])
         if s2 > 1:
@@ -403,10 +449,19 @@ class Model(object):
         x, u = env["x"], env["u"]
         sun = self.sun_at(env["ticks"]) if (self.power or self.sun3) else None   # held over the env step
         shadow = M(1)
+        first_fsw = True
         for _ in range(substeps):
             if self.n_rw and env["ticks"] % self.fsw_every == 0:
                 u = self.control(self.guidance(x, action))
-            x = self.rk4(x, u, env["lext"], env["ticks"] * self.dt, sun)
+                if self.desat and action == 2:
+                    self.desat_tick(env, x, first_fsw)
+                first_fsw = False
+            thr = None
+            if self.desat:
+                e2 = 2 * (env["ticks"] - env["thr_t0"])
+                if any(l > 0 and e2 <= l for l in env["thr_lim"]):
+                    thr = (env["thr_lim"], e2)
+            x = self.rk4(x, u, env["lext"], env["ticks"] * self.dt, sun, thr)
             if self.power:
                 env["charge"], shadow = self.power_tick(x, sun, env["charge"])
             env["ticks"] += 1
@@ -448,7 +503,7 @@ def run_case(name, n_rw, grav, n_envs, seed, schedule, cfg_edit=None, sh=None, i
     for e in range(n_envs):
         envs.append({"x": [M(float(ic[f, e])) for f in range(12 + n_rw)], "u": [M(0)] * n_rw,
                      "lext": [M(float(ic[t + k, e])) for k in range(3)], "charge": M(float(ic[t + 7, e])),
-                     "steps": 0, "ticks": 0})
+                     "steps": 0, "ticks": 0, "thr_rem": [M(0)] * 8, "thr_lim": [M(0)] * 8, "thr_t0": 0, "thr_cnt": 0})
     calls = []
     for ci, (actions, substeps) in enumerate(schedule):
         obs, rews, whys = [], [], []
@@ -463,6 +518,10 @@ def run_case(name, n_rw, grav, n_envs, seed, schedule, cfg_edit=None, sh=None, i
             state[t:t + 3, e] = [float(v) for v in env["lext"]]
             state[t + 3:t + 3 + n_rw, e] = [float(v) for v in env["u"]]
             state[t + 7, e] = float(env["charge"])
+            if model.desat:
+                state[t + 8:t + 16, e] = [float(v) for v in env["thr_rem"]]
+                state[t + 16:t + 24, e] = [float(v) for v in env["thr_lim"]]
+                state[t + 24, e], state[t + 25, e] = env["thr_t0"], env["thr_cnt"]
         calls.append({"actions": [int(a) for a in actions], "substeps": int(substeps), "state": state.tolist(),
                       "obs": np.array(obs).T.tolist(), "reward": rews, "reason": whys})
         print("  %s call %d/%d done" % (name, ci + 1, len(schedule)), flush=True)
@@ -497,6 +556,10 @@ def main():
         cfg.flags |= FLAG_POWER | FLAG_SUN_THIRD_BODY | FLAG_DRAG
         cfg.base_density, cfg.scale_height = 1e-9, 100e3
 
+    def desat_edit(cfg):
+        from basilisk_env_amd._lib import FLAG_DESAT, FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY
+        cfg.flags |= FLAG_POWER | FLAG_SUN_THIRD_BODY | FLAG_DRAG | FLAG_DESAT
+
     def penumbra_ic(cfg, ic):
         """envs 0..3 fly through the penumbra band behind the Earth during the run (the others keep their
         sampled orbits); env 3 starts with a nearly empty battery"""
@@ -520,6 +583,9 @@ def main():
         # rows f1 / f3: power system (with penumbra crossings), Sun third body, facet drag; J2 + 3 wheels
         ("scenario_rw3", lambda: run_case("scenario_rw3", 3, GRAV_PM_J2, 6, 15, [(np.array([0, 1, 0, 1, 2, 0]), k) for k in (1, 49, 150, 200)],
                                           cfg_edit=scenario_edit, ic_edit=penumbra_ic)),
+        # row f2: desaturation (action 2 on envs whose wheel momentum exceeds hs_min), full scenario otherwise
+        ("desat_rw3", lambda: run_case("desat_rw3", 3, GRAV_PM, 6, 16, [(np.array([2, 2, 0, 2, 1, 2]), k) for k in (7, 43, 100, 150)],
+                                       cfg_edit=desat_edit)),
         ("sh8_rw3", lambda: run_case("sh8_rw3", 3, GRAV_SH, 4, 14, [(np.array([0, 1, 2, 0]), k) for k in (1, 9, 90, 300)],
                                      cfg_edit=sh_edit, sh=(8, cb, sb))),
     ]

@@ -6,7 +6,7 @@ from basilisk_env_amd._lib import (FLAG_DESAT, FLAG_DRAG, FLAG_POWER, FLAG_SUN_T
                                    T_THR_LIM, T_THR_REM, T_THR_T0)
 from basilisk_env_amd.simulators.dynamics import BatchedPropagator, default_config
 from basilisk_env_amd.simulators.initial_conditions.batch import sample_ic_batch
-from helpers import max_group_err
+from helpers import cfg_for_case, max_group_err
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
@@ -86,3 +86,25 @@ def test_env_runs_desat_mode():
         oc, rc, dc, _ = c.step(a)
         assert np.abs(og[:4] - oc[:4]).max() < 1e-9 and abs(rg - rc) < 1e-12 and dg == dc
     g.close()
+
+
+def test_desat_matches_golden(golden):
+    """Desaturation inside the full scenario against the 50-digit golden (burst bookkeeping exact)."""
+    case = [c for c in golden["cases"] if c["name"] == "desat_rw3"][0]
+    cfg = cfg_for_case(case)
+    ic = np.array(case["ic"])
+    t = 12 + case["n_rw"]
+    prop = BatchedPropagator(cfg, ic.shape[1])
+    prop.reset(ic)
+    for call in case["calls"]:
+        prop.step(np.array(call["actions"], np.int32), call["substeps"])
+        obs, rew, done, why = prop.get_obs()
+        s, gs, go = prop.get_state(), np.array(call["state"]), np.array(call["obs"])
+        errs = max_group_err(s, gs, case["n_rw"])
+        assert max(errs.values()) < 1e-11, (call["substeps"], errs)
+        assert np.abs(s[t + T_THR_REM:t + T_THR_REM + 8] - gs[t + T_THR_REM:t + T_THR_REM + 8]).max() < 1e-12
+        assert np.array_equal(s[t + T_THR_LIM:t + T_THR_LIM + 8], gs[t + T_THR_LIM:t + T_THR_LIM + 8])
+        assert np.array_equal(s[t + T_THR_T0], gs[t + T_THR_T0]) and np.array_equal(s[t + T_THR_CNT], gs[t + T_THR_CNT])
+        assert np.abs(obs[:4] - go[:4]).max() < 1e-11 and np.abs(obs[4] - go[4]).max() < 1e-11
+        assert (why == np.array(call["reason"])).all()
+    prop.close()
