@@ -3,15 +3,16 @@
 // One "chunk" = the harmonics walk's 18 VALU ops (4 v_mul_f64 + 14 v_fmac_f64_dpp, same dependency pattern);
 // the modes add, per chunk:  1: nothing   2: + global_load_dwordx2 into a ring of 8 + s_waitcnt vmcnt(7)
 //                            3: + 2 x s_nop 0   4: + s_sub / s_cmp / s_cbranch (never taken)   5: all of them
-//   hipcc -O3 --offload-arch=gfx950 -o issue_mix issue_mix.hip && ./issue_mix
+//   hipcc -O3 --offload-arch=gfx950 -o issue_mix issue_mix.hip && ./issue_mix     (variants: 256-thread workgroups, 256 VGPRs allocated)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
 #define FM(acc, q, b, L) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #L " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(q), "v"(b));
 #define MUL(r, a, b) asm volatile("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
 
-template <int MODE>
-__global__ __launch_bounds__(64) void k(const double* __restrict__ tab, double* out, int bodies, double seed) {
+template <int MODE, int BLOCK = 64, bool BIGV = false>
+__global__ __launch_bounds__(BLOCK) void k(const double* __restrict__ tab, double* out, int bodies, double seed) {
+    if constexpr (BIGV) asm volatile("" ::: "v255");   // allocate 256 VGPRs like the harmonics kernel (2 waves per SIMD fit)
     double X1 = seed, X2 = seed, Y1 = seed, Y2 = seed, Z1 = seed, Z2 = seed;
     double P = seed, PP = seed * 0.5, m1 = seed, Bp = seed, nrr = -0.5, ur = 0.25;
     const double* p = tab + (threadIdx.x & 15);
@@ -51,18 +52,18 @@ __global__ __launch_bounds__(64) void k(const double* __restrict__ tab, double* 
     double s = X1 + X2 + Y1 + Y2 + Z1 + Z2 + P + PP;
 #pragma unroll
     for (int j = 0; j < 8; ++j) s += q[j];
-    out[blockIdx.x * 64 + threadIdx.x] = s;
+    out[blockIdx.x * BLOCK + threadIdx.x] = s;
 }
 
-template <int MODE>
+template <int MODE, int BLOCK = 64, bool BIGV = false>
 void run(const char* name, int grid, const double* tab, double* out) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const int bodies = 4000;
-    k<MODE><<<grid, 64>>>(tab, out, 50, 1e-9);
+    k<MODE, BLOCK, BIGV><<<grid * 64 / BLOCK, BLOCK>>>(tab, out, 50, 1e-9);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0);
-    k<MODE><<<grid, 64>>>(tab, out, bodies, 1e-9);
+    k<MODE, BLOCK, BIGV><<<grid * 64 / BLOCK, BLOCK>>>(tab, out, bodies, 1e-9);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms;
@@ -82,6 +83,9 @@ int main() {
         run<3>("18 VALU + 2 s_nop", grid, tab, out);
         run<4>("18 VALU + s_sub/s_cmp/s_cbranch", grid, tab, out);
         run<5>("18 VALU + all", grid, tab, out);
+        run<5, 256>("18 VALU + all, 256-thread workgroups", grid, tab, out);
+        run<5, 64, true>("18 VALU + all, 256 VGPRs allocated", grid, tab, out);
+        run<5, 256, true>("18 VALU + all, 256-thread wg, 256 VGPRs", grid, tab, out);
     }
     return 0;
 }
