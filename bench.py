@@ -37,8 +37,8 @@ FLOP_PER_RK4 = 4 * 330 + 110  # SURVEY.md §8(d) algorithmic flops per RK4 sub-s
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=1000)
-    p.add_argument("--warmup", type=int, default=50)
+    p.add_argument("--steps", type=int, default=10000)
+    p.add_argument("--warmup", type=int, default=200)
     p.add_argument("--envs", type=int, default=65536, help="spacecraft per GPU")
     p.add_argument("--substeps", type=int, default=1, help="RK4 sub-steps per env step")
     p.add_argument("--gravity", choices=["j2", "sh"], default="j2",
