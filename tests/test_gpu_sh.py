@@ -123,6 +123,38 @@ def test_sh_staggered_fsw_phases(form, monkeypatch):
     prop.close()
 
 
+@pytest.mark.parametrize("form", [4, 5])
+def test_sh_full_scenario_matches_oracle(form, monkeypatch):
+    """Harmonics under the full-scenario kernel (power, Sun third body, live drag, desaturation): the
+    divergent branches of that kernel all sit after the field evaluation, whose DPP broadcasts need the
+    whole wave active."""
+    from basilisk_env_amd._lib import FLAG_DESAT, FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY
+    monkeypatch.setenv("BSKGPU_SH_FORM", str(form))
+    degree, n, n_rw = 10, 140, 3
+    cbar, sbar = synthetic_sh_coefficients(degree, seed=5)
+    cfg = sh_cfg(n_rw, degree)
+    cfg.flags |= FLAG_POWER | FLAG_SUN_THIRD_BODY | FLAG_DRAG | FLAG_DESAT
+    cfg.base_density, cfg.scale_height = 1e-9, 100e3
+    ic = sample_ic_batch(n, n_rw, seed=8)
+    ic[12:12 + n_rw] *= 2.0
+    prop = BatchedPropagator(cfg, n)
+    prop.set_gravity_sh(degree, cbar, sbar)
+    prop.reset(ic)
+    st = ic.copy()
+    steps, ticks = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    rng = np.random.default_rng(6)
+    for k in (4, 26, 45):
+        act = rng.integers(0, 3, n).astype(np.int32)
+        o = oracle.step(cfg, st, steps, ticks, act, k, cbar=cbar, sbar=sbar)
+        prop.step(act, k)
+        obs, rew, done, why = prop.get_obs()
+        errs = max_group_err(prop.get_state(), st, n_rw)
+        assert max(errs.values()) < 1e-11, (k, errs)
+        assert np.abs(obs[:4] - o[0][:4]).max() < 1e-11 and np.abs(obs[4] - o[0][4]).max() < 2e-8
+        assert (why == o[3]).all()
+    prop.close()
+
+
 def test_sh_degree2_equals_j2_kernel():
     """The harmonics kernel with only C20 reproduces the closed-form J2 kernel (different code
     paths on the device) to rounding."""
