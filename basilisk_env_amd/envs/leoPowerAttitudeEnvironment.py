@@ -166,3 +166,37 @@ class leoPowerAttEnv(spaces.Env):
 
     def close(self):
         self._drop_simulator()
+
+
+if __name__ == "__main__":
+    # The reference module's demo main (:218-244): loop through the env twice with action 0 and keep the
+    # observation history; the plots are optional here (``--plot``), a text summary is always printed.
+    import sys
+
+    env = leoPowerAttEnv()
+    hist_list = []
+    for ind in range(0, 2):
+        hist = np.zeros([5, 2 * env.max_length])
+        env.reset()
+        env.seed(seed=12345)
+        total = 0.0
+        for step in range(0, env.max_length):
+            ob, reward, ep_over, info = env.step(0)
+            hist[:, step] = ob[:, 0]
+            total += reward
+            if ep_over:
+                break
+        hist_list.append(hist)
+        print("run %d: %d steps, return %.4f, final obs %s" % (ind, step + 1, total, np.array2string(ob[:, 0], precision=5)))
+    if "--plot" in sys.argv:
+        from matplotlib import pyplot as plt
+        labels = ['attitude norm', 'rate norm', 'wheel norm', 'Battery Level', 'Eclipse ind']
+        for count, hist in enumerate(hist_list):
+            plt.figure()
+            for k in range(5):
+                plt.plot(range(0, env.max_length * 2), hist[k, :], label=labels[k])
+            plt.grid()
+            plt.legend()
+            plt.title('History of run %d' % count)
+        plt.show()
+    env.close()
