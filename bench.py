@@ -59,9 +59,10 @@ def timed_run(prop, d_act_ptr, substeps, steps, warmup, barrier, torch, stamp_al
         prop.step_device(d_act_ptr, substeps)
     prop.sync()
     # dispatch timestamps on a sample of the timed launches: stamping costs ~5 us of launch throughput
-    # per stamped launch, so a pair is stamped every 16 launches and its second launch counted (every
-    # launch for short runs); see bsk_profile_set_stride
-    stride = 16 if (steps >= 64 and not stamp_all) else 1
+    # per stamped launch, so a pair is stamped every `stride` launches and its second launch counted (every
+    # launch for short runs); ~128 samples per run, never more often than every 16th launch; see
+    # bsk_profile_set_stride
+    stride = max(16, steps // 128) if (steps >= 64 and not stamp_all) else 1
     prop.profile_begin(steps, stride=stride)
     barrier()
     torch.cuda.synchronize()
@@ -222,7 +223,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_bytes, "traffic_unit": "bytes/launch",
                      "traffic_source": traffic_src, "algorithmic_bytes": BYTES_PER_ENV_STEP * n,
                      "kernel": info["name"], "kernel_us": kernel_ms * 1e3, "launches_timed": n_launch,
-                     "stamping": "every launch" if (a.stamp_every_launch or a.steps < 64) else "pairs every 16 launches, second counted",
+                     "stamping": "every launch" if (a.stamp_every_launch or a.steps < 64) else "pairs every %d launches, second counted" % max(16, a.steps // 128),
                      "bytes_per_env_step": BYTES_PER_ENV_STEP, "vgprs": info["vgprs"], "block": info["block"],
                      "grid": info["grid"]},
         "rk4_substeps_per_s": value * a.substeps,
