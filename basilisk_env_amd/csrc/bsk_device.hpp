@@ -362,9 +362,10 @@ constexpr int SH_RING = 8;
 // With one wave per SIMD every instruction of any kind costs the wave a full issue slot (measured: 18
 // VALU + 7 other instructions per chunk = 60 % VALU-active), so at small batches the columns of each
 // spacecraft are split over two waves (TWO; a 256-thread workgroup = 2 x 64 spacecraft x 2 halves, so that
-// its four waves land on the four SIMDs of a CU): both waves of a pair carry the same 64 spacecraft, each walks half of the entries, they exchange four partial sums through LDS, and the SIMD
-// overlaps one wave's loads / scalar instructions with the other's FMAs.  Both forms add the two halves'
-// partial sums in the same order, so their results are bit-identical.
+// its four waves land on the four SIMDs of a CU): both waves of a pair carry the same 64 spacecraft,
+// each walks half of the entries, they exchange four partial sums through LDS, and the SIMD overlaps
+// one wave's loads / scalar instructions with the other's FMAs.  Both forms add the two halves' partial
+// sums in the same order, so their results are bit-identical.
 template <bool TWO, class Hot>
 __device__ __forceinline__ V3 gravity_sh_dpp(const Hot& c, V3 p) {
     const double r2 = dot(p, p);
@@ -415,8 +416,9 @@ __device__ __forceinline__ V3 gravity_sh_dpp(const Hot& c, V3 p) {
     // One entry = the recursion step (two dependent ops: fmac -> mul -> next entry's fmac) interleaved with
     // the six coefficient sums of the PREVIOUS entry, so that no fp64 op waits on its predecessor's result
     // and the compiler has no hazard to pad with s_nop (a DPP FMA must not read a VGPR written by one of the
-    // two preceding instructions, a plain VALU read of a DPP-FMA result wants five in between).  Bn = -rho^2 Bt_(L-2) is prepared one entry ahead; the entry opens with
-    // the instruction that needs the chunk just loaded, so one s_waitcnt serves the whole chunk.
+    // two preceding instructions, a plain VALU read of a DPP-FMA result wants five in between).
+    // Bn = -rho^2 Bt_(L-2) is prepared one entry ahead; the entry opens with the instruction that needs
+    // the chunk just loaded, so one s_waitcnt serves the whole chunk.
     // Bp = the previous entry's Bt (its sums are still pending), (qp, OP) = where its coefficients sit.
     double Bp = 0.0, Bn = 0.0;
     auto entry = [&](double qc, auto OC, double qp, auto OP) {
