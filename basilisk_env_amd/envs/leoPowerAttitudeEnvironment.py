@@ -168,35 +168,41 @@ class leoPowerAttEnv(spaces.Env):
         self._drop_simulator()
 
 
-if __name__ == "__main__":
-    # The reference module's demo main (:218-244): loop through the env twice with action 0 and keep the
-    # observation history; the plots are optional here (``--plot``), a text summary is always printed.
-    import sys
 
+def demo(episodes=2, action=0, seed=12345, plot=False):
+    """What the reference module does when run as a script (:218-244): roll whole episodes with one fixed
+    action and keep the observation history.  Returns the per-episode histories (5, steps); prints one
+    line per episode; ``plot=True`` draws them if matplotlib is available."""
+    names = ("attitude error", "body rate", "wheel speed / limit", "battery / capacity", "sunlit fraction")
     env = leoPowerAttEnv()
-    hist_list = []
-    for ind in range(0, 2):
-        hist = np.zeros([5, 2 * env.max_length])
+    histories = []
+    for ep in range(episodes):
         env.reset()
-        env.seed(seed=12345)
-        total = 0.0
-        for step in range(0, env.max_length):
-            ob, reward, ep_over, info = env.step(0)
-            hist[:, step] = ob[:, 0]
-            total += reward
-            if ep_over:
+        env.seed(seed=seed)
+        rows, ret = [], 0.0
+        while True:
+            ob, reward, over, _ = env.step(action)
+            rows.append(ob[:, 0].copy())
+            ret += reward
+            if over or len(rows) >= env.max_length:
                 break
-        hist_list.append(hist)
-        print("run %d: %d steps, return %.4f, final obs %s" % (ind, step + 1, total, np.array2string(ob[:, 0], precision=5)))
-    if "--plot" in sys.argv:
+        hist = np.array(rows).T
+        histories.append(hist)
+        print("episode %d: %d steps, return %.4f, last observation %s" % (ep, hist.shape[1], ret, np.array2string(hist[:, -1], precision=5)))
+    env.close()
+    if plot:
         from matplotlib import pyplot as plt
-        labels = ['attitude norm', 'rate norm', 'wheel norm', 'Battery Level', 'Eclipse ind']
-        for count, hist in enumerate(hist_list):
+        for ep, hist in enumerate(histories):
             plt.figure()
-            for k in range(5):
-                plt.plot(range(0, env.max_length * 2), hist[k, :], label=labels[k])
+            for k, name in enumerate(names):
+                plt.plot(hist[k], label=name)
             plt.grid()
             plt.legend()
-            plt.title('History of run %d' % count)
+            plt.title("episode %d" % ep)
         plt.show()
-    env.close()
+    return histories
+
+
+if __name__ == "__main__":
+    import sys
+    demo(plot="--plot" in sys.argv)
