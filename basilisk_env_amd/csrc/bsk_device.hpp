@@ -231,14 +231,55 @@ __device__ __forceinline__ double asin_small(double s) {
     return s * fma(z, fma(z, fma(z, fma(z, 35.0 / 1152.0, 15.0 / 336.0), 3.0 / 40.0), 1.0 / 6.0), 1.0);
 }
 
+// asin(sqrt z) / sqrt z on z in [0, 1/4]: degree-12 polynomial (Chebyshev fit in 50-digit arithmetic, maximum
+// error 3e-17).  The two inverse functions the penumbra needs are built on it with half-angle reductions,
+// branch-free: the library's asin / atan2 cost the wave ~400 instructions with all their argument-range
+// branches, and the wave pays them whenever one lane is in the penumbra.
+__device__ __forceinline__ double asin_core(double z) {
+    double p = 0.03187962140081284;
+    p = fma(p, z, -0.016187392271599134);
+    p = fma(p, z, 0.019513468251252167);
+    p = fma(p, z, 0.0065293020047365695);
+    p = fma(p, z, 0.012170138592391726);
+    p = fma(p, z, 0.01388484282640208);
+    p = fma(p, z, 0.01735977964134998);
+    p = fma(p, z, 0.022371749733164054);
+    p = fma(p, z, 0.03038195969768514);
+    p = fma(p, z, 0.044642856805998936);
+    p = fma(p, z, 0.07500000000385201);
+    p = fma(p, z, 0.16666666666664942);
+    return fma(p, z, 1.0);
+}
+// asin(s) for s in [0, 1]
+__device__ __forceinline__ double asin01(double s) {
+    const bool big = s > 0.5;
+    const double z = big ? fma(-0.5, s, 0.5) : s * s;          // sin^2 of half the complementary angle | s^2
+    const double q = big ? sqrt_nr(z) : s;
+    const double r = q * asin_core(z);
+    return big ? fma(-2.0, r, 1.57079632679489661923) : r;
+}
+// the angle theta in [0, pi] with cos theta = x/a, sin theta = y/a (y >= 0, x^2 + y^2 = a^2): near the axes the
+// half angle comes from the SINE (y), so the result is well conditioned everywhere (acos(x/a) is not)
+__device__ __forceinline__ double angle_xy(double x, double y, double a) {
+    const double ia = rcp_nr(a), t = x * ia, sy = y * ia, at = fabs(t);
+    const bool big = at > 0.5;
+    const double z = big ? 0.5 * sy * sy * rcp_nr(1.0 + at) : t * t;
+    const double q = big ? sqrt_nr(z) : at;
+    const double r = q * asin_core(z);
+    const double PI = 3.14159265358979323846;
+    const double base = big ? (t > 0.0 ? 0.0 : PI) : 0.5 * PI;
+    const double k = big ? (t > 0.0 ? 2.0 : -2.0) : (t > 0.0 ? -1.0 : 1.0);
+    return fma(k, r, base);
+}
+
 // visible fraction of the solar disc inside the shadow cones: total eclipse is decided on cosines
 // (no inverse trigonometry); only partial / annular phases reach the inverse functions.
 // The reference's lens-area formula is  1 - [a^2 acos(x/a) + b^2 acos((c-x)/b) - c y] / (pi a^2),
 // x = (c^2 + a^2 - b^2)/2c, y = sqrt(a^2 - x^2), with the apparent radii a = asin(sa), b = asin(sb) and
 // the separation c = acos(cc).  When the solar disc is small against the planet's (always in LEO:
-// sa ~ 4.7e-3, sb ~ 0.93) the same quantities follow from two library calls instead of five, and
-// without the formula's cancellations: a and theta2 = acos((c-x)/b) = asin(y/b) by series,
-// delta = c - b from sin(delta) = sin c cos b - cos c sin b by series, theta1 = acos(x/a) = atan2(y, x),
+// sa ~ 4.7e-3, sb ~ 0.93) the same quantities follow without library calls and without the formula's
+// cancellations: a and theta2 = acos((c-x)/b) = asin(y/b) by series, delta = c - b from
+// sin(delta) = sin c cos b - cos c sin b by series, b = asin01(sb), theta1 = acos(x/a) = angle_xy(x, y, a),
 // and b^2 theta2 - c y = b^2 (theta2 - y/b) - delta y.  (The wave executes this path whenever one of its
 // 64 spacecraft is in the penumbra, and with one wave per SIMD the slowest wave sets the kernel time.)
 __device__ __forceinline__ double percent_shadow(const PowerCfg& pc, V3 r_HB, V3 r, double r2) {
@@ -251,13 +292,13 @@ __device__ __forceinline__ double percent_shadow(const PowerCfg& pc, V3 r_HB, V3
     if (cc <= fma(cb, ca, -(sb * sa))) return 1.0;                              // c >= a + b : none
     const double PI = 3.14159265358979323846;
     if (sa < 0.03125 * sb) {
-        const double a = asin_small(sa), b = asin(sb);
+        const double a = asin_small(sa), b = asin01(sb);
         const double sc = sqrt_nr(fma(-cc, cc, 1.0));
         const double d = asin_small(fma(sc, cb, -(cc * sb)));                   // c - b, |d| <= a
         const double c = b + d, a2 = a * a;
         const double x = fma(d, fma(2.0, b, d), a2) * rcp_nr(2.0 * c);
         const double y = sqrt_nr(fmax(fma(-x, x, a2), 0.0));
-        const double th1 = atan2(y, x);
+        const double th1 = angle_xy(x, y, a);
         const double w = y * rcp_nr(b), z = w * w;                              // theta2 - y/b = w^3 (1/6 + ...)
         const double t2 = w * z * fma(z, fma(z, fma(z, 35.0 / 1152.0, 15.0 / 336.0), 3.0 / 40.0), 1.0 / 6.0);
         const double area = fma(a2, th1, fma(b * b, t2, -(d * y)));
