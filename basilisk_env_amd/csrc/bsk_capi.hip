@@ -287,6 +287,14 @@ int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool&
             k.fa_r[1][axis][j] = 0.5 * (rp - rm);
         }
     }
+    if (k.facet_axis) {
+        bool diagonal = true;
+        for (int sgn = 0; sgn < 2; ++sgn)
+            for (int axis = 0; axis < 3; ++axis)
+                for (int j = 0; j < 3; ++j)
+                    if (j != axis && k.fa_r[sgn][axis][j] != 0.0) diagonal = false;
+        if (diagonal) k.facet_axis = 2;   // facet centres on their own normal axes: 12 table values suffice
+    }
     for (int i = 0; i < 8; ++i) {
         k.facet_acd[i] = c.facet_area[i] * c.facet_cd[i];
         for (int j = 0; j < 3; ++j) { k.facet_n[i][j] = c.facet_normal[i][j]; k.facet_r[i][j] = c.facet_pos[i][j]; }

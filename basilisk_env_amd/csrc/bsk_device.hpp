@@ -133,7 +133,7 @@ struct ColdCfg {
     double facet_n[8][3], facet_r[8][3];
     // facets whose normals are +-body axes (all eight of the reference's): per axis k, half sum [0] and
     // half difference [1] of the +e_k and -e_k facets' area*Cd and area*Cd*r (facet_axis = 1 when every
-    // facet is of that kind)
+    // facet is of that kind, 2 when in addition every fa_r[.][k][j != k] is exactly zero)
     double fa_c[2][3];
     double fa_r[2][3][3];
     int32_t n_facets, n_thr;
@@ -653,10 +653,12 @@ struct Env {
     double thr_lim[BSK_MAX_THR];
     double thr_max;   // max over thrusters of thr_lim (0 = no burst pending): one compare per tick decides thr_on
     int e2;
-    // axis-aligned facet tables (registers; loaded once per launch when drag is enabled)
-    bool facet_axis;
-    double fa_c[2][3];
-    V3 fa_r[2][3];
+    // axis-aligned facets (ColdCfg::facet_axis): 2 = every facet centre also lies on its own normal axis
+    // (all eight of the reference's), so the moment table is diagonal and 12 values in registers describe
+    // the whole set; 1 = axis-aligned normals only, tables read from memory at each use; 0 = generic loop
+    int facet_axis;
+    double fa_c[2][3];   // half sum / half difference of area*Cd per axis
+    double fa_d[2][3];   // the same for area*Cd*r_k (component k of the facet centre)
 };
 
 // thrust of the active thrusters at integrator time e2 (half dyn steps since the burst started)
@@ -690,16 +692,24 @@ __device__ __forceinline__ void facet_drag(const Env& ev, V3 sig, V3 vN, V3& aN,
     const V3 vh = iv * vB;
     double S = 0.0;
     V3 Rc = mk(0, 0, 0);
-    if (ev.facet_axis) {
-        // normals are +-e_k: the facets facing the flow on axis k are the +e_k ones when v_hat_k > 0, the
-        // -e_k ones otherwise, and |x| sel(x > 0, p, m) = |x| (p + m)/2 + x (p - m)/2 needs no select
-        // (fa_c / fa_r hold the half sums [0] and half differences [1]; |x| is a free source modifier)
+    // normals are +-e_k: the facets facing the flow on axis k are the +e_k ones when v_hat_k > 0, the
+    // -e_k ones otherwise, and |x| sel(x > 0, p, m) = |x| (p + m)/2 + x (p - m)/2 needs no select
+    // (the tables hold the half sums [0] and half differences [1]; |x| is a free source modifier)
+    if (ev.facet_axis == 2) {
+        S = fma(fabs(vh.x), ev.fa_c[0][0], fma(vh.x, ev.fa_c[1][0], S));
+        S = fma(fabs(vh.y), ev.fa_c[0][1], fma(vh.y, ev.fa_c[1][1], S));
+        S = fma(fabs(vh.z), ev.fa_c[0][2], fma(vh.z, ev.fa_c[1][2], S));
+        Rc = mk(fma(fabs(vh.x), ev.fa_d[0][0], vh.x * ev.fa_d[1][0]), fma(fabs(vh.y), ev.fa_d[0][1], vh.y * ev.fa_d[1][1]),
+                fma(fabs(vh.z), ev.fa_d[0][2], vh.z * ev.fa_d[1][2]));
+    } else if (ev.facet_axis == 1) {
+        const ColdCfg* cc = ev.cold;
         const double vk[3] = {vh.x, vh.y, vh.z};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const double a = fabs(vk[k]);
-            S = fma(a, ev.fa_c[0][k], fma(vk[k], ev.fa_c[1][k], S));
-            Rc = axpy(a, ev.fa_r[0][k], axpy(vk[k], ev.fa_r[1][k], Rc));
+            S = fma(a, cc->fa_c[0][k], fma(vk[k], cc->fa_c[1][k], S));
+            Rc = axpy(a, mk(cc->fa_r[0][k][0], cc->fa_r[0][k][1], cc->fa_r[0][k][2]),
+                      axpy(vk[k], mk(cc->fa_r[1][k][0], cc->fa_r[1][k][1], cc->fa_r[1][k][2]), Rc));
         }
     } else {
         const ColdCfg* cc = ev.cold;

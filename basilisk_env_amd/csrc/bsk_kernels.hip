@@ -119,15 +119,21 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : BSK_MIN_WAVES
         ev.s3.sun3 = (a.extra.mu_sun * sg.ism * sg.ism * sg.ism) * sg.sun;
         ev.thr_on = false;
         ev.e2 = 0;
-        ev.facet_axis = false;
-        if (a.extra.base_density != 0.0 && cold->facet_axis) {
-            ev.facet_axis = true;
+        ev.facet_axis = (a.extra.base_density != 0.0) ? cold->facet_axis : 0;
+#pragma unroll
+        for (int sgn = 0; sgn < 2; ++sgn)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                ev.fa_c[sgn][k] = 0.0;
+                ev.fa_d[sgn][k] = 0.0;
+            }
+        if (ev.facet_axis == 2) {
 #pragma unroll
             for (int sgn = 0; sgn < 2; ++sgn)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     ev.fa_c[sgn][k] = cold->fa_c[sgn][k];
-                    ev.fa_r[sgn][k] = mk(cold->fa_r[sgn][k][0], cold->fa_r[sgn][k][1], cold->fa_r[sgn][k][2]);
+                    ev.fa_d[sgn][k] = cold->fa_r[sgn][k][k];
                 }
         }
 #pragma unroll
