@@ -63,7 +63,7 @@ def timed_run(prop, d_act_ptr, substeps, steps, warmup, barrier, torch, stamp_al
     # launch for short runs); ~128 samples per run, never more often than every 16th launch; see
     # bsk_profile_set_stride
     stride = max(16, steps // 128) if (steps >= 64 and not stamp_all) else 1
-    prop.profile_begin(steps, stride=stride)
+    prop.profile_begin(steps // stride + 2, stride=stride)   # capacity = launches that will be stamped and counted
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
