@@ -120,6 +120,38 @@ def test_facet_geometries_match_oracle(geometry):
     prop.close()
 
 
+def test_full_scenario_full_size_65536():
+    """The full-scenario kernel at the bench size: a sample of envs spread over the batch against the oracle,
+    and size-independent properties on all of them (battery within its capacity, eclipse fraction in [0, 1],
+    |sigma| <= 1, device batch scalars = host sums)."""
+    from basilisk_env_amd._lib import FLAG_DESAT
+    n, n_rw, k = 65536, 4, 60
+    cfg = default_config(n_rw, GRAV_PM_J2)
+    cfg.flags |= FLAG_POWER | FLAG_SUN_THIRD_BODY | FLAG_DRAG | FLAG_DESAT
+    ic = sample_ic_batch(n, n_rw, seed=2)
+    rng = np.random.default_rng(2)
+    act = rng.integers(0, 3, n).astype(np.int32)
+    prop = BatchedPropagator(cfg, n)
+    prop.reset(ic)
+    prop.step(act, k)
+    obs, rew, done, why = prop.get_obs()
+    s = prop.get_state()
+    idx = np.linspace(0, n - 1, 64).astype(int)
+    st = np.ascontiguousarray(ic[:, idx])
+    o = oracle.step(cfg, st, np.zeros(idx.size, np.int32), np.zeros(idx.size, np.int32), act[idx], k)
+    errs = max_group_err(s[:, idx], st, n_rw)
+    assert max(errs.values()) < 1e-11, errs
+    assert np.abs(obs[:4, idx] - o[0][:4]).max() < 1e-11 and np.abs(obs[4, idx] - o[0][4]).max() < 2e-8
+    t = 12 + n_rw
+    assert np.isfinite(s).all()
+    assert (s[t + 7] >= 0).all() and (s[t + 7] <= cfg.storage_capacity).all()
+    assert (obs[4] >= 0).all() and (obs[4] <= 1).all() and ((obs[4] > 0) & (obs[4] < 1)).any()
+    assert ((s[6:9] ** 2).sum(0) <= 1 + 1e-12).all()
+    rsum, ndone = prop.batch_stats()
+    assert abs(rsum - rew.sum()) < 1e-9 and ndone == int(done.sum())
+    prop.close()
+
+
 def test_flags_need_power():
     cfg = default_config(0, GRAV_PM)
     cfg.flags |= FLAG_DRAG
