@@ -143,7 +143,8 @@ struct ColdCfg {
     double thr_f[BSK_MAX_THR][3], thr_l[BSK_MAX_THR][3];  // force / torque of thruster i at full thrust, body frame
     double hs_min, inv_max_thrust, thr_min_fire_time, thr_min_on_time;
     double gs[BSK_MAX_RW][3], js[BSK_MAX_RW];
-    int32_t thr_max_counter, pad_;
+    int32_t thr_max_counter;
+    int32_t fsw_lag;   // bsk_config.fsw_lag: MRP_Feedback consumes the previous FSW tick's att_guidance
 };
 
 // Guidance / observation / reward constants: by value in the kernarg (used once per launch, outside

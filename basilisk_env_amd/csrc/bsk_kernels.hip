@@ -73,7 +73,9 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : BSK_MIN_WAVES
     double charge = ldf(FLD(TAIL + BSK_T_CHARGE), bo);
     const int2 cnt = *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(a.cnt) + bo);  // {steps | phase << 20, ticks}
     const int action = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(a.act) + (bo >> 1));
-    double u[NRW > 0 ? NRW : 1];
+    double u[NRW > 0 ? NRW : 1], up[NRW > 0 ? NRW : 1];
+#pragma unroll
+    for (int k = 0; k < (NRW > 0 ? NRW : 1); ++k) up[k] = 0.0;
     // the held motor torque only matters when this launch starts between two FSW ticks; it is
     // loaded unconditionally so that all loads are in flight at once
 #pragma unroll
@@ -156,8 +158,23 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : BSK_MIN_WAVES
         int m = substeps_eff - j;
         if constexpr (NRW > 0) {
             if (phase == 0) {
+                // mrpControlTask order of the reference (MRP_Feedback before attTrackingError, ...Simulator.py:484-486;
+                // bsk_config.fsw_lag): this tick commands the torque the PREVIOUS tick's guidance maps to and
+                // leaves its own for the next one.  The pending torque comes from the slab on the launch's first
+                // FSW tick (issued here, consumed after the guidance arithmetic) and stays in registers afterwards.
+                const bool lag = cold->fsw_lag != 0;
+                if (lag && first_fsw) {
+#pragma unroll
+                    for (int k = 0; k < NRW; ++k) up[k] = ldf(st + (int64_t)(TAIL + BSK_T_UPEND + k) * S, bo);
+                }
                 Guid g = guidance<NRW>(cold->sigma_R0N, x, action);
-                control<NRW>(cold, g, u);
+                if (lag) {
+#pragma unroll
+                    for (int k = 0; k < NRW; ++k) u[k] = up[k];
+                    control<NRW>(cold, g, up);
+                } else {
+                    control<NRW>(cold, g, u);
+                }
                 fsw_ran = true;
                 if constexpr (FEAT == FEAT_FULL) {
                     if (desat && action == 2) {
@@ -297,10 +314,15 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : BSK_MIN_WAVES
             if (fsw_ran) {
 #pragma unroll
                 for (int k = 0; k < NRW; ++k) stf(FLD(TAIL + BSK_T_UCMD + k), bo, u[k]);
+                if (tp->fsw_lag) {
+#pragma unroll
+                    for (int k = 0; k < NRW; ++k) stf(FLD(TAIL + BSK_T_UPEND + k), bo, up[k]);
+                }
             }
         }
         // int2 {steps | phase << 20, ticks} written as one 8-byte word
-        const unsigned long long packed = (unsigned long long)(unsigned)((steps0 + 1) | (phase << 20)) |
+        // the step count saturates at 2^20 - 1 so that it can never spill into the phase bits
+        const unsigned long long packed = (unsigned long long)(unsigned)(min(steps0 + 1, 0xFFFFF) | (phase << 20)) |
                                           ((unsigned long long)(unsigned)(cnt.y + tp->substeps) << 32);
         *(gptr<unsigned long long>)((gptr<char>)uniform_ptr(tp->cnt) + bo) = packed;
         stf(ob + 0 * S2, bo, o0); stf(ob + 1 * S2, bo, o1); stf(ob + 2 * S2, bo, o2); stf(ob + 3 * S2, bo, o3);
@@ -473,6 +495,7 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     a.tail.stride = b.stride; a.tail.n = b.n; a.tail.substeps = b.substeps;
     a.tail.pool = b.pool; a.tail.term_obs = b.term_obs; a.tail.episodes = b.episodes;
     a.tail.n_pool = b.n_pool; a.tail.n_fields = b.n_fields;
+    a.tail.fsw_lag = p.fsw_lag; a.tail.pad_ = 0;
     if (SPLIT == 5) block = 256;
     const int grid = SPLIT == 5 ? (b.n + 127) / 128 : (b.n + block - 1) / block;
     const size_t lds = 0;

@@ -29,6 +29,7 @@ struct TailArgs {
     int* episodes;                 // [stride]
     int n_pool;
     int n_fields;
+    int fsw_lag, pad_;
 };
 
 // Passed by value to step_kernel (kernarg segment -> SGPRs).
@@ -63,6 +64,7 @@ struct StepParams {
     int32_t sh_bodies, sh_bodies0, sh_bodies1, sh_chunk1;   // DPP stream: bodies (whole / per half), first chunk of half 1
     int sh_form;            // 1 scalar-load stream, 4 DPP broadcast, 5 DPP broadcast over two cooperating waves
     int feat;               // FEAT_BARE / FEAT_POWER / FEAT_FULL
+    int fsw_lag;
     PowerCfg pc;
     ExtraCfg ex;
 };

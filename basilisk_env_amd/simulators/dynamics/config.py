@@ -59,6 +59,7 @@ def default_config(n_rw=3, gravity_model=GRAV_PM, mass=330.0, width=1.38, depth=
     c.gravity_model = gravity_model
     c.n_rw = n_rw
     c.max_length = 540
+    c.fsw_lag = 1   # mrpControlTask order of the reference (...Simulator.py:484-486): control lags guidance by one FSW tick
     c.mu = MU_EARTH
     c.req = REQ_EARTH_KM * 1000.0
     c.j2 = math.sqrt(5.0) * -CBAR_20

@@ -2,27 +2,37 @@
 """bench.py — env-steps/s of the batched HIP propagator on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 works both ways: as typed (this process starts ``python -m torch.distributed.run --nproc-per-node N
+bench.py ...`` as a CHILD, before anything here has touched the GPU, relays its output and exits with its
+code) or already under ``torch.distributed.run`` (RANK / LOCAL_RANK / WORLD_SIZE in the environment).
 
 Workload (BASELINE.json configs[2], the one the metric is quoted on): 65 536 spacecraft PER GPU,
 J2 gravity + 4 reaction wheels (pyramid) + nadir-pointing reward (action 0), fp64, synthetic
 random-orbit batch, one RK4 sub-step of 0.1 s per env step (the HBM framing
 of the metric).  Envs are independent: ranks shard them with no collective on the step path
-("scaling": "weak"); one RCCL all-gather of the observation shards is exercised and timed
-after the timed region (``gather_ms``).
+("scaling": "weak"); the one exchange step — delivering the observation batch — is timed after
+the timed region (``gather``: RCCL gather to rank 0, RCCL all-gather, and each GPU's direct D2H).
 
 A "step" = one pass of the hot path over the whole batch (one kernel launch per GPU): mode
 switch, FSW chain when due, RK4, observation, reward, done mask, wave reductions.  Actions and
 state are resident in HBM when the timed region starts.
 
-Besides the contract keys the JSON line carries ``roofline`` (dominant kernel, algorithmic
-bytes = 340 B/env-step), ``cpu_baseline`` (the CPU oracle on this box's host
-cores, rank 0 at N=1 only) and ``extra`` (the reference-faithful 1 800 sub-steps/env-step rate
-and a large-batch roofline point).
+Timing.  ``value`` / ``ms_per_step`` come from the wall clock around EXACTLY ``--steps`` launches that
+carry no timestamps (nothing but the launches is enqueued between the two synchronisations), so they do
+not depend on ``--steps``.  ``roofline.kernel_us`` comes from a separate, shorter pass afterwards in which
+every launch is dispatch-stamped (hipExtLaunchKernelGGL start/stop events on the launch stream).
+
+Besides the contract keys the JSON line carries ``roofline`` (dominant kernel: HBM-bound at K = 1 with
+340 algorithmic bytes per env-step; fp64-issue-bound for K >> 1, the harmonics and the
+scenario levels, with EXECUTED flops from the committed SQ_INSTS_VALU_*_F64 counter passes),
+``cpu_baseline`` (the CPU oracle on this box's host cores, rank 0 at N = 1 only) and ``extra``.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,10 +41,12 @@ sys.path.insert(0, ROOT)
 
 BYTES_PER_ENV_STEP = 340.0   # config 3/4 algorithmic bytes per env-step
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FLOP_PER_RK4 = 4 * 330 + 110  # SURVEY.md §8(d) algorithmic flops per RK4 sub-step, config 3
+HBM_COPY_CEILING_GBS = 6290.0  # MI355X_MICROARCH.md: measured copy ceiling (SURVEY.md §8(d) asks for both)
+FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector peak (FMA = 2 flop), per GPU
+STAMPED_LAUNCHES = 64        # launches of the separate dispatch-stamped pass
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=10000)
@@ -46,61 +58,103 @@ def parse():
     p.add_argument("--scenario", choices=["bare", "power", "full"], default="bare",
                    help="bare = BASELINE configs[2] as named (headline); power / full add the reference scenario's "
                         "power system / + Sun third body, drag and desaturation (what the drop-in env runs)")
-    p.add_argument("--stamp-every-launch", action="store_true",
-                   help="dispatch-timestamp every launch of the timed region (lower throughput, every kernel isolated; "
-                        "used for the rocprofv3 kernel-trace passes so that both report the same thing)")
+    p.add_argument("--lds-scratch", action="store_true", help="BSK_FLAG_LDS_SCRATCH kernel variant (RK4 accumulator in LDS)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true")
-    return p.parse_args()
+    return p.parse_args(argv)
 
 
-def timed_run(prop, d_act_ptr, substeps, steps, warmup, barrier, torch, stamp_all=False):
+# ---------------------------------------------------------------------------------------------
+# N > 1 as typed: spawn the launcher as a child.  Nothing above or in here imports torch or touches HIP, so the
+# parent never initialises the GPU (a process that has must not exec or be replaced; it may start children).
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launcher_command(gpus, argv, port):
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(gpus, argv, popen=subprocess.Popen, out=None):
+    """Run ``bench.py argv`` on ``gpus`` ranks in a child ``torch.distributed.run``; relay its stdout line by
+    line (rank 0 prints the one JSON line) and return its exit code."""
+    out = out or sys.stdout
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    proc = popen(launcher_command(gpus, argv, _free_port()), stdout=subprocess.PIPE, text=True, env=env)
+    for line in proc.stdout:
+        out.write(line)
+        out.flush()
+    return proc.wait()
+
+
+# ---------------------------------------------------------------------------------------------
+def timed_run(prop, d_act_ptr, substeps, steps, warmup, barrier, device_sync):
+    """Wall time of exactly ``steps`` un-stamped launches between two barrier + device synchronisations."""
     for _ in range(warmup):
         prop.step_device(d_act_ptr, substeps)
     prop.sync()
-    # dispatch timestamps on a sample of the timed launches: stamping costs ~5 us of launch throughput
-    # per stamped launch, so a pair is stamped every `stride` launches and its second launch counted (every
-    # launch for short runs); ~128 samples per run, never more often than every 16th launch; see
-    # bsk_profile_set_stride
-    stride = max(16, steps // 128) if (steps >= 64 and not stamp_all) else 1
-    prop.profile_begin(steps // stride + 2, stride=stride)   # capacity = launches that will be stamped and counted
     barrier()
-    torch.cuda.synchronize()
+    device_sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         prop.step_device(d_act_ptr, substeps)
-    torch.cuda.synchronize()
+    device_sync()
     t1 = time.perf_counter()   # this rank's K steps are done; the MAX over ranks is taken by the caller
     barrier()
-    kernel_ms, n_launch = prop.profile_end()
-    return t1 - t0, kernel_ms, n_launch
+    return t1 - t0
 
 
-def cpu_baseline(cfg, n_rw, substeps):
+def kernel_time(prop, d_act_ptr, substeps, launches):
+    """Mean duration [ms] of the step kernel over ``launches`` dispatch-stamped launches (its own pass)."""
+    prop.sync()
+    prop.profile_begin(launches, stride=1)
+    for _ in range(launches):
+        prop.step_device(d_act_ptr, substeps)
+    return prop.profile_end()
+
+
+def cpu_baseline(cfg, n_rw, substeps, budget_s=12.0, n=8192):
     """The CPU oracle (plain-C restatement, oracle/bsk_oracle.c) on the host cores of this box:
-    OpenMP over spacecraft, bounded to ~10-20 s.  A reported baseline, not the target."""
+    OpenMP over spacecraft, bounded to ~budget_s.  A reported baseline, not the target."""
     import numpy as np
 
     from basilisk_env_amd.simulators.initial_conditions.batch import sample_ic_batch
     from oracle import oracle
 
     cores = oracle.set_threads(oracle.usable_cpus())
-    n = 8192
     st = sample_ic_batch(n, n_rw, seed=0)
     steps_c, ticks_c = np.zeros(n, np.int32), np.zeros(n, np.int32)
     act = np.zeros(n, np.int32)
-    oracle.step(cfg, st, steps_c, ticks_c, act, substeps, omp=True)  # warm
+    if substeps == 1:
+        oracle.step(cfg, st, steps_c, ticks_c, act, substeps, omp=True)  # warm
     t0 = time.perf_counter()
     done_steps = 0
     while True:
         oracle.step(cfg, st, steps_c, ticks_c, act, substeps, omp=True)
         done_steps += 1
         el = time.perf_counter() - t0
-        if el > 12.0 or done_steps >= 100000:
+        if el > budget_s or done_steps >= 100000:
             break
     return {"value": n * done_steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": "%d envs x %d env-steps of %d RK4 sub-step(s), same physics/config, OpenMP over envs, %.1f s"
                       % (n, done_steps, substeps, el)}
+
+
+def _latest_profile(name):
+    d = os.path.join(ROOT, "profiles")
+    best = None
+    for sub in sorted(os.listdir(d)) if os.path.isdir(d) else []:
+        f = os.path.join(d, sub, name)
+        if os.path.exists(f):
+            best = f
+    return best
 
 
 def pmc_traffic(n_envs, substeps):
@@ -109,11 +163,7 @@ def pmc_traffic(n_envs, substeps):
     same command, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  None when no matching profile."""
     if substeps != 1:
         return None, None
-    best = None
-    for d in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
-        f = os.path.join(ROOT, "profiles", d, "summary_latest.json")
-        if os.path.exists(f):
-            best = f
+    best = _latest_profile("summary_latest.json")
     if not best:
         return None, None
     try:
@@ -123,13 +173,91 @@ def pmc_traffic(n_envs, substeps):
         return None, None
 
 
+def isa_mix(key):
+    """fp64 instructions the step kernel EXECUTES per RK4 sub-step and wave, by class, from the committed
+    SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 counter passes (tools/isa_mix.sh -> profiles/*/isa_mix.json).
+    key: 'bare' | 'power' | 'full' | 'sh'.  -> (dict, source) or (None, None)."""
+    best = _latest_profile("isa_mix.json")
+    if not best:
+        return None, None
+    try:
+        m = json.load(open(best)).get(key)
+        return (m, os.path.relpath(best, ROOT)) if m else (None, None)
+    except Exception:
+        return None, None
+
+
+def fp64_roofline(key, rk4_steps_per_gpu, kernel_s, info):
+    """Roofline object for the fp64-issue-bound regimes: executed flop = 64 lanes x (2 FMA + MUL + ADD + TRANS)
+    per wave-instruction (counter passes), against the 78.6 TFLOP/s fp64 vector peak."""
+    mix, src = isa_mix(key)
+    out = {"bound": "fp64", "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None, "kernel": info["name"],
+           "kernel_us": kernel_s * 1e6, "vgprs": info["vgprs"], "block": info["block"], "grid": info["grid"]}
+    if not mix or kernel_s <= 0:
+        out.update({"achieved": None, "frac": None, "note": "no isa_mix.json entry '%s' under profiles/" % key})
+        return out
+    flop_per_lane_step = 2.0 * mix["fma"] + mix["mul"] + mix["add"] + mix.get("trans", 0.0)
+    achieved = flop_per_lane_step * rk4_steps_per_gpu / kernel_s / 1e12
+    # the same instructions as issue slots: one fp64 wave-instruction occupies its SIMD for 4 cycles
+    out.update({"achieved": achieved, "frac": achieved / FP64_PEAK_TFLOPS, "flop_per_rk4_step_executed": flop_per_lane_step,
+                "fp64_instr_per_rk4_step": mix["fma"] + mix["mul"] + mix["add"] + mix.get("trans", 0.0),
+                "valu_instr_per_rk4_step": mix.get("valu"), "isa_mix_source": src})
+    return out
+
+
+def hbm_roofline(n, kernel_s, info, traffic_bytes, traffic_src, launches):
+    achieved = BYTES_PER_ENV_STEP * n / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS, "copy_ceiling": HBM_COPY_CEILING_GBS,
+            "traffic": traffic_bytes, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+            "algorithmic_bytes": BYTES_PER_ENV_STEP * n, "kernel": info["name"], "kernel_us": kernel_s * 1e6,
+            "launches_timed": launches, "stamping": "separate pass after the timed region, every launch stamped",
+            "bytes_per_env_step": BYTES_PER_ENV_STEP, "vgprs": info["vgprs"], "lds_bytes": info["lds_bytes"],
+            "block": info["block"], "grid": info["grid"]}
+
+
 def _with_degree(cfg, degree):
     cfg.sh_degree = degree
     return cfg
 
 
+def gather_legs(prop, dist, torch, world, n):
+    """The one exchange step of the path, three ways: RCCL gather of the observation shards to
+    rank 0, RCCL all-gather, and every GPU copying its own shard to pinned host memory.  Max over ranks, ms."""
+    from basilisk_env_amd.parallel import gather_observations, local_obs_tensor
+
+    def clock(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64)
+        dist.barrier()
+        cpu = dist.get_backend() == "gloo"
+        t = t if cpu else t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    local = local_obs_tensor(prop)
+    host = torch.empty(tuple(local.shape), dtype=local.dtype, pin_memory=True)
+    out = {"shard_bytes": int(local.numel() * 8), "total_bytes": int(local.numel() * 8 * world),
+           "gather_to_rank0_ms": clock(lambda: gather_observations(prop, dist, dst=0)),
+           "all_gather_ms": clock(lambda: gather_observations(prop, dist)),
+           "direct_d2h_per_gpu_ms": clock(lambda: host.copy_(local_obs_tensor(prop), non_blocking=True))}
+    full = gather_observations(prop, dist)
+    assert tuple(full.shape) == (world, 5, n)
+    return out
+
+
 def main():
-    a = parse()
+    argv = sys.argv[1:]
+    a = parse(argv)
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(self_launch(a.gpus, argv))
+
     import numpy as np
     import torch
 
@@ -137,9 +265,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d (run `python bench.py --gpus N` as typed, or "
+                         "torch.distributed.run --nproc-per-node N)" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: no HIP device visible (there is no CPU path to measure)")
     # BENCH_REHEARSAL=1: exercise the N > 1 control flow on a box with a single GPU (every rank on
@@ -160,7 +287,14 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    from basilisk_env_amd._lib import GRAV_PM_J2, GRAV_SH
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    from basilisk_env_amd._lib import FLAG_LDS_SCRATCH, GRAV_PM_J2, GRAV_SH
     from basilisk_env_amd.simulators.dynamics import BatchedPropagator, default_config
     from basilisk_env_amd.simulators.dynamics.gravity_sh import synthetic_sh_coefficients
     from basilisk_env_amd.simulators.initial_conditions.batch import sample_ic_batch
@@ -171,6 +305,8 @@ def main():
     if a.scenario != "bare":
         from basilisk_env_amd._lib import FLAG_DESAT, FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY
         cfg.flags |= FLAG_POWER | ((FLAG_SUN_THIRD_BODY | FLAG_DRAG | FLAG_DESAT) if a.scenario == "full" else 0)
+    if a.lds_scratch:
+        cfg.flags |= FLAG_LDS_SCRATCH
     n = a.envs
     ic = sample_ic_batch(n, n_rw, seed=rank)       # rank r owns env indices [r*n, (r+1)*n)
     prop = BatchedPropagator(cfg if not sh else _with_degree(cfg, 70), n, device=local)
@@ -180,33 +316,23 @@ def main():
     prop.reset(ic)
     d_act = torch.zeros(n, dtype=torch.int32, device="cuda")  # action 0 = nadir pointing (reward mode)
     torch.cuda.synchronize()
+    sync = torch.cuda.synchronize
 
-    el, kernel_ms, n_launch = timed_run(prop, d_act.data_ptr(), a.substeps, a.steps, a.warmup, barrier, torch,
-                                        stamp_all=a.stamp_every_launch)
-    el_t = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
-    if dist is not None:
-        dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
-    el = float(el_t.item())
+    el = max_over_ranks(timed_run(prop, d_act.data_ptr(), a.substeps, a.steps, a.warmup, barrier, sync))
+    kernel_ms, n_launch = kernel_time(prop, d_act.data_ptr(), a.substeps, min(STAMPED_LAUNCHES, max(a.steps, 4)))
     obs, rew, done, why = prop.get_obs()
     assert np.isfinite(obs).all() and np.isfinite(rew).all()
     info = prop.kernel_info()
 
-    # the one exchange step of the path: all-gather of the observation shards over RCCL/xGMI
-    gather_ms = None
-    if dist is not None:
-        from basilisk_env_amd.parallel import gather_observations
-        gather_observations(prop, dist)  # warm
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        full = gather_observations(prop, dist)
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - t0) * 1e3
-        assert full.shape == (world, 5, n)
-
     value = n * world * a.steps / el
-    traffic_bytes, traffic_src = pmc_traffic(n, a.substeps) if not sh else (None, None)
     kernel_s = kernel_ms * 1e-3
-    achieved = BYTES_PER_ENV_STEP * n / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    traffic_bytes, traffic_src = pmc_traffic(n, a.substeps) if (not sh and a.scenario == "bare") else (None, None)
+    hbm = hbm_roofline(n, kernel_s, info, traffic_bytes, traffic_src, n_launch)
+    # which roofline bounds this configuration: K = 1 of the bare / power / full propagator streams its state once
+    # per launch (HBM); many sub-steps per launch and the harmonics are fp64-issue bound
+    mix_key = "sh" if sh else a.scenario
+    fp64_bound = sh or a.substeps >= 10
+    fp64 = fp64_roofline(mix_key, float(n) * a.substeps, kernel_s, info)
     out = {
         "metric": "env steps/sec at 65k parallel spacecraft, 1/2/4/8 MI355X; HBM GB/s vs roofline",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -214,53 +340,73 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "BASELINE configs[%s]: %d envs/GPU, %s gravity + 4 reaction wheels (pyramid) + "
                                "nadir-pointing reward, fp64, dt 0.1 s, %d RK4 sub-step(s) per env step, fsw every 10 "
-                               "sub-steps, synthetic random-orbit batch PCG64(rank)"
+                               "sub-steps (reference task order: fsw_lag 1), synthetic random-orbit batch PCG64(rank)"
                                % ("4" if sh else "2", n, "degree-70 spherical-harmonic (synthetic Kaula field)" if sh else "J2",
                                   a.substeps),
-                   "envs_per_gpu": n, "substeps": a.substeps, "scenario": a.scenario,
+                   "envs_per_gpu": n, "substeps": a.substeps, "scenario": a.scenario, "lds_scratch": bool(a.lds_scratch),
                    "sharding": "env ranges, no step-path collective"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_bytes, "traffic_unit": "bytes/launch",
-                     "traffic_source": traffic_src, "algorithmic_bytes": BYTES_PER_ENV_STEP * n,
-                     "kernel": info["name"], "kernel_us": kernel_ms * 1e3, "launches_timed": n_launch,
-                     "stamping": "every launch" if (a.stamp_every_launch or a.steps < 64) else "pairs every %d launches, second counted" % max(16, a.steps // 128),
-                     "bytes_per_env_step": BYTES_PER_ENV_STEP, "vgprs": info["vgprs"], "block": info["block"],
-                     "grid": info["grid"]},
+        "roofline": fp64 if fp64_bound else hbm,
         "rk4_substeps_per_s": value * a.substeps,
     }
-    if gather_ms is not None:
-        out["gather_ms"] = gather_ms
-
+    if fp64_bound:
+        out["roofline_hbm"] = hbm
     if sh:
-        # config 5 is fp64-VALU bound, not HBM bound: 9 fp64 instructions (7 FMA + 2 MUL = 16 flop) per
-        # (l, m) entry of the padded Pines stream (2 592 entries at degree 70), four field evaluations per RK4
-        # step, + ~450 fp64 instructions for the rest of the step; peak = MI355X fp64 vector 78.6 TFLOP/s
-        flop = (4 * 2592 * 16 + 2 * 450) * a.substeps
-        tf = n * world * a.steps * flop / el / 1e12
-        out["sh"] = {"degree": 70, "fp64_tflops_executed": tf, "fp64_peak_tflops": 78.6 * world,
-                     "frac_of_fp64_peak": tf / (78.6 * world),
-                     "field_evals_per_s": n * world * a.steps * a.substeps * 4 / el}
-    if rank == 0 and world == 1 and not a.no_extra and not sh:
-        extra = {}
+        out["sh"] = {"degree": 70, "field_evals_per_s": n * world * a.steps * a.substeps * 4 / el}
+
+    if dist is not None:
+        out["gather"] = gather_legs(prop, dist, torch, world, n)
+        out["gather_ms"] = out["gather"]["all_gather_ms"]
+
+    extra = {}
+    if world == 1 and not a.no_extra and not sh and a.scenario == "bare" and not a.lds_scratch:
         # reference-faithful env step: 180 s of sim time = 1 800 RK4 sub-steps, 180 FSW updates
         ksteps = 5
-        el2, km2, _ = timed_run(prop, d_act.data_ptr(), 1800, ksteps, 1, barrier, torch)
+        el2 = timed_run(prop, d_act.data_ptr(), 1800, ksteps, 1, barrier, sync)
+        km2, _ = kernel_time(prop, d_act.data_ptr(), 1800, 3)
         extra["k1800"] = {"env_steps_per_s": n * ksteps / el2, "rk4_substeps_per_s": n * ksteps * 1800 / el2,
-                          "fp64_tflops_algorithmic": n * ksteps * 1800 * FLOP_PER_RK4 / el2 / 1e12,
-                          "kernel_ms": km2, "ms_per_step": el2 / ksteps * 1e3}
+                          "kernel_ms": km2, "ms_per_step": el2 / ksteps * 1e3,
+                          "roofline": fp64_roofline("bare", float(n) * 1800, km2 * 1e-3, info)}
         # large-batch point where the HBM roofline is the binding limit (4 Mi envs = 1.4 GB/launch)
         nl = 1 << 22
         big = BatchedPropagator(cfg, nl, device=local)
         big.reset(sample_ic_batch(nl, n_rw, seed=1))
         d_act_big = torch.zeros(nl, dtype=torch.int32, device="cuda")
-        el3, km3, _ = timed_run(big, d_act_big.data_ptr(), 1, 50, 5, barrier, torch)
-        extra["large_n"] = {"envs": nl, "env_steps_per_s": nl * 50 / el3, "kernel_us": km3 * 1e3,
-                            "achieved_gbs": BYTES_PER_ENV_STEP * nl / (km3 * 1e-3) / 1e9,
-                            "frac_of_8TBs": BYTES_PER_ENV_STEP * nl / (km3 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        el3 = timed_run(big, d_act_big.data_ptr(), 1, 50, 5, barrier, sync)
+        km3, nl3 = kernel_time(big, d_act_big.data_ptr(), 1, 20)
+        tb, ts = pmc_traffic(nl, 1)
+        extra["large_n"] = {"envs": nl, "env_steps_per_s": nl * 50 / el3,
+                            "roofline": hbm_roofline(nl, km3 * 1e-3, big.kernel_info(), tb, ts, nl3)}
         big.close()
+    if world > 1 and not a.no_extra and not sh and a.scenario == "bare":
+        # BASELINE configs[3]: 131 072 envs per GPU (1 048 576 on 8), config-3 physics, + the observation exchange
+        n3 = 131072
+        p3 = BatchedPropagator(cfg, n3, device=local)
+        p3.reset(sample_ic_batch(n3, n_rw, seed=1000 + rank))
+        d_act3 = torch.zeros(n3, dtype=torch.int32, device="cuda")
+        el4 = max_over_ranks(timed_run(p3, d_act3.data_ptr(), 1, 500, 20, barrier, sync))
+        km4, _ = kernel_time(p3, d_act3.data_ptr(), 1, 32)
+        extra["config3"] = {"workload": "BASELINE configs[3]: %d envs sharded over %d GPUs (%d per GPU), K = 1" % (n3 * world, world, n3),
+                            "env_steps_per_s": n3 * world * 500 / el4, "ms_per_step": el4 / 500 * 1e3,
+                            "roofline": hbm_roofline(n3, km4 * 1e-3, p3.kernel_info(), None, None, 32),
+                            "gather": gather_legs(p3, dist, torch, world, n3)}
+        p3.close()
+        # strong-scaling points of the literal target (65 536 spacecraft in total), K = 1 and the reference's K = 1 800
+        ns = max(1, 65536 // world)
+        ps = BatchedPropagator(cfg, ns, device=local)
+        ps.reset(sample_ic_batch(ns, n_rw, seed=2000 + rank))
+        d_acts = torch.zeros(ns, dtype=torch.int32, device="cuda")
+        el5 = max_over_ranks(timed_run(ps, d_acts.data_ptr(), 1, 500, 20, barrier, sync))
+        el6 = max_over_ranks(timed_run(ps, d_acts.data_ptr(), 1800, 3, 1, barrier, sync))
+        extra["strong_65536_total"] = {"envs_per_gpu": ns, "k1_env_steps_per_s": ns * world * 500 / el5,
+                                       "k1800_env_steps_per_s": ns * world * 3 / el6, "k1800_ms_per_step": el6 / 3 * 1e3}
+        ps.close()
+    if extra and rank == 0:
         out["extra"] = extra
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not sh:
         out["cpu_baseline"] = cpu_baseline(cfg, n_rw, a.substeps)
+        if "k1800" in extra:
+            # like for like beside extra.k1800: a bounded sample of the reference-faithful env step on the host cores
+            extra["k1800"]["cpu_baseline"] = cpu_baseline(cfg, n_rw, 1800, budget_s=8.0, n=512)
     prop.close()
     if rank == 0:
         print(json.dumps(out), flush=True)

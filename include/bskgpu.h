@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BSK_ABI_VERSION 2u
+#define BSK_ABI_VERSION 3u
 #define BSK_MAX_RW 4
 #define BSK_MAX_THR 8
 #define BSK_MAX_SH_DEGREE 70
@@ -69,7 +69,10 @@ enum {
     BSK_T_THR_LIM = 16, /* current burst: on-time per thruster in half dyn steps (integer-valued)     */
     BSK_T_THR_T0 = 24,  /* RK4 tick at which the current burst started                               */
     BSK_T_THR_CNT = 25, /* thrMomentumDumping counter (control periods until the next burst)         */
-    BSK_NF_TAIL = 26,
+    /* FSW task order (bsk_config.fsw_lag): the wheel torque that the NEXT FSW tick will apply, i.e.
+     * rwMotorTorque(MRP_Feedback(att_guidance of the last tick)); zero after a reset (empty message) */
+    BSK_T_UPEND = 26,   /* BSK_MAX_RW fields                                                           */
+    BSK_NF_TAIL = 30,
 };
 
 typedef struct bsk_config {
@@ -84,6 +87,13 @@ typedef struct bsk_config {
     int32_t n_rw;      /* 0..BSK_MAX_RW                                                      */
     uint32_t flags;
     int32_t max_length; /* episode length in env steps (leoPowerAttitudeEnvironment.py:25)   */
+    /* 1 (default, reference order): mrpControlTask runs MRP_Feedback BEFORE attTrackingError
+     * (AddModelToTask order, …Simulator.py:484-486), so the controller consumes the att_guidance
+     * message of the PREVIOUS FSW tick: the wheel torque lags the guidance by one FSW period and
+     * the first tick after a reset commands zero (empty message).  0: guidance and control on the
+     * same tick (the order the module names suggest).                                           */
+    int32_t fsw_lag;
+    int32_t pad1_;
 
     /* gravity constants (leo_orbit.py:30; REQ_EARTH at …Simulator.py:146) */
     double mu;      /* m^3/s^2 */

@@ -527,6 +527,9 @@ int orc_step(const bsk_config* c, int n, double* state, int32_t* steps, int32_t*
         for (int f = 0; f < 12 + nrw; ++f) x[f] = S(f, e);
         for (int k = 0; k < 3; ++k) lext[k] = S(tail + BSK_T_LEXT + k, e);
         for (int i = 0; i < BSK_MAX_RW; ++i) u[i] = S(tail + BSK_T_UCMD + i, e);
+        /* torque the next FSW tick will command (fsw_lag; zero after a reset = empty att_guidance message) */
+        double upend[BSK_MAX_RW];
+        for (int i = 0; i < BSK_MAX_RW; ++i) upend[i] = S(tail + BSK_T_UPEND + i, e);
         double charge = S(tail + BSK_T_CHARGE, e), shadow = 1.0;
         int act = actions[e], tick = ticks[e];
         /* desaturation state (row f2) */
@@ -540,9 +543,20 @@ int orc_step(const bsk_config* c, int n, double* state, int32_t* steps, int32_t*
         for (int k = 0; k < 3; ++k) sun[k] = (c->sun_r0[k] + c->sun_v[k] * sim_time0) + c->sun_v[k] * (tick * c->dt);
         for (int j = 0; j < substeps; ++j, ++tick) {
             if (nrw > 0 && tick % c->fsw_every == 0) {
+                /* mrpControlTask runs MRP_Feedback, attTrackingError, rwMotorTorque in THAT order
+                   (AddModelToTask calls, …Simulator.py:484-486): the controller reads the att_guidance
+                   message the previous FSW tick wrote, then this tick's guidance overwrites it.  Holding
+                   the message or holding the torque it maps to is the same thing (MRP_Feedback without
+                   integral term and rwMotorTorque are pure functions of the message), so the slab keeps
+                   the 4 torques rather than the 12 message entries. */
                 att_guid g;
                 guidance(&ctx, x, act, &g);
-                control(&ctx, &g, u);
+                if (c->fsw_lag) {
+                    for (int i = 0; i < BSK_MAX_RW; ++i) u[i] = upend[i];
+                    control(&ctx, &g, upend);
+                } else {
+                    control(&ctx, &g, u);
+                }
                 if (desat && act == 2) {
                     /* rwDesatTask (…Simulator.py:452-478, 488-490; enabled in mode 2 only, :574-588) */
                     const double Tc = c->fsw_every * c->dt;
@@ -628,6 +642,7 @@ int orc_step(const bsk_config* c, int n, double* state, int32_t* steps, int32_t*
         if (reason) reason[e] = why;
         for (int f = 0; f < 12 + nrw; ++f) S(f, e) = x[f];
         for (int i = 0; i < BSK_MAX_RW; ++i) S(tail + BSK_T_UCMD + i, e) = u[i];
+        for (int i = 0; i < BSK_MAX_RW; ++i) S(tail + BSK_T_UPEND + i, e) = upend[i];
         S(tail + BSK_T_CHARGE, e) = charge;
         if (desat) {
             for (int i = 0; i < BSK_MAX_THR; ++i) { S(tail + BSK_T_THR_REM + i, e) = thr_rem[i]; S(tail + BSK_T_THR_LIM + i, e) = thr_lim[i]; }

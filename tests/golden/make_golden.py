@@ -139,6 +139,7 @@ class Model(object):
         self.grav = int(c["gravity_model"])
         self.dt = M(float(c["dt"]))
         self.fsw_every = int(c["fsw_every"])
+        self.fsw_lag = int(c["fsw_lag"])
         self.mu, self.req, self.j2 = M(float(c["mu"])), M(float(c["req"])), M(float(c["j2"]))
         self.I = [[M(float(c["inertia"][3 * i + j])) for j in range(3)] for i in range(3)]
         self.gs = [[M(float(c["gs"][i][k])) for k in range(3)] for i in range(self.n_rw)]
@@ -452,7 +453,14 @@ class Model(object):
         first_fsw = True
         for _ in range(substeps):
             if self.n_rw and env["ticks"] % self.fsw_every == 0:
-                u = self.control(self.guidance(x, action))
+                if self.fsw_lag:
+                    # the reference adds MRP_Feedback to mrpControlTask BEFORE attTrackingError: the controller
+                    # reads the att_guidance message as the previous FSW tick left it (all zeros = never
+                    # written, after a reset), then this tick's tracking error overwrites the message
+                    u = self.control(env["guid"])
+                    env["guid"] = self.guidance(x, action)
+                else:
+                    u = self.control(self.guidance(x, action))
                 if self.desat and action == 2:
                     self.desat_tick(env, x, first_fsw)
                 first_fsw = False
@@ -503,7 +511,8 @@ def run_case(name, n_rw, grav, n_envs, seed, schedule, cfg_edit=None, sh=None, i
     for e in range(n_envs):
         envs.append({"x": [M(float(ic[f, e])) for f in range(12 + n_rw)], "u": [M(0)] * n_rw,
                      "lext": [M(float(ic[t + k, e])) for k in range(3)], "charge": M(float(ic[t + 7, e])),
-                     "steps": 0, "ticks": 0, "thr_rem": [M(0)] * 8, "thr_lim": [M(0)] * 8, "thr_t0": 0, "thr_cnt": 0})
+                     "steps": 0, "ticks": 0, "thr_rem": [M(0)] * 8, "thr_lim": [M(0)] * 8, "thr_t0": 0, "thr_cnt": 0,
+                     "guid": ([M(0)] * 3, [M(0)] * 3, [M(0)] * 3, [M(0)] * 3)})   # att_guidance message, never written yet
     calls = []
     for ci, (actions, substeps) in enumerate(schedule):
         obs, rews, whys = [], [], []
@@ -518,6 +527,9 @@ def run_case(name, n_rw, grav, n_envs, seed, schedule, cfg_edit=None, sh=None, i
             state[t:t + 3, e] = [float(v) for v in env["lext"]]
             state[t + 3:t + 3 + n_rw, e] = [float(v) for v in env["u"]]
             state[t + 7, e] = float(env["charge"])
+            if model.fsw_lag and n_rw:
+                # the slab keeps the torque the held message maps to (BSK_T_UPEND), not the message itself
+                state[t + 26:t + 26 + n_rw, e] = [float(v) for v in model.control(env["guid"])]
             if model.desat:
                 state[t + 8:t + 16, e] = [float(v) for v in env["thr_rem"]]
                 state[t + 16:t + 24, e] = [float(v) for v in env["thr_lim"]]
@@ -556,6 +568,10 @@ def main():
         cfg.flags |= FLAG_POWER | FLAG_SUN_THIRD_BODY | FLAG_DRAG
         cfg.base_density, cfg.scale_height = 1e-9, 100e3
 
+    def nolag_edit(cfg):
+        """guidance and control on the same FSW tick (bsk_config.fsw_lag = 0)"""
+        cfg.fsw_lag = 0
+
     def desat_edit(cfg):
         from basilisk_env_amd._lib import FLAG_DESAT, FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY
         cfg.flags |= FLAG_POWER | FLAG_SUN_THIRD_BODY | FLAG_DRAG | FLAG_DESAT
@@ -578,6 +594,9 @@ def main():
         ("pm_norw", lambda: run_case("pm_norw", 0, GRAV_PM, n, 11, [(np.zeros(n, int), k) for k in (1, 9, 90, 900)])),
         # config-3 shape: J2 + 4-wheel pyramid; nadir/sun-point per env; u is held across the calls
         ("j2_rw4", lambda: run_case("j2_rw4", 4, GRAV_PM_J2, n, 12, [(np.arange(n) % 2, k) for k in (1, 9, 90, 900)])),
+        # the same with fsw_lag = 0 (first three checkpoints)
+        ("j2_rw4_nolag", lambda: run_case("j2_rw4_nolag", 4, GRAV_PM_J2, n, 12, [(np.arange(n) % 2, k) for k in (1, 9, 90)],
+                                          cfg_edit=nolag_edit)),
         # reference wiring: point mass + 3-wheel triad, mode switches between calls, odd call lengths
         ("pm_rw3_modes", lambda: run_case("pm_rw3_modes", 3, GRAV_PM, n, 13, sched)),
         # rows f1 / f3: power system (with penumbra crossings), Sun third body, facet drag; J2 + 3 wheels

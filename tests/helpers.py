@@ -7,6 +7,7 @@ def field_groups(n_rw):
     if n_rw:
         g["Omega"] = slice(12, 12 + n_rw)
         g["u"] = slice(12 + n_rw + 3, 12 + n_rw + 3 + n_rw)
+        g["u_pend"] = slice(12 + n_rw + 26, 12 + n_rw + 26 + n_rw)
     return g
 
 
@@ -30,6 +31,8 @@ def cfg_for_case(case):
     if case.get("cfg_edit") == "desat_edit":
         from basilisk_env_amd._lib import FLAG_DESAT
         cfg.flags |= FLAG_POWER | FLAG_SUN_THIRD_BODY | FLAG_DRAG | FLAG_DESAT
+    if case.get("cfg_edit") == "nolag_edit":
+        cfg.fsw_lag = 0
     if "sh_degree" in case:
         cfg.sh_degree = case["sh_degree"]
     return cfg

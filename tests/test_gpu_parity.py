@@ -7,7 +7,7 @@ import pytest
 from basilisk_env_amd._lib import GRAV_PM, GRAV_PM_J2
 from basilisk_env_amd.simulators.dynamics import BatchedPropagator, default_config
 from basilisk_env_amd.simulators.initial_conditions.batch import sample_ic_batch
-from helpers import max_group_err
+from helpers import cfg_for_case, max_group_err
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
@@ -24,10 +24,10 @@ def run_oracle(cfg, ic, schedule):
     return outs, steps, ticks
 
 
-@pytest.mark.parametrize("case_idx", [0, 1, 2])
-def test_hip_matches_golden(golden, case_idx):
-    case = golden["cases"][case_idx]
-    cfg = default_config(case["n_rw"], case["gravity_model"])
+@pytest.mark.parametrize("name", ["pm_norw", "j2_rw4", "j2_rw4_nolag", "pm_rw3_modes"])
+def test_hip_matches_golden(golden, name):
+    case = [c for c in golden["cases"] if c["name"] == name][0]
+    cfg = cfg_for_case(case)
     ic = np.array(case["ic"])
     prop = BatchedPropagator(cfg, ic.shape[1])
     prop.reset(ic)

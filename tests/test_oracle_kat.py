@@ -279,3 +279,38 @@ def test_friction_and_deadband_branches():
     x3 = np.concatenate([r0, v0, [0.9, 0, 0], np.zeros(3), np.zeros(3)])
     _, u = oracle.fsw(cfg2, x3, 1)
     assert abs(abs(u[0]) - cfg.u_max) < 1e-15
+
+
+def test_fsw_task_order_lag():
+    """mrpControlTask order (reference leoPowerAttitudeSimulator.py:484-486: MRP_Feedback, attTrackingError,
+    rwMotorTorque): with fsw_lag = 1 the torque commanded at FSW tick k is the one fsw_lag = 0 would have
+    commanded at tick k - fsw_every from the state of THAT tick; the first tick after a reset commands zero."""
+    n, n_rw = 6, 3
+    ic = sample_ic_batch(n, n_rw, seed=21)
+    act = np.array([0, 1, 2, 0, 1, 0], np.int32)
+    t = 12 + n_rw
+    lag, nolag = default_config(n_rw, GRAV_PM_J2), default_config(n_rw, GRAV_PM_J2)
+    assert lag.fsw_lag == 1
+    nolag.fsw_lag = 0
+    # first FSW period: zero torque, and the pending torque is exactly what the un-lagged chain applies now
+    s1, _ = run(lag, ic, act, 1)
+    s0, _ = run(nolag, ic, act, 1)
+    assert np.all(s1[t + 3:t + 3 + n_rw] == 0.0)
+    assert np.abs(s0[t + 3:t + 3 + n_rw]).max() > 0.0
+    assert np.array_equal(s1[t + 26:t + 26 + n_rw], s0[t + 3:t + 3 + n_rw])
+    # second period: the held torque becomes the command, bit for bit, and a new one is pending
+    s1b, _ = run(lag, ic, act, 11)
+    assert np.array_equal(s1b[t + 3:t + 3 + n_rw], s1[t + 26:t + 26 + n_rw])
+    assert not np.array_equal(s1b[t + 26:t + 26 + n_rw], s1[t + 26:t + 26 + n_rw])
+    # a wheel-free torque-free first second: lagged hub is untouched by the controller (only L_ext acts)
+    free = default_config(n_rw, GRAV_PM_J2)
+    free.K = free.P = 0.0
+    sf, _ = run(free, ic, act, 10)
+    s1c, _ = run(lag, ic, act, 10)
+    assert np.array_equal(sf[:12 + n_rw], s1c[:12 + n_rw])
+    # split calls keep the pending torque in the slab: 11 = 4 + 7
+    st = ic.copy()
+    steps, ticks = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    oracle.step(lag, st, steps, ticks, act, 4)
+    oracle.step(lag, st, steps, ticks, act, 7)
+    assert np.array_equal(st, s1b)
