@@ -65,7 +65,7 @@ class BskConfig(C.Structure):
 EXPORTS = [
     "bsk_default_config", "bsk_create", "bsk_destroy", "bsk_set_gravity_sh", "bsk_reset", "bsk_step",
     "bsk_step_device", "bsk_get_obs", "bsk_get_obs_device", "bsk_get_batch_stats", "bsk_n_fields",
-    "bsk_get_state", "bsk_set_state", "bsk_get_counters", "bsk_set_ic_pool", "bsk_sample_ic_pool", "bsk_reset_from_pool", "bsk_get_terminal_obs", "bsk_set_sim_time", "bsk_sync",
+    "bsk_get_state", "bsk_set_state", "bsk_get_counters", "bsk_set_counters", "bsk_set_ic_pool", "bsk_sample_ic_pool", "bsk_reset_from_pool", "bsk_get_ic_pool", "bsk_get_terminal_obs", "bsk_set_sim_time", "bsk_sync",
     "bsk_profile_begin", "bsk_profile_set_stride", "bsk_profile_end", "bsk_kernel_info", "bsk_last_error", "bsk_version",
 ]
 
@@ -132,10 +132,12 @@ def load():
     lib.bsk_get_state.argtypes = [vp, vp]
     lib.bsk_set_state.argtypes = [vp, vp]
     lib.bsk_get_counters.argtypes = [vp, vp, vp]
+    lib.bsk_set_counters.argtypes = [vp, vp, vp]
     lib.bsk_set_ic_pool.argtypes = [vp, C.c_int, vp]
     lib.bsk_get_terminal_obs.argtypes = [vp, vp, vp]
     lib.bsk_sample_ic_pool.argtypes = [vp, C.c_int, C.c_uint64]
     lib.bsk_reset_from_pool.argtypes = [vp, vp]
+    lib.bsk_get_ic_pool.argtypes = [vp, vp]
     lib.bsk_set_sim_time.argtypes = [vp, C.c_double]
     lib.bsk_sync.argtypes = [vp]
     lib.bsk_profile_begin.argtypes = [vp, C.c_int]

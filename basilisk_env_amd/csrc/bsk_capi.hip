@@ -353,6 +353,7 @@ struct bsk_handle {
     // masked-reset staging
     double* d_ic_stage = nullptr;
     int* d_idx_stage = nullptr;
+    unsigned char* d_mask_stage = nullptr;
     size_t stage_cap = 0;
     double* d_sh_tab = nullptr;    // scalar-load stream (form 1)
     double* d_sh_tab4 = nullptr;   // DPP-broadcast stream (forms 4 and 5, default)
@@ -654,7 +655,7 @@ void bsk_destroy(bsk_handle* h) {
     for (hipEvent_t ev : h->ev_warm)
         if (ev) (void)hipEventDestroy(ev);
     void* bufs[] = {h->d_state, h->d_cnt, h->d_act, h->d_obs, h->d_reward, h->d_done_mask, h->d_reason,
-                    h->d_wave_reward, h->d_stat_sum, h->d_stat_done, h->d_ic_stage, h->d_idx_stage, h->d_cold, h->d_sh_tab, h->d_sh_tab4, h->d_pool, h->d_term_obs, h->d_episodes};
+                    h->d_wave_reward, h->d_stat_sum, h->d_stat_done, h->d_ic_stage, h->d_idx_stage, h->d_mask_stage, h->d_cold, h->d_sh_tab, h->d_sh_tab4, h->d_pool, h->d_term_obs, h->d_episodes};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -814,6 +815,20 @@ int bsk_get_counters(bsk_handle* h, int32_t* steps, int32_t* ticks) {
     return BSK_OK;
 }
 
+int bsk_set_counters(bsk_handle* h, const int32_t* steps, const int32_t* ticks) {
+    if (!h || !steps || !ticks) return fail(BSK_EINVAL, "handle/steps/ticks is NULL");
+    DeviceGuard guard(h->device);
+    std::vector<int2> tmp(h->n);
+    for (int i = 0; i < h->n; ++i) {
+        if (steps[i] < 0 || steps[i] > 0xFFFFF || ticks[i] < 0) return fail(BSK_EINVAL, "steps must be in 0..2^20-1 and ticks >= 0");
+        tmp[i].x = steps[i] | ((ticks[i] % h->cfg.fsw_every) << 20);
+        tmp[i].y = ticks[i];
+    }
+    HIP_TRY(hipMemcpyAsync(h->d_cnt, tmp.data(), (size_t)h->n * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return BSK_OK;
+}
+
 int bsk_set_ic_pool(bsk_handle* h, int n_pool, const double* ic_pool) {
     if (!h || !ic_pool) return fail(BSK_EINVAL, "handle/ic_pool is NULL");
     if (!(h->cfg.flags & BSK_FLAG_AUTO_RESET)) return fail(BSK_EINVAL, "handle was not created with BSK_FLAG_AUTO_RESET");
@@ -862,15 +877,22 @@ int bsk_reset_from_pool(bsk_handle* h, const uint8_t* mask) {
     DeviceGuard guard(h->device);
     unsigned char* d_mask = nullptr;
     if (mask) {
-        HIP_TRY(hipMalloc(&d_mask, (size_t)h->n));
+        if (!h->d_mask_stage) HIP_TRY(hipMalloc(&h->d_mask_stage, (size_t)h->stride));   // kept for the handle's lifetime
+        d_mask = h->d_mask_stage;
         HIP_TRY(hipMemcpyAsync(d_mask, mask, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
     }
-    hipError_t e = bsk::launch_reset_from_pool(h->d_state, h->stride, h->nf, h->d_pool, h->n_pool, d_mask, h->n, h->d_cnt,
-                                               h->d_episodes, h->stream);
-    hipError_t e2 = hipStreamSynchronize(h->stream);
-    if (d_mask) (void)hipFree(d_mask);
-    HIP_TRY(e);
-    HIP_TRY(e2);
+    HIP_TRY(bsk::launch_reset_from_pool(h->d_state, h->stride, h->nf, h->d_pool, h->n_pool, d_mask, h->n, h->d_cnt,
+                                        h->d_episodes, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return BSK_OK;
+}
+
+int bsk_get_ic_pool(bsk_handle* h, double* ic_pool) {
+    if (!h || !ic_pool) return fail(BSK_EINVAL, "handle/ic_pool is NULL");
+    if (h->n_pool == 0) return fail(BSK_EINVAL, "no IC pool staged (bsk_set_ic_pool / bsk_sample_ic_pool)");
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(ic_pool, h->d_pool, (size_t)h->nf * h->n_pool * sizeof(double), hipMemcpyDeviceToHost));
     return BSK_OK;
 }
 

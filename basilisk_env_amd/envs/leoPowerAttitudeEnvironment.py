@@ -140,8 +140,8 @@ class leoPowerAttEnv(spaces.Env):
 
     def _drop_simulator(self):
         sim, self.simulator = self.simulator, None
-        if sim is not None and hasattr(sim, "propagator"):
-            sim.propagator.close()
+        if sim is not None and hasattr(sim, "release"):
+            sim.release()      # the device handle is parked and re-used by the next simulator
 
     def _render(self, mode='human', close=False):
         return
@@ -166,6 +166,7 @@ class leoPowerAttEnv(spaces.Env):
 
     def close(self):
         self._drop_simulator()
+        leoPowerAttitudeSimulator.drain_idle_propagators()
 
 
 

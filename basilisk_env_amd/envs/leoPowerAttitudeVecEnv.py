@@ -15,10 +15,30 @@ from ..simulators.dynamics.config import default_config
 from ..simulators.dynamics.propagator import BatchedPropagator
 from ..simulators.initial_conditions.batch import sample_ic_batch
 
-_EMPTY = {}
 
 
-class LeoPowerAttVecEnv(object):
+def _vec_env_base():
+    """stable-baselines' abstract ``VecEnv`` when one is installed (so that ``isinstance`` checks in its
+    wrappers hold), else ``object``: the class below implements the whole protocol itself either way."""
+    import importlib
+    for mod in ("stable_baselines.common.vec_env", "stable_baselines3.common.vec_env"):
+        try:
+            return importlib.import_module(mod).VecEnv
+        except Exception:
+            continue
+    return object
+
+
+_Base = _vec_env_base()
+
+
+def pool_slot(env, episode, n_pool):
+    """IC-pool slot the device-side reset picks for ``env`` after ``episode`` finished episodes
+    (include/bskgpu.h: bsk_set_ic_pool)."""
+    return ((int(env) * 2654435761 + int(episode) * 40503 + 12345) & 0xFFFFFFFF) % int(n_pool)
+
+
+class LeoPowerAttVecEnv(_Base):
     def __init__(self, num_envs, n_rw=4, gravity_model=GRAV_PM_J2, step_duration=180., dynRate=0.1, fswRate=1.0,
                  seed=0, device=0, cfg=None, auto_reset=True, propagator_factory=None, power=True, sun_third_body=True, drag=True, desat=True,
                  device_reset_pool=0, device_sampler=False):
@@ -26,6 +46,8 @@ class LeoPowerAttVecEnv(object):
         the step kernel reset finished envs itself (no host round trip at episode boundaries); 0 keeps
         the host-side masked reset with freshly sampled ICs.  With ``device_sampler`` the pool itself is
         drawn on the GPU (Philox4x32-10 keyed by ``seed``) and ``reset()`` restarts from it on the device."""
+        if _Base is not object:
+            _Base.__init__(self, int(num_envs), spaces.Box(-1e16, 1e16, shape=(5, 1)), spaces.Discrete(3))
         self.num_envs = int(num_envs)
         self.observation_space = spaces.Box(-1e16, 1e16, shape=(5, 1))
         self.action_space = spaces.Discrete(3)
@@ -63,10 +85,13 @@ class LeoPowerAttVecEnv(object):
             self.device_sampler = bool(device_sampler)
             if self.device_sampler:
                 self.propagator.sample_ic_pool(n_pool, seed)
+                self._pool = self.propagator.get_ic_pool()      # host mirror: reset_init() replays device-side resets
             else:
-                self.propagator.set_ic_pool(sample_ic_batch(n_pool, self.n_rw, rng=self._rng))
+                self._pool = sample_ic_batch(n_pool, self.n_rw, rng=self._rng)
+                self.propagator.set_ic_pool(self._pool)
         else:
             self.device_sampler = False
+            self._pool = None
         self.episode_returns = np.zeros(self.num_envs)
         self.episode_lengths = np.zeros(self.num_envs, dtype=np.int64)
 
@@ -97,6 +122,7 @@ class LeoPowerAttVecEnv(object):
         else:
             self._ic = sample_ic_batch(self.num_envs, self.n_rw, rng=self._rng) if ic is None else np.array(ic, dtype=np.float64)
             self.propagator.reset(self._ic)
+        self._actions = None
         self.episode_returns[:] = 0
         self.episode_lengths[:] = 0
         return self._initial_obs(self._ic).T.reshape(self.num_envs, 5, 1)
@@ -113,15 +139,20 @@ class LeoPowerAttVecEnv(object):
         self.propagator.step(a, self.substeps)
 
     def step_wait(self):
+        if self._actions is None:
+            raise RuntimeError("step_wait() without a pending step_async()")
+        self._actions = None
         obs, rew, done, why = self.propagator.get_obs()
         self.episode_returns += rew
-        infos = [_EMPTY] * self.num_envs
+        infos = [{} for _ in range(self.num_envs)]     # one fresh dict per env: wrappers write into them
         obs_out = obs.T.reshape(self.num_envs, 5, 1).copy()
         idx = np.flatnonzero(done)
         if idx.size and self.device_reset:
             # the kernel already reset these envs and wrote their new first observation into obs
-            term, _ = self.propagator.get_terminal_obs()
+            term, episodes = self.propagator.get_terminal_obs()
             for i in idx:
+                # the new episode's initial conditions, for reset_init(): the slot rule of the device-side reset
+                self._ic[:, i] = self._pool[:, pool_slot(i, episodes[i] - 1, self._pool.shape[1])]
                 infos[i] = {
                     "episode": {"r": float(self.episode_returns[i]), "l": int(self.episode_lengths[i])},
                     "terminal_observation": term[:, i].reshape(5, 1).copy(),
@@ -157,19 +188,39 @@ class LeoPowerAttVecEnv(object):
     def close(self):
         self.propagator.close()
 
+    def _n_indexed(self, indices):
+        if indices is None:
+            return self.num_envs
+        idx = np.atleast_1d(np.asarray(indices, dtype=np.int64))
+        if idx.size and (idx.min() < -self.num_envs or idx.max() >= self.num_envs):
+            raise IndexError("env index out of range")
+        return int(idx.size)
+
     def get_attr(self, attr_name, indices=None):
-        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
-        return [getattr(self, attr_name)] * n
+        """One value per selected env.  The envs share their constants (one batch, one config), so every entry
+        is the batch's own attribute."""
+        return [getattr(self, attr_name) for _ in range(self._n_indexed(indices))]
 
     def set_attr(self, attr_name, value, indices=None):
+        """Attributes belong to the batch: setting one for a strict subset of the envs cannot be honoured."""
+        if self._n_indexed(indices) != self.num_envs:
+            raise ValueError("the envs of a LeoPowerAttVecEnv share their attributes; set_attr needs indices=None")
         setattr(self, attr_name, value)
 
     def env_method(self, method_name, *args, indices=None, **kwargs):
-        return [getattr(self, method_name)(*args, **kwargs)]
+        """Calls the batch's method once and returns the result once per selected env."""
+        n = self._n_indexed(indices)
+        res = getattr(self, method_name)(*args, **kwargs)
+        return [res for _ in range(n)]
 
     def env_is_wrapped(self, wrapper_class, indices=None):
-        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
-        return [False] * n
+        return [False] * self._n_indexed(indices)
+
+    def get_images(self):
+        return [None] * self.num_envs
+
+    def render(self, mode="human"):
+        return None
 
     # ------------------------------------------------------------------ extras
     def get_state(self):

@@ -122,6 +122,14 @@ class BatchedPropagator(object):
         check(self._lib.bsk_get_counters(self._handle(), steps.ctypes.data, ticks.ctypes.data))
         return steps, ticks
 
+    def set_counters(self, steps, ticks):
+        """Restore the per-env counters (with ``set_state``: a full checkpoint of the batch)."""
+        steps = np.ascontiguousarray(steps, dtype=np.int32)
+        ticks = np.ascontiguousarray(ticks, dtype=np.int32)
+        if steps.shape != (self.n_envs,) or ticks.shape != (self.n_envs,):
+            raise ValueError("steps and ticks must have shape (%d,)" % self.n_envs)
+        check(self._lib.bsk_set_counters(self._handle(), steps.ctypes.data, ticks.ctypes.data))
+
     # ------------------------------------------------------------------ stepping
     def step(self, actions, substeps):
         a = np.ascontiguousarray(actions, dtype=np.int32)
@@ -161,16 +169,26 @@ class BatchedPropagator(object):
             "stride": st.value,
         }
 
+    def get_ic_pool(self):
+        """Host copy [n_fields, n_pool] of the staged pool (as set or as sampled on the device)."""
+        if not getattr(self, "_n_pool", 0):
+            raise RuntimeError("no IC pool staged")
+        pool = np.empty((self.n_fields, self._n_pool), dtype=np.float64)
+        check(self._lib.bsk_get_ic_pool(self._handle(), pool.ctypes.data))
+        return pool
+
     def set_ic_pool(self, ic_pool):
         """Stage initial conditions [n_fields, n_pool] for device-side auto-reset (FLAG_AUTO_RESET)."""
         pool = np.ascontiguousarray(ic_pool, dtype=np.float64)
         if pool.ndim != 2 or pool.shape[0] != self.n_fields:
             raise ValueError("ic_pool must have shape (%d, n_pool)" % self.n_fields)
         check(self._lib.bsk_set_ic_pool(self._handle(), pool.shape[1], pool.ctypes.data))
+        self._n_pool = pool.shape[1]
 
     def sample_ic_pool(self, n_pool, seed):
         """Draw ``n_pool`` initial conditions on the device (Philox4x32-10, reference distributions)."""
         check(self._lib.bsk_sample_ic_pool(self._handle(), int(n_pool), int(seed) & 0xFFFFFFFFFFFFFFFF))
+        self._n_pool = int(n_pool)
 
     def reset_from_pool(self, mask=None):
         """(Re)start all (or the masked) envs from the staged pool, entirely on the device."""

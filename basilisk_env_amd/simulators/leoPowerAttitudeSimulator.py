@@ -33,6 +33,45 @@ def ic_dict_to_block(ic, n_rw):
                    charge=[float(ic.get("storedCharge_Init", 0.0))])
 
 
+# The reference deletes and rebuilds its simulator on every reset (envs/leoPowerAttitudeEnvironment.py:184-185).
+# A propagator handle is 11 device allocations and a stream, none of which depend on the initial conditions, so
+# released handles wait here and the next simulator with the same configuration takes one over (reset = upload
+# of one IC block).  Keyed by the full bsk_config bytes, batch size, device and factory; a few entries at most.
+_IDLE_PROPAGATORS = {}
+_IDLE_MAX = 4
+
+
+def _prop_key(cfg, n_envs, device, factory):
+    import ctypes
+    return (ctypes.string_at(ctypes.addressof(cfg), ctypes.sizeof(cfg)), int(n_envs), int(device), factory)
+
+
+def acquire_propagator(cfg, n_envs, device, factory):
+    key = _prop_key(cfg, n_envs, device, factory)
+    idle = _IDLE_PROPAGATORS.get(key)
+    if idle:
+        return idle.pop(), key
+    return factory(cfg, n_envs, device=device), key
+
+
+def release_propagator(prop, key):
+    """Park a propagator for re-use, or close it when enough are parked already."""
+    if prop is None:
+        return
+    if sum(len(v) for v in _IDLE_PROPAGATORS.values()) >= _IDLE_MAX:
+        prop.close()
+        return
+    _IDLE_PROPAGATORS.setdefault(key, []).append(prop)
+
+
+def drain_idle_propagators():
+    """Close every parked propagator (process exit, tests)."""
+    for v in _IDLE_PROPAGATORS.values():
+        while v:
+            v.pop().close()
+    _IDLE_PROPAGATORS.clear()
+
+
 class LEOPowerAttitudeSimulator(object):
     """Drop-in for the reference simulator class; see the module docstring for the surface.
 
@@ -97,7 +136,7 @@ class LEOPowerAttitudeSimulator(object):
         self.cfg = cfg
 
         factory = propagator_factory or BatchedPropagator
-        self.propagator = factory(cfg, 1, device=device)
+        self.propagator, self._prop_key = acquire_propagator(cfg, 1, device, factory)
         self.propagator.reset(ic_dict_to_block(ic, n_rw))
 
         # initial observation exactly as the reference fills it (:348-351): |sigma_BN| (not
@@ -162,6 +201,12 @@ class LEOPowerAttitudeSimulator(object):
         if np.linalg.norm(st[0:3, 0]) < (_config.REQ_EARTH_KM / 1000.):
             self.sim_over = True
         return self.obs, self.sim_states, self.sim_over
+
+    def release(self):
+        """Hand the propagator back for the next simulator (the env calls this where the reference does
+        ``del self.simulator``); the object must not be stepped afterwards."""
+        prop, self.propagator = self.propagator, None
+        release_propagator(prop, self._prop_key)
 
     def close_gracefully(self):
         """The reference unloads SPICE kernels here (:646-652); this build has none to unload.

@@ -208,6 +208,9 @@ int bsk_get_state(bsk_handle* h, double* state);
 int bsk_set_state(bsk_handle* h, const double* state);
 /* per-env counters: env steps and RK4 ticks since reset, int32[n_envs] each (may be NULL) */
 int bsk_get_counters(bsk_handle* h, int32_t* steps, int32_t* ticks);
+/* Restore the per-env counters (checkpoint / resume together with bsk_set_state): steps in 0..2^20-1,
+ * ticks >= 0, int32[n_envs] each, both required.  The FSW phase follows as ticks mod fsw_every. */
+int bsk_set_counters(bsk_handle* h, const int32_t* steps, const int32_t* ticks);
 
 /* Device-side auto-reset (BSK_FLAG_AUTO_RESET; reference reset semantics,
  * envs/leoPowerAttitudeEnvironment.py:172-191, without the host round trip).  Stage a pool of
@@ -226,6 +229,9 @@ int bsk_set_ic_pool(bsk_handle* h, int n_pool, const double* ic_pool);
  * or the masked envs from the pool with the slot rule above, without any host data. */
 int bsk_sample_ic_pool(bsk_handle* h, int n_pool, uint64_t seed);
 int bsk_reset_from_pool(bsk_handle* h, const uint8_t* mask);
+/* Host copy of the staged pool, SoA [n_fields][n_pool] (n_pool as staged; the caller sizes the buffer):
+ * lets the host replay a device-side reset (reset_init, leoPowerAttitudeEnvironment.py:202-216). */
+int bsk_get_ic_pool(bsk_handle* h, double* ic_pool);
 /* terminal observations f64[5][n_envs] (valid for envs whose done flag is set) and per-env
  * finished-episode counts int32[n_envs]; either pointer may be NULL.  Synchronises. */
 int bsk_get_terminal_obs(bsk_handle* h, double* term_obs, int32_t* episodes);

@@ -55,6 +55,10 @@ class OraclePropagator(object):
     def get_counters(self):
         return self.steps.copy(), self.ticks.copy()
 
+    def set_counters(self, steps, ticks):
+        self.steps[:] = steps
+        self.ticks[:] = ticks
+
     def step(self, actions, substeps):
         self._out = oracle.step(self.cfg, self.state, self.steps, self.ticks, np.asarray(actions, np.int32), substeps,
                                 sim_time0=self._t0, cbar=self._cbar, sbar=self._sbar)
@@ -67,6 +71,9 @@ class OraclePropagator(object):
     def sample_ic_pool(self, n_pool, seed):
         from _philox_ref import sample_pool
         self._pool = sample_pool(n_pool, self.n_rw, seed & 0xFFFFFFFFFFFFFFFF, mu=self.cfg.mu)
+
+    def get_ic_pool(self):
+        return self._pool.copy()
 
     def reset_from_pool(self, mask=None):
         n_pool = self._pool.shape[1]

@@ -18,8 +18,7 @@ def _load_bench():
 
 def test_defaults_and_constants(monkeypatch):
     b = _load_bench()
-    monkeypatch.setattr(sys, "argv", ["bench.py"])
-    a = b.parse()
+    a = b.parse([])
     assert a.gpus == 1 and a.envs == 65536 and a.substeps == 1 and a.gravity == "j2" and a.scenario == "bare"
     assert a.steps >= 1000 and a.warmup >= 50
     assert b.BYTES_PER_ENV_STEP == 340.0 and b.HBM_PEAK_GBS == 8000.0
@@ -52,6 +51,118 @@ def test_world_size_must_match_gpus():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                          timeout=300, env=env)
     assert res.returncode != 0 and "torch.distributed.run" in (res.stderr + res.stdout)
+
+
+class _FakeProp(object):
+    """Records what bench.py's timing helpers ask of a propagator."""
+
+    def __init__(self):
+        self.log = []
+
+    def step_device(self, ptr, substeps):
+        self.log.append("step")
+
+    def sync(self):
+        self.log.append("sync")
+
+    def profile_begin(self, capacity, stride=1):
+        self.log.append("profile_begin(%d,%d)" % (capacity, stride))
+
+    def profile_end(self):
+        self.log.append("profile_end")
+        return 0.007, self.log.count("step")
+
+
+def test_timed_region_is_unstamped_and_counts_exactly_k_steps():
+    """`value` must not depend on dispatch stamping: the wall-timed loop arms no events and holds exactly K
+    launches between its two barrier + synchronise pairs; kernel_us comes from a separate stamped pass."""
+    b = _load_bench()
+    p = _FakeProp()
+    marks = []
+    el = b.timed_run(p, 0, 1, 20, 5, lambda: marks.append(("barrier", len(p.log))), lambda: marks.append(("devsync", len(p.log))))
+    assert el >= 0 and not any(x.startswith("profile") for x in p.log)
+    assert p.log.count("step") == 25
+    # barrier, devsync | 20 steps | devsync, barrier  -- nothing else inside the timed window
+    (b0, i0), (s0, j0), (s1, j1), (b1, i1) = marks
+    assert (b0, s0, s1, b1) == ("barrier", "devsync", "devsync", "barrier") and i0 == j0 and j1 - j0 == 20 and i1 == j1
+    assert p.log[j0:j1] == ["step"] * 20
+    q = _FakeProp()
+    ms, n = b.kernel_time(q, 0, 1, 7)
+    assert q.log[:2] == ["sync", "profile_begin(7,1)"] and q.log.count("step") == 7 and q.log[-1] == "profile_end"
+
+
+def test_self_launch_composes_the_launcher_as_a_child_and_relays():
+    """`python bench.py --gpus N` as typed: torch.distributed.run is started as a CHILD process (never exec),
+    with the original arguments, rendezvous on 127.0.0.1, and its output / exit code are passed through."""
+    import io
+    b = _load_bench()
+    seen = {}
+
+    class FakeProc(object):
+        stdout = io.StringIO("warning line\n{\"metric\": \"m\"}\n")
+
+        def wait(self):
+            return 7
+
+    def fake_popen(cmd, stdout=None, text=None, env=None):
+        seen.update(cmd=cmd, env=env, stdout=stdout)
+        return FakeProc()
+
+    os.environ["RANK"] = "3"          # stale variables of an outer launcher must not leak into the child
+    try:
+        out = io.StringIO()
+        rc = b.self_launch(4, ["--gpus", "4", "--steps", "20"], popen=fake_popen, out=out)
+    finally:
+        del os.environ["RANK"]
+    assert rc == 7 and out.getvalue().endswith('{"metric": "m"}\n')
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-5:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "20"]
+    assert "RANK" not in seen["env"] and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert seen["stdout"] == subprocess.PIPE
+
+
+def test_parent_of_a_self_launch_never_touches_torch_or_hip():
+    """The parent must not initialise the GPU before it spawns the launcher: importing bench.py and parsing
+    arguments pulls in neither torch nor the HIP library."""
+    code = ("import sys, importlib.util; spec = importlib.util.spec_from_file_location('b', %r); "
+            "m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m); m.parse(['--gpus', '8']); "
+            "bad = [k for k in sys.modules if k == 'torch' or k.startswith('basilisk_env_amd')]; "
+            "assert not bad, bad" % os.path.join(ROOT, "bench.py"))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+
+
+def test_gpus_2_as_typed_reaches_the_ranks_and_relays_their_failure():
+    """End to end on this GPU-less box: `python bench.py --gpus 2` starts two ranks, each refuses to run without a
+    HIP device, and the parent exits non-zero without fabricating a JSON line."""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode != 0 and "no HIP device" in (res.stderr + res.stdout)
+    assert not any(line.startswith("{") for line in res.stdout.splitlines())
+
+
+def test_rooflines():
+    b = _load_bench()
+    info = {"name": "k", "vgprs": 200, "lds_bytes": 0, "block": 64, "grid": 1024}
+    h = b.hbm_roofline(65536, 7e-6, info, 25.9e6, "profiles/x", 64)
+    assert h["bound"] == "hbm" and abs(h["achieved"] - 340 * 65536 / 7e-6 / 1e9) < 1e-6
+    assert abs(h["frac"] - h["achieved"] / 8000.0) < 1e-12 and abs(h["frac_of_copy_ceiling"] - h["achieved"] / 6290.0) < 1e-12
+    mix, src = b.isa_mix("bare")
+    f = b.fp64_roofline("bare", 65536.0 * 1800, 1.9e-3, info)
+    assert f["bound"] == "fp64" and f["peak"] == 78.6 and f["unit"] == "TFLOP/s"
+    if mix:      # executed flops from the committed counter pass: can never exceed the peak
+        assert src.startswith("profiles/") and 0.0 < f["frac"] < 1.0
+        assert abs(f["achieved"] - (2 * mix["fma"] + mix["mul"] + mix["add"] + mix.get("trans", 0)) * 65536 * 1800 / 1.9e-3 / 1e12) < 1e-9
+    else:
+        assert f["achieved"] is None
+    assert b.fp64_roofline("nope", 1.0, 1.0, info)["achieved"] is None
 
 
 def test_committed_bench_line_has_the_contract_keys():

@@ -310,3 +310,52 @@ def test_large_ragged_batch_block256():
     assert abs(rsum - rew.sum()) < 1e-8 and ndone == int(done.sum())
     assert np.isfinite(st).all()
     prop.close()
+
+
+def test_step_counter_saturates_below_the_phase_bits():
+    """The packed counter word keeps the env-step count in its low 20 bits and the FSW phase above them: a batch
+    stepped past 2^20 env steps without a reset keeps its FSW schedule (the count saturates at 2^20 - 1)."""
+    n, n_rw = 130, 4
+    cfg = default_config(n_rw, GRAV_PM_J2)
+    ic = sample_ic_batch(n, n_rw, seed=31)
+    act = (np.arange(n) % 3).astype(np.int32)
+    prop = BatchedPropagator(cfg, n)
+    prop.reset(ic)
+    start = 0xFFFFF - 3
+    prop.set_counters(np.full(n, start, np.int32), np.full(n, 7, np.int32))
+    st = ic.copy()
+    steps, ticks = np.full(n, start, np.int32), np.full(n, 7, np.int32)
+    for k in range(25):                                   # K = 1: crosses 2^20 env steps and three FSW ticks
+        oracle.step(cfg, st, steps, ticks, act, 1)
+        prop.step(act, 1)
+    errs = max_group_err(prop.get_state(), st, n_rw)
+    assert max(errs.values()) < TOL, errs
+    assert np.abs(st[12 + n_rw + 3:12 + n_rw + 7]).max() > 0          # the FSW chain did command torques
+    gs, gt = prop.get_counters()
+    assert (gs == 0xFFFFF).all() and (gt == 7 + 25).all()
+    assert (prop.get_obs()[3] & 1).all()                  # DONE_LENGTH stays set, it does not wrap around
+    prop.close()
+
+
+def test_checkpoint_restore_is_bit_exact():
+    """get_state + get_counters -> set_state + set_counters resumes a batch bit for bit (mid FSW period, with a
+    pending wheel torque in the slab)."""
+    n, n_rw = 200, 3
+    cfg = default_config(n_rw, GRAV_PM)
+    ic = sample_ic_batch(n, n_rw, seed=32)
+    act = (np.arange(n) % 3).astype(np.int32)
+    a = BatchedPropagator(cfg, n)
+    a.reset(ic)
+    a.step(act, 13)
+    snap_state, (snap_steps, snap_ticks) = a.get_state(), a.get_counters()
+    a.step(act, 17)
+    b = BatchedPropagator(cfg, n)
+    b.set_state(snap_state)
+    b.set_counters(snap_steps, snap_ticks)
+    b.step(act, 17)
+    assert np.array_equal(a.get_state(), b.get_state()) and np.array_equal(a.get_obs()[0], b.get_obs()[0])
+    assert np.array_equal(a.get_counters()[0], b.get_counters()[0]) and np.array_equal(a.get_counters()[1], b.get_counters()[1])
+    with pytest.raises(Exception):
+        b.set_counters(np.full(n, 1 << 20, np.int32), snap_ticks)
+    a.close()
+    b.close()

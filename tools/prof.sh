@@ -2,14 +2,13 @@
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root).
 # Each counter set gets its own pass; --pmc is never combined with tracing other than kernel-trace.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r01}
+TAG=${1:-r02}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L > $O/counters_list.txt 2>&1
 B="python3 $R/bench.py --no-cpu-baseline --no-extra"
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_65k -- $B --stamp-every-launch > $O/kt_65k.log 2>&1 && echo kt_65k ok
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_65k_default -- $B > $O/kt_65k_default.log 2>&1 && echo kt_65k_default ok
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_65k -- $B > $O/kt_65k.log 2>&1 && echo kt_65k ok
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_65k -- $B --steps 50 > $O/fetch_65k.log 2>&1 && echo fetch_65k ok
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_65k -- $B --steps 50 > $O/write_65k.log 2>&1 && echo write_65k ok
 timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $O/sq_65k -- $B --steps 50 > $O/sq_65k.log 2>&1 && echo sq_65k ok
