@@ -942,7 +942,7 @@ int bsk_profile_set_stride(bsk_handle* h, int stride) {
     return BSK_OK;
 }
 
-int bsk_profile_end(bsk_handle* h, double* mean_kernel_ms, int* n_launches) {
+int bsk_profile_end_samples(bsk_handle* h, double* mean_kernel_ms, int* n_launches, float* samples_ms, int cap) {
     if (!h) return fail(BSK_EINVAL, "handle is NULL");
     DeviceGuard guard(h->device);
     h->prof = false;
@@ -953,11 +953,16 @@ int bsk_profile_end(bsk_handle* h, double* mean_kernel_ms, int* n_launches) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, h->ev[2 * k], h->ev[2 * k + 1]));
         tot += ms;
+        if (samples_ms && k < cap) samples_ms[k] = ms;
     }
     if (mean_kernel_ms) *mean_kernel_ms = n ? tot / n : 0.0;
     if (n_launches) *n_launches = n;
     h->ev_used = 0;
     return BSK_OK;
+}
+
+int bsk_profile_end(bsk_handle* h, double* mean_kernel_ms, int* n_launches) {
+    return bsk_profile_end_samples(h, mean_kernel_ms, n_launches, nullptr, 0);
 }
 
 int bsk_kernel_info(bsk_handle* h, char* name, int name_cap, int* vgprs, int* lds_bytes, int* block, int* grid) {

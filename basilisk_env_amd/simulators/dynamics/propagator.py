@@ -223,6 +223,13 @@ class BatchedPropagator(object):
         check(self._lib.bsk_profile_end(self._handle(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def profile_end_samples(self, cap=4096):
+        """-> (mean kernel ms, individual kernel durations [ms] as a float32 array)."""
+        ms, n = C.c_double(), C.c_int()
+        buf = np.zeros(cap, dtype=np.float32)
+        check(self._lib.bsk_profile_end_samples(self._handle(), C.byref(ms), C.byref(n), buf.ctypes.data, cap))
+        return ms.value, buf[:min(cap, n.value)].copy()
+
     def kernel_info(self):
         name = C.create_string_buffer(128)
         v, l, b, g = C.c_int(), C.c_int(), C.c_int(), C.c_int()

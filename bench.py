@@ -80,7 +80,7 @@ def launcher_command(gpus, argv, port):
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
-def self_launch(gpus, argv, popen=subprocess.Popen, out=None):
+def self_launch(gpus, argv, popen=subprocess.Popen, out=None, err=None):
     """Run ``bench.py argv`` on ``gpus`` ranks in a child ``torch.distributed.run``; relay its stdout line by
     line (rank 0 prints the one JSON line) and return its exit code."""
     out = out or sys.stdout
@@ -89,8 +89,11 @@ def self_launch(gpus, argv, popen=subprocess.Popen, out=None):
         env.pop(k, None)
     proc = popen(launcher_command(gpus, argv, _free_port()), stdout=subprocess.PIPE, text=True, env=env)
     for line in proc.stdout:
-        out.write(line)
-        out.flush()
+        # the bench line goes to stdout; whatever else the ranks or their libraries print there (gloo / RCCL
+        # banners) is passed on through stderr, so that stdout carries exactly the one JSON line
+        dst = out if line.lstrip().startswith("{") else (err or sys.stderr)
+        dst.write(line)
+        dst.flush()
     return proc.wait()
 
 
@@ -111,13 +114,26 @@ def timed_run(prop, d_act_ptr, substeps, steps, warmup, barrier, device_sync):
     return t1 - t0
 
 
-def kernel_time(prop, d_act_ptr, substeps, launches):
-    """Mean duration [ms] of the step kernel over ``launches`` dispatch-stamped launches (its own pass)."""
+def kernel_time(prop, d_act_ptr, substeps, launches, lead=4):
+    """Duration of the step kernel over ``launches`` dispatch-stamped launches (its own pass): -> (mean ms, n,
+    stats dict).  ``lead`` stamped launches go first and are not counted (the transition from un-stamped
+    back-to-back stepping; their events are simply re-armed)."""
     prop.sync()
+    if lead:
+        prop.profile_begin(lead, stride=1)
+        for _ in range(lead):
+            prop.step_device(d_act_ptr, substeps)
+        prop.profile_end()
     prop.profile_begin(launches, stride=1)
     for _ in range(launches):
         prop.step_device(d_act_ptr, substeps)
-    return prop.profile_end()
+    if hasattr(prop, "profile_end_samples"):
+        mean_ms, samples = prop.profile_end_samples()
+        srt = sorted(float(x) for x in samples)
+        stats = {"median_us": srt[len(srt) // 2] * 1e3, "min_us": srt[0] * 1e3, "max_us": srt[-1] * 1e3} if srt else {}
+        return mean_ms, len(srt), stats
+    mean_ms, n = prop.profile_end()
+    return mean_ms, n, {}
 
 
 def cpu_baseline(cfg, n_rw, substeps, budget_s=12.0, n=8192):
@@ -319,7 +335,7 @@ def main():
     sync = torch.cuda.synchronize
 
     el = max_over_ranks(timed_run(prop, d_act.data_ptr(), a.substeps, a.steps, a.warmup, barrier, sync))
-    kernel_ms, n_launch = kernel_time(prop, d_act.data_ptr(), a.substeps, min(STAMPED_LAUNCHES, max(a.steps, 4)))
+    kernel_ms, n_launch, kstats = kernel_time(prop, d_act.data_ptr(), a.substeps, min(STAMPED_LAUNCHES, max(a.steps, 4)))
     obs, rew, done, why = prop.get_obs()
     assert np.isfinite(obs).all() and np.isfinite(rew).all()
     info = prop.kernel_info()
@@ -328,11 +344,13 @@ def main():
     kernel_s = kernel_ms * 1e-3
     traffic_bytes, traffic_src = pmc_traffic(n, a.substeps) if (not sh and a.scenario == "bare") else (None, None)
     hbm = hbm_roofline(n, kernel_s, info, traffic_bytes, traffic_src, n_launch)
+    hbm.update(kstats)
     # which roofline bounds this configuration: K = 1 of the bare / power / full propagator streams its state once
     # per launch (HBM); many sub-steps per launch and the harmonics are fp64-issue bound
     mix_key = "sh" if sh else a.scenario
     fp64_bound = sh or a.substeps >= 10
     fp64 = fp64_roofline(mix_key, float(n) * a.substeps, kernel_s, info)
+    fp64.update(kstats)
     out = {
         "metric": "env steps/sec at 65k parallel spacecraft, 1/2/4/8 MI355X; HBM GB/s vs roofline",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -362,7 +380,7 @@ def main():
         # reference-faithful env step: 180 s of sim time = 1 800 RK4 sub-steps, 180 FSW updates
         ksteps = 5
         el2 = timed_run(prop, d_act.data_ptr(), 1800, ksteps, 1, barrier, sync)
-        km2, _ = kernel_time(prop, d_act.data_ptr(), 1800, 3)
+        km2, _, _ = kernel_time(prop, d_act.data_ptr(), 1800, 3, lead=0)
         extra["k1800"] = {"env_steps_per_s": n * ksteps / el2, "rk4_substeps_per_s": n * ksteps * 1800 / el2,
                           "kernel_ms": km2, "ms_per_step": el2 / ksteps * 1e3,
                           "roofline": fp64_roofline("bare", float(n) * 1800, km2 * 1e-3, info)}
@@ -372,7 +390,7 @@ def main():
         big.reset(sample_ic_batch(nl, n_rw, seed=1))
         d_act_big = torch.zeros(nl, dtype=torch.int32, device="cuda")
         el3 = timed_run(big, d_act_big.data_ptr(), 1, 50, 5, barrier, sync)
-        km3, nl3 = kernel_time(big, d_act_big.data_ptr(), 1, 20)
+        km3, nl3, _ = kernel_time(big, d_act_big.data_ptr(), 1, 20)
         tb, ts = pmc_traffic(nl, 1)
         extra["large_n"] = {"envs": nl, "env_steps_per_s": nl * 50 / el3,
                             "roofline": hbm_roofline(nl, km3 * 1e-3, big.kernel_info(), tb, ts, nl3)}
@@ -384,7 +402,7 @@ def main():
         p3.reset(sample_ic_batch(n3, n_rw, seed=1000 + rank))
         d_act3 = torch.zeros(n3, dtype=torch.int32, device="cuda")
         el4 = max_over_ranks(timed_run(p3, d_act3.data_ptr(), 1, 500, 20, barrier, sync))
-        km4, _ = kernel_time(p3, d_act3.data_ptr(), 1, 32)
+        km4, _, _ = kernel_time(p3, d_act3.data_ptr(), 1, 32)
         extra["config3"] = {"workload": "BASELINE configs[3]: %d envs sharded over %d GPUs (%d per GPU), K = 1" % (n3 * world, world, n3),
                             "env_steps_per_s": n3 * world * 500 / el4, "ms_per_step": el4 / 500 * 1e3,
                             "roofline": hbm_roofline(n3, km4 * 1e-3, p3.kernel_info(), None, None, 32),

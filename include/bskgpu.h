@@ -252,6 +252,9 @@ int bsk_profile_begin(bsk_handle* h, int capacity);
  * launch on MI355X, so a timed region samples instead of stamping every launch. */
 int bsk_profile_set_stride(bsk_handle* h, int stride);
 int bsk_profile_end(bsk_handle* h, double* mean_kernel_ms, int* n_launches);
+/* Same, also copying the individual kernel durations [ms] of the first min(cap, n) counted launches
+ * into samples_ms (so that a caller can report median / min / max beside the mean). */
+int bsk_profile_end_samples(bsk_handle* h, double* mean_kernel_ms, int* n_launches, float* samples_ms, int cap);
 
 /* Kernel resource facts for DESIGN.md / bench: name of the kernel variant selected for this
  * handle, its VGPR count, static LDS bytes and the launch geometry. */

@@ -87,8 +87,9 @@ def test_timed_region_is_unstamped_and_counts_exactly_k_steps():
     assert (b0, s0, s1, b1) == ("barrier", "devsync", "devsync", "barrier") and i0 == j0 and j1 - j0 == 20 and i1 == j1
     assert p.log[j0:j1] == ["step"] * 20
     q = _FakeProp()
-    ms, n = b.kernel_time(q, 0, 1, 7)
-    assert q.log[:2] == ["sync", "profile_begin(7,1)"] and q.log.count("step") == 7 and q.log[-1] == "profile_end"
+    ms, n, stats = b.kernel_time(q, 0, 1, 7, lead=2)
+    assert q.log[:2] == ["sync", "profile_begin(2,1)"] and q.log.count("step") == 9 and q.log[-1] == "profile_end"
+    assert q.log.index("profile_begin(7,1)") == 5
 
 
 def test_self_launch_composes_the_launcher_as_a_child_and_relays():
@@ -110,11 +111,11 @@ def test_self_launch_composes_the_launcher_as_a_child_and_relays():
 
     os.environ["RANK"] = "3"          # stale variables of an outer launcher must not leak into the child
     try:
-        out = io.StringIO()
-        rc = b.self_launch(4, ["--gpus", "4", "--steps", "20"], popen=fake_popen, out=out)
+        out, err = io.StringIO(), io.StringIO()
+        rc = b.self_launch(4, ["--gpus", "4", "--steps", "20"], popen=fake_popen, out=out, err=err)
     finally:
         del os.environ["RANK"]
-    assert rc == 7 and out.getvalue().endswith('{"metric": "m"}\n')
+    assert rc == 7 and out.getvalue() == '{"metric": "m"}\n' and err.getvalue() == "warning line\n"
     cmd = seen["cmd"]
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd
     assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
