@@ -612,6 +612,8 @@ int bsk_create(const bsk_config* cfg, int n_envs, int device_id, void* stream, b
         const int v = std::atoi(b);
         if (v == 64 || v == 128 || v == 256) h->block = v;
     }
+    // the power-system kernels carry 29 KB of LDS per wave: one wave per workgroup at every batch size
+    if (cfg->flags & BSK_FLAG_POWER) h->block = 64;
     if (stream) { h->stream = (hipStream_t)stream; h->own_stream = false; }
     else {
         hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);

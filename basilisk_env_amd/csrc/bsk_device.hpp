@@ -324,10 +324,47 @@ __device__ __forceinline__ double shadow_factor(const PowerCfg& pc, const SunGeo
     return 1.0;
 }
 
-// one EnvTask tick: shadow factor, panel power, Euler battery update with clamping
-__device__ __forceinline__ void power_step(const PowerCfg& pc, const SunGeom& g, V3 r, V3 sig, double h, double& charge,
-                                           double& shadow) {
-    shadow = shadow_factor(pc, g, r);
+// The EnvTask of one dyn tick (eclipse -> simpleSolarPanel -> simpleBattery <- simplePowerSink), split so that the
+// one expensive piece — the partially eclipsed disc, percent_shadow, ~250 issue slots — leaves the tick loop.
+// With one spacecraft per lane the wave pays that path whenever ANY of its 64 spacecraft is in the penumbra, and
+// with one wave per SIMD the kernel lasts as long as its slowest wave: a single spacecraft whose orbit grazes the
+// shadow cone kept its wave on the slow path at every tick of the launch.  Instead, each tick only classifies
+// (shadow_quick: lit / umbra / partial) and records what the battery update needs:
+//   g[t][lane]  the tick's panel power per unit of lit disc,  s[t][lane]  its shadow factor when known,
+// and a partially eclipsed tick appends (position, owner lane, slot) to a per-wave queue in LDS.  After at most
+// PEN_SLOTS ticks (one FSW period of the reference) the wave drains the queue COOPERATIVELY — entry e is
+// evaluated by lane e mod 64, whoever owns it, so ten penumbra ticks of one spacecraft cost one pass of
+// percent_shadow instead of ten — and every lane replays its battery updates in tick order (three operations per
+// tick).  Same arithmetic on the same inputs as the tick-by-tick form, hence the same results bit for bit.
+constexpr int PEN_SLOTS = 10;                 // ticks between two flushes (the inner loop is chunked to this)
+constexpr int PEN_QCAP = 64 * PEN_SLOTS;      // every lane partially eclipsed at every tick still fits
+struct PowerLds {                             // one per wavefront, in dynamic LDS (29 KB)
+    double g[PEN_SLOTS][64];
+    double s[PEN_SLOTS][64];
+    double sun[3][64];                        // each lane's Sun position of this launch
+    double qr[3][PEN_QCAP];                   // queue: spacecraft position
+    int qown[PEN_QCAP];                       // queue: owner lane | slot << 8
+    int qcount, pad_[3];
+};
+
+// shadow factor where it is cheap (1 lit, 0 umbra), `band` where the disc is partially covered
+__device__ __forceinline__ double shadow_quick(const SunGeom& g, V3 r, bool& band) {
+    band = false;
+    const double rs = dot(r, g.sun), r2 = dot(r, r);
+    if (r2 < 2.0 * rs) return 1.0;                       // day side of the planet
+    const double s0 = -rs * g.ism;
+    const double c1 = s0 + g.re_sf1, c2 = s0 - g.re_sf2;
+    const double l2v = fma(-s0, s0, r2);                 // squared distance from the shadow axis
+    const double l1 = c1 * g.tf1, l2 = c2 * g.tf2;
+    if (l2v < l2 * l2 && c2 < 0.0) return 0.0;          // inside the umbra cone: the disc is fully covered
+    band = l2v < l2 * l2 || l2v < l1 * l1;               // penumbra / antumbra band
+    return 1.0;
+}
+
+// per tick: classify, record the panel gain and (when known) the shadow factor of slot t
+__device__ __forceinline__ void power_tick(const PowerCfg& pc, const SunGeom& g, V3 r, V3 sig, PowerLds* L, int t, int lane) {
+    bool band;
+    const double sh = shadow_quick(g, r, band);
     const V3 d = g.sun - r;
     const double d2 = dot(d, d), id = rsqrt_nr(d2);
     const V3 sN = id * d;
@@ -336,8 +373,38 @@ __device__ __forceinline__ void power_step(const PowerCfg& pc, const SunGeom& g,
     const V3 t1 = cross(sig, sN), t2 = cross(sig, t1);
     const V3 sB = sN + (8.0 * iop2) * t2 - (4.0 * (1.0 - q2) * iop2) * t1;
     const double proj = fmax(fma(pc.nB[0], sB.x, fma(pc.nB[1], sB.y, pc.nB[2] * sB.z)), 0.0);
-    const double p = fma(pc.kflux * (id * id), proj * shadow, pc.draw);
-    charge = fmin(fmax(fma(p, h, charge), 0.0), pc.cap);
+    L->g[t][lane] = pc.kflux * (id * id) * proj;
+    if (band) {
+        const int e = __hip_atomic_fetch_add(&L->qcount, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        L->qr[0][e] = r.x; L->qr[1][e] = r.y; L->qr[2][e] = r.z;
+        L->qown[e] = lane | (t << 8);
+    } else {
+        L->s[t][lane] = sh;
+    }
+}
+
+// after the chunk's ticks (control flow reconverged, every lane of the wave here): drain the queue cooperatively,
+// then replay this lane's `m` battery updates in order.  `shadow` ends as the last tick's factor.
+__device__ __forceinline__ void power_flush(const PowerCfg& pc, PowerLds* L, int m, int lane, double h, double& charge,
+                                            double& shadow) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const int qc = L->qcount;
+    if (qc > 0) {                                         // wave-uniform
+        for (int e = lane; e < qc; e += 64) {
+            const int own = L->qown[e], ol = own & 63, k = own >> 8;
+            const V3 r = mk(L->qr[0][e], L->qr[1][e], L->qr[2][e]);
+            const V3 sun = mk(L->sun[0][ol], L->sun[1][ol], L->sun[2][ol]);
+            L->s[k][ol] = percent_shadow(pc, sun - r, r, dot(r, r));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane == 0) L->qcount = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    for (int k = 0; k < m; ++k) {
+        shadow = L->s[k][lane];
+        const double p = fma(L->g[k][lane], shadow, pc.draw);
+        charge = fmin(fmax(fma(p, h, charge), 0.0), pc.cap);
+    }
 }
 
 template <bool DIAG>

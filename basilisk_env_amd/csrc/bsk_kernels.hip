@@ -108,7 +108,15 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : BSK_MIN_WAVES
     double shadow = 1.0;
     SunGeom sg;
     constexpr bool POWER = FEAT >= FEAT_POWER;
-    if constexpr (POWER) sg = sun_setup(a.power, (double)tick * c.h);
+    extern __shared__ __align__(16) unsigned char lds_dyn[];
+    PowerLds* L = nullptr;
+    const int lane = (int)(threadIdx.x & 63u);
+    if constexpr (POWER) {
+        sg = sun_setup(a.power, (double)tick * c.h);
+        L = reinterpret_cast<PowerLds*>(lds_dyn) + (threadIdx.x >> 6);
+        L->sun[0][lane] = sg.sun.x; L->sun[1][lane] = sg.sun.y; L->sun[2][lane] = sg.sun.z;
+        if (lane == 0) L->qcount = 0;
+    }
     Env ev;
     if constexpr (FEAT == FEAT_FULL) {
         ev.cold = cold;
@@ -188,12 +196,14 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : BSK_MIN_WAVES
                 first_fsw = false;
             }
             m = min(m, fsw_every - phase);
+            if constexpr (POWER) m = min(m, PEN_SLOTS);   // the power system's per-wave tick record holds PEN_SLOTS ticks
             // The DPP-broadcast harmonics need every lane active inside the RK4 loop, so the trip count is
             // made wave-uniform: envs of one wave that sit at different FSW phases (after a masked reset)
             // advance together to the nearest FSW tick of any of them.
             if constexpr (GRAV == BSK_GRAV_SH) m = wave_min_uniform(m);
             phase = (phase + m == fsw_every) ? 0 : phase + m;
         }
+        if constexpr (POWER && NRW == 0) m = min(m, PEN_SLOTS);
         j += m;
         for (int t = 0; t < m; ++t, ++tick) {
             if constexpr (FEAT == FEAT_FULL) {
@@ -210,8 +220,9 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : BSK_MIN_WAVES
                 }
             }
             rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT>(c, wv, x, u, lext, (double)tick * c.h, ev);
-            if constexpr (POWER) power_step(a.power, sg, x.r, x.s, c.h, charge, shadow);
+            if constexpr (POWER) power_tick(a.power, sg, x.r, x.s, L, t, lane);
         }
+        if constexpr (POWER) power_flush(a.power, L, m, lane, c.h, charge, shadow);
     }
 
     // Re-read the post-loop arguments from the kernarg segment through an opaque pointer: the
@@ -498,9 +509,19 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     a.tail.fsw_lag = p.fsw_lag; a.tail.pad_ = 0;
     if (SPLIT == 5) block = 256;
     const int grid = SPLIT == 5 ? (b.n + 127) / 128 : (b.n + block - 1) / block;
-    const size_t lds = 0;
+    // the power system keeps a per-wave tick record and penumbra queue in dynamic LDS (bsk_device.hpp: PowerLds)
+    const size_t lds = FEAT >= FEAT_POWER ? sizeof(PowerLds) * (size_t)(block / 64) : 0;
     // hipExtLaunchKernelGGL stamps ev0/ev1 from the dispatch packet itself (no marker packets), so
     // their difference is the kernel's own duration, as rocprofv3 --kernel-trace reports it.
+    if (lds > 48 * 1024) {   // the two-wave harmonics form with the power system: 4 waves x 29 KB of dynamic LDS
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute((const void*)&step_kernel<GRAV, NRW, DIAG, FEAT, SPLIT>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            raised = true;
+        }
+    }
     hipExtLaunchKernelGGL((step_kernel<GRAV, NRW, DIAG, FEAT, SPLIT>), dim3(grid), dim3(block), lds, s, ev0, ev1, 0, a);
     return hipGetLastError();
 }
@@ -512,6 +533,10 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     X(BSK_GRAV_PM_J2, 0, true, P) X(BSK_GRAV_PM_J2, 3, true, P) X(BSK_GRAV_PM_J2, 4, true, P)                \
     X(BSK_GRAV_PM, 0, false, P) X(BSK_GRAV_PM, 3, false, P) X(BSK_GRAV_PM, 4, false, P)                      \
     X(BSK_GRAV_PM_J2, 0, false, P) X(BSK_GRAV_PM_J2, 3, false, P) X(BSK_GRAV_PM_J2, 4, false, P)
+#ifdef BSK_FAST_BUILD   // ISA inspection / A-B builds: only the J2 + 4-wheel (bench) and J2 + 3-wheel (env) kernels
+#undef BSK_VARIANTS_P
+#define BSK_VARIANTS_P(X, P) X(BSK_GRAV_PM_J2, 4, true, P) X(BSK_GRAV_PM_J2, 3, true, P)
+#endif
 #define BSK_VARIANTS(X) BSK_VARIANTS_P(X, 0) BSK_VARIANTS_P(X, 1) BSK_VARIANTS_P(X, 2)
 
 hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams& p, const StepBuffers& b, int block,
