@@ -259,7 +259,7 @@ int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool&
         for (int i = 0; i < c.n_thr; ++i)
             for (int a = 0; a < 3; ++a) k.thr_map[i][a] = ddi[3 * a] * Dm[i][0] + ddi[3 * a + 1] * Dm[i][1] + ddi[3 * a + 2] * Dm[i][2];
     }
-    p.feat = full ? bsk::FEAT_FULL : ((c.flags & BSK_FLAG_POWER) ? bsk::FEAT_POWER : bsk::FEAT_BARE);
+    p.feat = full ? bsk::FEAT_FULL : ((c.flags & BSK_FLAG_POWER) ? bsk::FEAT_POWER : bsk::FEAT_BARE);   // FEAT_FULLG: below
     p.ex.mu_sun = (c.flags & BSK_FLAG_SUN_THIRD_BODY) ? c.mu_sun : 0.0;
     p.ex.base_density = (c.flags & BSK_FLAG_DRAG) ? c.base_density : 0.0;
     p.ex.inv_scale_height = c.scale_height > 0.0 ? 1.0 / c.scale_height : 0.0;
@@ -297,6 +297,8 @@ int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool&
                     if (j != axis && k.fa_r[sgn][axis][j] != 0.0) diagonal = false;
         if (diagonal) k.facet_axis = 2;   // facet centres on their own normal axes: 12 table values suffice
     }
+    // any other facet set with live drag runs the generic-geometry variant of the full-scenario kernel
+    if (full && (c.flags & BSK_FLAG_DRAG) && c.base_density != 0.0 && k.facet_axis != 2) p.feat = bsk::FEAT_FULLG;
     for (int i = 0; i < 8; ++i) {
         k.facet_acd[i] = c.facet_area[i] * c.facet_cd[i];
         for (int j = 0; j < 3; ++j) { k.facet_n[i][j] = c.facet_normal[i][j]; k.facet_r[i][j] = c.facet_pos[i][j]; }
@@ -325,6 +327,31 @@ int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool&
     p.obs.r_min2 = c.r_min * c.r_min;
     p.obs.max_length = c.max_length;
     p.obs.pad_ = 0;
+    // broadcast table of the full-scenario kernels (bsk_device.hpp: KTab, KA_* / KB_* / KC_*)
+    for (int i = 0; i < c.n_rw; ++i) {
+        for (int j = 0; j < 3; ++j) k.kt[bsk::KA_G + 3 * i + j] = c.gs[i][j];
+        k.kt[bsk::KA_JS + i] = c.js[i];
+        k.kt[16 + bsk::KB_IJS + i] = 1.0 / c.js[i];
+    }
+    for (int sgn = 0; sgn < 2; ++sgn)
+        for (int axis = 0; axis < 3; ++axis) {
+            k.kt[16 + bsk::KB_FAC + 3 * sgn + axis] = k.fa_c[sgn][axis];
+            k.kt[16 + bsk::KB_FAD + 3 * sgn + axis] = k.fa_r[sgn][axis][axis];
+        }
+    k.kt[32 + bsk::KC_IMASS] = p.ex.inv_mass;
+    for (int j = 0; j < 3; ++j) k.kt[32 + bsk::KC_NB + j] = c.panel_normal[j];
+    k.kt[32 + bsk::KC_KFLUX] = p.pc.kflux;
+    k.kt[32 + bsk::KC_RHO0] = p.ex.base_density;
+    k.kt[32 + bsk::KC_NIH] = -p.ex.inv_scale_height;
+    k.kt[32 + bsk::KC_REQIH] = c.req * p.ex.inv_scale_height;
+    // thruster subset table: row m = sums over the set bits of m, ascending thruster index
+    for (int m = 0; m < (1 << BSK_MAX_THR); ++m) {
+        double f[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < c.n_thr && i < BSK_MAX_THR; ++i)
+            if (m & (1 << i))
+                for (int j = 0; j < 3; ++j) { f[j] += k.thr_f[i][j]; f[3 + j] += k.thr_l[i][j]; }
+        for (int j = 0; j < 6; ++j) k.thr_tab[m][j] = f[j];
+    }
     return BSK_OK;
 }
 
@@ -978,7 +1005,8 @@ int bsk_kernel_info(bsk_handle* h, char* name, int name_cap, int* vgprs, int* ld
     if (name && name_cap > 0)
         std::snprintf(name, name_cap, "step_kernel<%s,%d,%s>",
                       h->cfg.gravity_model == BSK_GRAV_PM ? "PM" : (h->cfg.gravity_model == BSK_GRAV_PM_J2 ? "PM_J2" : (h->sp.sh_form == 5 ? "SH/dpp2" : (h->sp.sh_form == 4 ? "SH/dpp" : "SH/scalar"))), h->cfg.n_rw,
-                      h->sp.feat == 2 ? (h->diag ? "diag,scenario" : "full,scenario")
+                      h->sp.feat >= 2 ? (h->sp.feat == 3 ? (h->diag ? "diag,scenario/generic-facets" : "full,scenario/generic-facets")
+                                                         : (h->diag ? "diag,scenario" : "full,scenario"))
                                       : (h->sp.feat == 1 ? (h->diag ? "diag,power" : "full,power") : (h->diag ? "diag" : "full")));
     if (vgprs) *vgprs = at.numRegs;
     if (lds_bytes) *lds_bytes = (int)at.sharedSizeBytes;

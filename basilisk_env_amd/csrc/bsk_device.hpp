@@ -145,7 +145,18 @@ struct ColdCfg {
     double gs[BSK_MAX_RW][3], js[BSK_MAX_RW];
     int32_t thr_max_counter;
     int32_t fsw_lag;   // bsk_config.fsw_lag: MRP_Feedback consumes the previous FSW tick's att_guidance
+    // wave-uniform constants of the full-scenario kernels: three rows of 16 doubles, fetched lane-wise into three
+    // VGPR pairs (lane l holds entry l & 15 of each row) and fed to the FMAs through the DPP row broadcast (KTab)
+    double kt[48];
+    // force / torque sums of every subset of the thrusters at full thrust, body frame: row m = sum over the bits
+    // of m of (thr_f[i], thr_l[i]) added in ascending i (the oracle's order), so an 8-term conditional sum with
+    // 48 table loads per integrator stage becomes one 6-double row picked by the activity mask
+    double thr_tab[1 << BSK_MAX_THR][6];
 };
+// entries of the broadcast table (ColdCfg::kt): row A, row B, row C
+enum { KA_G = 0, KA_JS = 12 };                                 // wheel spin axes g[i][k] at 3 i + k, Js_i
+enum { KB_IJS = 0, KB_FAC = 4, KB_FAD = 10 };                  // 1/Js_i, facet half sums / differences (6 + 6)
+enum { KC_IMASS = 0, KC_NB = 1, KC_KFLUX = 4, KC_RHO0 = 5, KC_NIH = 6, KC_REQIH = 7 };   // 1/m, panel normal, ...
 
 // Guidance / observation / reward constants: by value in the kernarg (used once per launch, outside
 // the RK4 loop, so they may be parked in VGPR lanes across it at no cost to the loop).
@@ -166,22 +177,34 @@ __device__ __forceinline__ double to_vgpr(double x) {
 }
 template <int NRW>
 struct WheelV {
-    double g[NRW > 0 ? NRW : 1][3];
-    double js[NRW > 0 ? NRW : 1], ijs[NRW > 0 ? NRW : 1];
+    double g_[NRW > 0 ? NRW : 1][3];
+    double js_[NRW > 0 ? NRW : 1], ijs_[NRW > 0 ? NRW : 1];
     template <class Hot>
     __device__ __forceinline__ void load(const Hot& c) {
 #pragma unroll
         for (int i = 0; i < NRW; ++i) {
-            g[i][0] = to_vgpr(c.g[i][0]); g[i][1] = to_vgpr(c.g[i][1]); g[i][2] = to_vgpr(c.g[i][2]);
-            js[i] = to_vgpr(c.js[i]); ijs[i] = to_vgpr(c.ijs[i]);
+            g_[i][0] = to_vgpr(c.g[i][0]); g_[i][1] = to_vgpr(c.g[i][1]); g_[i][2] = to_vgpr(c.g[i][2]);
+            js_[i] = to_vgpr(c.js[i]); ijs_[i] = to_vgpr(c.ijs[i]);
         }
+    }
+    // the four uses of the wheel geometry in an RK4 step
+    template <int I> __device__ __forceinline__ V3 acc_g(double a, V3 v) const { return axpy(a, mk(g_[I][0], g_[I][1], g_[I][2]), v); }   // v + a g_I
+    template <int I> __device__ __forceinline__ double js_times(double x) const { return js_[I] * x; }
+    template <int I> __device__ __forceinline__ double ijs_times(double x) const { return ijs_[I] * x; }
+    template <int I> __device__ __forceinline__ double minus_g_dot(V3 d, double base) const {   // base - g_I . d
+        return fma(-g_[I][0], d.x, fma(-g_[I][1], d.y, fma(-g_[I][2], d.z, base)));
     }
 };
 
 // Feature level of a kernel variant (template parameter FEAT):
 //   0 bare propagator (the bench headline), 1 + power system, 2 full scenario = power + the
 //   wave-uniform runtime switches below (Sun third-body gravity, atmospheric drag).
-enum { FEAT_BARE = 0, FEAT_POWER = 1, FEAT_FULL = 2 };
+//   3 = level 2 for facet sets that are not "axis-aligned with every centre on its own normal axis" (the
+//   reference's eight are): tables read at each use / loop over the facet list.  Kept out of level 2 so that the
+//   kernel the drop-in env runs carries neither their code nor their registers.
+enum { FEAT_BARE = 0, FEAT_POWER = 1, FEAT_FULL = 2, FEAT_FULLG = 3 };
+template <int FEAT>
+constexpr bool is_full() { return FEAT == FEAT_FULL || FEAT == FEAT_FULLG; }
 
 // Sun third-body gravity (leoPowerAttitudeSimulator.py:227-232) and exponentialAtmosphere +
 // facet drag (:265-284, parameters :146-148); FEAT_FULL only.
@@ -346,6 +369,60 @@ struct PowerLds {                             // one per wavefront, in dynamic L
     int qown[PEN_QCAP];                       // queue: owner lane | slot << 8
     int qcount, pad_[3];
 };
+// LDS pointers are spelled with their address space (through a generic pointer the accesses would be flat)
+typedef PowerLds __attribute__((address_space(3))) * LdsP;
+
+// ---------------------------------------------------------------------------------------------------------
+// Wave-uniform constants as DPP broadcast operands (full-scenario kernels).  These kernels need ~45 doubles that
+// are the same in every lane (wheel geometry, facet tables, panel normal, atmosphere) on top of the RK4 loop's
+// HotCfg, which alone nearly fills the SGPR file.  Parked in VGPRs they end up in AGPRs (two v_accvgpr_read per
+// use); spilled from SGPRs they cost two v_readlane per use; read from LDS their latency is exposed with one wave
+// per SIMD.  Every one of them is a multiplicand of an FMA, so they sit in THREE VGPR pairs instead — lane l of
+// each 16-lane row holds entry l & 15 — and v_fmac_f64 picks its factor with the DPP control row_newbcast:k: no
+// extra instruction, no latency, 6 registers.  A DPP operand is read from ANOTHER lane's register, so every lane
+// of the wave must be active where these are used: the full-scenario kernels keep the RK4 loop's trip count and
+// the drag / thruster switches wave-uniform.  asm volatile keeps the compiler from sinking one into a branch.
+struct KTab {
+    double a, b, c;
+};
+template <int K>
+__device__ __forceinline__ double fmac_k(double acc, double tab, double x) {        // acc + tab[K] * x
+    static_assert(K >= 0 && K < 16, "row lane");
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tab), "v"(x), "n"(K));
+    return acc;
+}
+template <int K>
+__device__ __forceinline__ double fmac_k_abs(double acc, double tab, double x) {    // acc + tab[K] * |x|
+    asm volatile("v_fmac_f64_dpp %0, %1, |%2| row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tab), "v"(x), "n"(K));
+    return acc;
+}
+template <int K>
+__device__ __forceinline__ double fmac_k_neg(double acc, double tab, double x) {    // acc - tab[K] * x
+    asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tab), "v"(x), "n"(K));
+    return acc;
+}
+template <int K>
+__device__ __forceinline__ double mul_k(double tab, double x) { return fmac_k<K>(0.0, tab, x); }   // tab[K] * x
+template <int K>
+__device__ __forceinline__ double get_k(double tab) {                                                // tab[K]
+    double r;
+    asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(tab), "n"(K));
+    return r;
+}
+
+// wheel geometry through the broadcast table (rows A and B of KTab): same operations in the same order as WheelV
+template <int NRW>
+struct WheelDpp {
+    double ta, tb;
+    template <int I> __device__ __forceinline__ V3 acc_g(double a, V3 v) const {
+        return mk(fmac_k<KA_G + 3 * I>(v.x, ta, a), fmac_k<KA_G + 3 * I + 1>(v.y, ta, a), fmac_k<KA_G + 3 * I + 2>(v.z, ta, a));
+    }
+    template <int I> __device__ __forceinline__ double js_times(double x) const { return mul_k<KA_JS + I>(ta, x); }
+    template <int I> __device__ __forceinline__ double ijs_times(double x) const { return mul_k<KB_IJS + I>(tb, x); }
+    template <int I> __device__ __forceinline__ double minus_g_dot(V3 d, double base) const {
+        return fmac_k_neg<KA_G + 3 * I>(fmac_k_neg<KA_G + 3 * I + 1>(fmac_k_neg<KA_G + 3 * I + 2>(base, ta, d.z), ta, d.y), ta, d.x);
+    }
+};
 
 // shadow factor where it is cheap (1 lit, 0 umbra), `band` where the disc is partially covered
 __device__ __forceinline__ double shadow_quick(const SunGeom& g, V3 r, bool& band) {
@@ -362,7 +439,8 @@ __device__ __forceinline__ double shadow_quick(const SunGeom& g, V3 r, bool& ban
 }
 
 // per tick: classify, record the panel gain and (when known) the shadow factor of slot t
-__device__ __forceinline__ void power_tick(const PowerCfg& pc, const SunGeom& g, V3 r, V3 sig, PowerLds* L, int t, int lane) {
+template <bool LDSK>
+__device__ __forceinline__ void power_tick(const PowerCfg& pc, const SunGeom& g, V3 r, V3 sig, LdsP L, int t, int lane, double tc) {
     bool band;
     const double sh = shadow_quick(g, r, band);
     const V3 d = g.sun - r;
@@ -372,8 +450,13 @@ __device__ __forceinline__ void power_tick(const PowerCfg& pc, const SunGeom& g,
     const double q2 = dot(sig, sig), op = 1.0 + q2, iop2 = rcp_nr(op * op);
     const V3 t1 = cross(sig, sN), t2 = cross(sig, t1);
     const V3 sB = sN + (8.0 * iop2) * t2 - (4.0 * (1.0 - q2) * iop2) * t1;
-    const double proj = fmax(fma(pc.nB[0], sB.x, fma(pc.nB[1], sB.y, pc.nB[2] * sB.z)), 0.0);
-    L->g[t][lane] = pc.kflux * (id * id) * proj;
+    if constexpr (LDSK) {     // panel normal and flux constant from the broadcast table (row C)
+        const double proj = fmax(fmac_k<KC_NB>(fmac_k<KC_NB + 1>(mul_k<KC_NB + 2>(tc, sB.z), tc, sB.y), tc, sB.x), 0.0);
+        L->g[t][lane] = mul_k<KC_KFLUX>(tc, id * id) * proj;
+    } else {
+        const double proj = fmax(fma(pc.nB[0], sB.x, fma(pc.nB[1], sB.y, pc.nB[2] * sB.z)), 0.0);
+        L->g[t][lane] = pc.kflux * (id * id) * proj;
+    }
     if (band) {
         const int e = __hip_atomic_fetch_add(&L->qcount, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         L->qr[0][e] = r.x; L->qr[1][e] = r.y; L->qr[2][e] = r.z;
@@ -385,7 +468,7 @@ __device__ __forceinline__ void power_tick(const PowerCfg& pc, const SunGeom& g,
 
 // after the chunk's ticks (control flow reconverged, every lane of the wave here): drain the queue cooperatively,
 // then replay this lane's `m` battery updates in order.  `shadow` ends as the last tick's factor.
-__device__ __forceinline__ void power_flush(const PowerCfg& pc, PowerLds* L, int m, int lane, double h, double& charge,
+__device__ __forceinline__ void power_flush(const PowerCfg& pc, LdsP L, int m, int lane, double h, double& charge,
                                             double& shadow) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const int qc = L->qcount;
@@ -400,10 +483,11 @@ __device__ __forceinline__ void power_flush(const PowerCfg& pc, PowerLds* L, int
         if (lane == 0) L->qcount = 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
+    const double draw = pc.draw, cap = pc.cap;
     for (int k = 0; k < m; ++k) {
         shadow = L->s[k][lane];
-        const double p = fma(L->g[k][lane], shadow, pc.draw);
-        charge = fmin(fmax(fma(p, h, charge), 0.0), pc.cap);
+        const double p = fma(L->g[k][lane], shadow, draw);
+        charge = fmin(fmax(fma(p, h, charge), 0.0), cap);
     }
 }
 
@@ -711,46 +795,64 @@ __device__ __forceinline__ V3 gravity(const Hot& c, V3 r, double tsim) {
 //   Om_i' = (u_i + tau_f,i)/Js_i - g_i . w'
 // The wheel torque tq_i = u_i + tau_f,i depends on the state only through sign(Om_i) (Coulomb
 // friction), so the caller passes rhs0 = L_ext - sum tq_i g_i and tqj_i = tq_i / Js_i.
-// Per-step environment handed to the equations of motion by FEAT_FULL (nothing at lower levels).
+// Per-step environment handed to the equations of motion by the full-scenario levels (nothing at lower levels).
+// The switches are WAVE-UNIFORM (a ballot over the lanes that need the term): every lane then evaluates the term
+// and a lane that does not need it contributes exact zeros (density 0, empty thruster mask), so the per-lane
+// results are those of a per-lane branch without its exec-mask bookkeeping.
 struct Env {
     Sun3 s3;
     bool sun_on, drag_on, thr_on;
-    double rho, inv_mass;
+    double rho;              // density of this dyn tick, 0 below the skip threshold
     const ColdCfg* cold;
-    // thrusterDynamicEffector: current burst, on-time per thruster in half dyn steps, elapsed e2
-    double thr_lim[BSK_MAX_THR];
-    double thr_max;   // max over thrusters of thr_lim (0 = no burst pending): one compare per tick decides thr_on
+    KTab kt;                 // broadcast table (facet tables, 1/mass, ...)
+    // thrusterDynamicEffector: current burst, on-time per thruster in half dyn steps (integers <= 2 * fsw_every <
+    // 2^16, two per register: the slab keeps them as doubles), elapsed e2
+    unsigned thr_lim2[BSK_MAX_THR / 2];
+    int thr_max;      // max over thrusters of the limits (0 = no burst pending)
     int e2;
-    // axis-aligned facets (ColdCfg::facet_axis): 2 = every facet centre also lies on its own normal axis
-    // (all eight of the reference's), so the moment table is diagonal and 12 values in registers describe
-    // the whole set; 1 = axis-aligned normals only, tables read from memory at each use; 0 = generic loop
-    int facet_axis;
-    double fa_c[2][3];   // half sum / half difference of area*Cd per axis
-    double fa_d[2][3];   // the same for area*Cd*r_k (component k of the facet centre)
+    // burst ticks only: which thrusters fire at the integrator times e2, e2 + 1, e2 + 2 (bit i = thruster i) and
+    // the force / torque row of the first mask (ColdCfg::thr_tab); a stage whose mask differs reloads its own row
+    int m0, m1, m2;
+    V3 FB0, LB0;
+    int facet_axis;   // generic-facet level only: ColdCfg::facet_axis
 };
 
-// thrust of the active thrusters at integrator time e2 (half dyn steps since the burst started)
-__device__ __forceinline__ void thrusters(const Env& ev, int e2, V3 sig, V3& aN, V3& LB) {
-    const ColdCfg* cc = ev.cold;
-    V3 FB = mk(0, 0, 0);
-    LB = mk(0, 0, 0);
-    const double e = (double)e2;
+__device__ __forceinline__ int thr_limit(const Env& ev, int i) { return (int)((ev.thr_lim2[i >> 1] >> (16 * (i & 1))) & 0xFFFFu); }
+__device__ __forceinline__ void thr_row(const ColdCfg* cc, int mask, V3& FB, V3& LB) {
+    const double* row = cc->thr_tab[mask];
+    FB = mk(row[0], row[1], row[2]);
+    LB = mk(row[3], row[4], row[5]);
+}
+// per dyn tick with a burst pending somewhere in the wave: activity masks of the three integrator times
+__device__ __forceinline__ void thr_masks(Env& ev) {
+    int m0 = 0, m1 = 0, m2 = 0;
 #pragma unroll
     for (int i = 0; i < BSK_MAX_THR; ++i) {
-        if (i < cc->n_thr && ev.thr_lim[i] > 0.0 && e <= ev.thr_lim[i]) {
-            FB = FB + mk(cc->thr_f[i][0], cc->thr_f[i][1], cc->thr_f[i][2]);
-            LB = LB + mk(cc->thr_l[i][0], cc->thr_l[i][1], cc->thr_l[i][2]);
-        }
+        const int lim = thr_limit(ev, i);      // 0 = thruster not in the burst
+        m0 |= (lim > 0 && ev.e2 <= lim) ? (1 << i) : 0;
+        m1 |= (lim > 0 && ev.e2 + 1 <= lim) ? (1 << i) : 0;
+        m2 |= (lim > 0 && ev.e2 + 2 <= lim) ? (1 << i) : 0;
     }
+    ev.m0 = m0; ev.m1 = m1; ev.m2 = m2;
+    thr_row(ev.cold, m0, ev.FB0, ev.LB0);
+}
+// thrust of the active thrusters at integrator stage `de2` (0, 1, 1, 2 half dyn steps after the tick started)
+__device__ __forceinline__ void thrusters(const Env& ev, int de2, V3 sig, V3& aN, V3& LB) {
+    V3 FB = ev.FB0;
+    LB = ev.LB0;
+    const int mk_ = de2 == 0 ? ev.m0 : (de2 == 1 ? ev.m1 : ev.m2);
+    if (mk_ != ev.m0) thr_row(ev.cold, mk_, FB, LB);      // a pulse ends inside this dyn step
     const double q2 = dot(sig, sig), op = 1.0 + q2, iop2 = rcp_nr(op * op);
     const V3 u1 = cross(sig, FB), u2 = cross(sig, u1);
-    aN = ev.inv_mass * (FB + (8.0 * iop2) * u2 + (4.0 * (1.0 - q2) * iop2) * u1);   // [BN]^T F_B / m
+    const V3 FN = FB + (8.0 * iop2) * u2 + (4.0 * (1.0 - q2) * iop2) * u1;                      // [BN]^T F_B
+    aN = mk(mul_k<KC_IMASS>(ev.kt.c, FN.x), mul_k<KC_IMASS>(ev.kt.c, FN.y), mul_k<KC_IMASS>(ev.kt.c, FN.z));   // / m
 }
 
 // facet drag: F = -1/2 rho |v|^2 sum_i Cd_i A_i max(0, n_i . v_hat) v_hat,  L = sum_i r_i x F_i, with v
 // the inertial velocity.  Only the projected-area sum S = sum c_i (n_i . v_hat)+ and its moment
 // Rc = sum c_i (n_i . v_hat)+ r_i need the body frame; the force is along -v_hat in ANY frame, so the
 // inertial acceleration is -(1/2 rho |v| S / m) v_N with no rotation back, and L_B = Rc x (-1/2 rho |v| v_B).
+template <bool GENERIC>
 __device__ __forceinline__ void facet_drag(const Env& ev, V3 sig, V3 vN, V3& aN, V3& LB) {
     const double q2 = dot(sig, sig), op = 1.0 + q2, iop2 = rcp_nr(op * op);
     const double ka = 8.0 * iop2, kb = 4.0 * (1.0 - q2) * iop2;
@@ -763,12 +865,15 @@ __device__ __forceinline__ void facet_drag(const Env& ev, V3 sig, V3 vN, V3& aN,
     // normals are +-e_k: the facets facing the flow on axis k are the +e_k ones when v_hat_k > 0, the
     // -e_k ones otherwise, and |x| sel(x > 0, p, m) = |x| (p + m)/2 + x (p - m)/2 needs no select
     // (the tables hold the half sums [0] and half differences [1]; |x| is a free source modifier)
-    if (ev.facet_axis == 2) {
-        S = fma(fabs(vh.x), ev.fa_c[0][0], fma(vh.x, ev.fa_c[1][0], S));
-        S = fma(fabs(vh.y), ev.fa_c[0][1], fma(vh.y, ev.fa_c[1][1], S));
-        S = fma(fabs(vh.z), ev.fa_c[0][2], fma(vh.z, ev.fa_c[1][2], S));
-        Rc = mk(fma(fabs(vh.x), ev.fa_d[0][0], vh.x * ev.fa_d[1][0]), fma(fabs(vh.y), ev.fa_d[0][1], vh.y * ev.fa_d[1][1]),
-                fma(fabs(vh.z), ev.fa_d[0][2], vh.z * ev.fa_d[1][2]));
+    if (!GENERIC) {
+        // facet centres on their own normal axes: 12 table values (row B of the broadcast table), same operation
+        // order as the fma chains of the generic forms
+        const double tb = ev.kt.b;
+        S = fmac_k_abs<KB_FAC + 0>(fmac_k<KB_FAC + 3>(S, tb, vh.x), tb, vh.x);
+        S = fmac_k_abs<KB_FAC + 1>(fmac_k<KB_FAC + 4>(S, tb, vh.y), tb, vh.y);
+        S = fmac_k_abs<KB_FAC + 2>(fmac_k<KB_FAC + 5>(S, tb, vh.z), tb, vh.z);
+        Rc = mk(fmac_k_abs<KB_FAD + 0>(mul_k<KB_FAD + 3>(tb, vh.x), tb, vh.x), fmac_k_abs<KB_FAD + 1>(mul_k<KB_FAD + 4>(tb, vh.y), tb, vh.y),
+                fmac_k_abs<KB_FAD + 2>(mul_k<KB_FAD + 5>(tb, vh.z), tb, vh.z));
     } else if (ev.facet_axis == 1) {
         const ColdCfg* cc = ev.cold;
         const double vk[3] = {vh.x, vh.y, vh.z};
@@ -790,9 +895,9 @@ __device__ __forceinline__ void facet_drag(const Env& ev, V3 sig, V3 vN, V3& aN,
             }
         }
     }
-    const double kq = -0.5 * ev.rho * (v2 * iv);          // -1/2 rho |v|
+    const double kq = -0.5 * ev.rho * (v2 * iv);          // -1/2 rho |v|  (0 for a lane above the atmosphere)
     LB = cross(Rc, kq * vB);
-    aN = (ev.inv_mass * S * kq) * vN;
+    aN = (mul_k<KC_IMASS>(ev.kt.c, S) * kq) * vN;
 }
 
 // Integration state inside one RK4 step.  The hub sees the wheels only through their total
@@ -811,17 +916,17 @@ __device__ __forceinline__ void eom(const HotCfg<NRW, DIAG>& c, const Core& x, V
                                     int de2, Core& d) {
     d.r = x.v;
     d.v = gravity<GRAV, SPLIT>(c, x.r, tsim);
-    if constexpr (FEAT == FEAT_FULL) {
+    if constexpr (is_full<FEAT>()) {
         if (ev.sun_on) d.v = d.v + third_body(ev.s3, x.r);
         if (ev.drag_on) {
             V3 aN, LB;
-            facet_drag(ev, x.s, x.v, aN, LB);
+            facet_drag<FEAT == FEAT_FULLG>(ev, x.s, x.v, aN, LB);
             d.v = d.v + aN;
             rhs0 = rhs0 + LB;
         }
         if (ev.thr_on) {
             V3 aN, LB;
-            thrusters(ev, ev.e2 + de2, x.s, aN, LB);
+            thrusters(ev, de2, x.s, aN, LB);
             d.v = d.v + aN;
             rhs0 = rhs0 + LB;
         }
@@ -862,25 +967,28 @@ __device__ __forceinline__ void core_axpy(double a, const Core& k, const Core& x
 // shadow-set switch once per completed step.  Motor torque and Coulomb friction are evaluated
 // from the wheel speeds at the start of the step and held through its four stages (the RW
 // effector updates both once per dyn tick, outside the equations of motion).
-template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT>
-__device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, const WheelV<NRW>& wv, State<NRW>& x,
+template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT, class WV>
+__device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, const WV& wv, State<NRW>& x,
                                          const double* u, V3 lext, double t0, const Env& ev) {
     Core y, k, yt, acc;
     y.r = x.r; y.v = x.v; y.s = x.s; y.w = x.w;
     y.p = mk(0, 0, 0);
     V3 T = mk(0, 0, 0);
     double tqj[NRW > 0 ? NRW : 1];
-#pragma unroll
-    for (int i = 0; i < NRW; ++i) {
+    auto wheel_head = [&](auto IC) {
+        constexpr int i = decltype(IC)::value;
         // Coulomb friction -fc sign(Om), 0 at rest; branch-free
         double fr = __builtin_copysign(c.fc, -x.Om[i]);
         fr = (x.Om[i] == 0.0) ? 0.0 : fr;
         const double tq = u[i] + fr;
-        const V3 g = mk(wv.g[i][0], wv.g[i][1], wv.g[i][2]);
-        T = axpy(tq, g, T);
-        y.p = axpy(wv.js[i] * x.Om[i], g, y.p);
-        tqj[i] = tq * wv.ijs[i];
-    }
+        T = wv.template acc_g<i>(tq, T);
+        y.p = wv.template acc_g<i>(wv.template js_times<i>(x.Om[i]), y.p);
+        tqj[i] = wv.template ijs_times<i>(tq);
+    };
+    if constexpr (NRW > 0) wheel_head(std::integral_constant<int, 0>{});
+    if constexpr (NRW > 1) wheel_head(std::integral_constant<int, 1>{});
+    if constexpr (NRW > 2) wheel_head(std::integral_constant<int, 2>{});
+    if constexpr (NRW > 3) wheel_head(std::integral_constant<int, 3>{});
     const V3 rhs0 = lext - T;
     eom<GRAV, NRW, DIAG, FEAT, SPLIT>(c, y, rhs0, T, t0, ev, 0, k);
     core_axpy<NRW>(c.h6, k, y, acc);
@@ -895,8 +1003,11 @@ __device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, const Wheel
     core_axpy<NRW>(c.h6, k, acc, yt);
     const V3 dw = yt.w - y.w;
 #pragma unroll
-    for (int i = 0; i < NRW; ++i)
-        x.Om[i] = fma(-wv.g[i][0], dw.x, fma(-wv.g[i][1], dw.y, fma(-wv.g[i][2], dw.z, fma(c.h, tqj[i], x.Om[i]))));
+    for (int i = 0; i < NRW; ++i) tqj[i] = fma(c.h, tqj[i], x.Om[i]);
+    if constexpr (NRW > 0) x.Om[0] = wv.template minus_g_dot<0>(dw, tqj[0]);
+    if constexpr (NRW > 1) x.Om[1] = wv.template minus_g_dot<1>(dw, tqj[1]);
+    if constexpr (NRW > 2) x.Om[2] = wv.template minus_g_dot<2>(dw, tqj[2]);
+    if constexpr (NRW > 3) x.Om[3] = wv.template minus_g_dot<3>(dw, tqj[3]);
     x.r = yt.r; x.v = yt.v; x.s = yt.s; x.w = yt.w;
     double s2 = dot(x.s, x.s);
     if (s2 > 1.0) x.s = (-rcp_nr(s2)) * x.s;
@@ -1019,8 +1130,11 @@ __device__ __forceinline__ void control(const ColdCfg* __restrict__ c, const Gui
 // thruster's MinOnTime).  thr_lim is the new burst in half dyn steps.
 template <int NRW>
 __device__ __forceinline__ void desat_tick(const ColdCfg* __restrict__ cc, const double* Om, bool first, double Tc,
-                                           double two_over_dt, int fsw_every, int tick, double* thr_rem, double* thr_lim,
-                                           int& thr_t0, int& thr_cnt) {
+                                           double two_over_dt, int fsw_every, int tick, double* __restrict__ rem_base,
+                                           int64_t S, uint32_t bo, unsigned* thr_lim2, int& thr_t0, int& thr_cnt) {
+    // on-time still owed per thruster lives in the state slab and is touched only here (one request per mode entry,
+    // one burst every thr_max_counter + 1 control periods): nothing of it is held across the RK4 loop
+    double thr_rem[BSK_MAX_THR];
     if (first) {
         V3 hs = mk(0, 0, 0);
 #pragma unroll
@@ -1037,22 +1151,31 @@ __device__ __forceinline__ void desat_tick(const ColdCfg* __restrict__ cc, const
 #pragma unroll
         for (int i = 0; i < BSK_MAX_THR; ++i) thr_rem[i] = (i < cc->n_thr) ? (F[i] - fmin) * cc->inv_max_thrust : 0.0;
         thr_cnt = 0;
+    } else if (thr_cnt <= 0) {
+#pragma unroll
+        for (int i = 0; i < BSK_MAX_THR; ++i) thr_rem[i] = ldf(rem_base + (int64_t)i * S, bo);
     }
     if (thr_cnt <= 0) {
+        unsigned lim[BSK_MAX_THR];
 #pragma unroll
         for (int i = 0; i < BSK_MAX_THR; ++i) {
+            lim[i] = 0u;
             if (i >= cc->n_thr) continue;
             double on = fmin(thr_rem[i], Tc);
             if (on < cc->thr_min_fire_time) {
                 thr_rem[i] = 0.0;
-                thr_lim[i] = 0.0;
             } else {
                 thr_rem[i] -= on;
-                thr_lim[i] = (on >= Tc) ? 2.0 * fsw_every : floor(fmax(on, cc->thr_min_on_time) * two_over_dt);
+                lim[i] = (on >= Tc) ? 2u * (unsigned)fsw_every : (unsigned)floor(fmax(on, cc->thr_min_on_time) * two_over_dt);
             }
         }
+#pragma unroll
+        for (int i = 0; i < BSK_MAX_THR / 2; ++i) thr_lim2[i] = lim[2 * i] | (lim[2 * i + 1] << 16);
         thr_t0 = tick;
         thr_cnt = cc->thr_max_counter;
+#pragma unroll
+        for (int i = 0; i < BSK_MAX_THR; ++i)
+            *(gptr<double>)((gptr<char>)(gptr<double>)(rem_base + (int64_t)i * S) + bo) = thr_rem[i];
     } else {
         thr_cnt -= 1;
     }

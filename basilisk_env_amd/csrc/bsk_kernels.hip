@@ -82,11 +82,11 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : BSK_MIN_WAVES
     for (int k = 0; k < NRW; ++k) u[k] = ldf(FLD(TAIL + BSK_T_UCMD + k), bo);
 #undef FLD
 
-    // desaturation state (FEAT_FULL with BSK_FLAG_DESAT)
-    double thr_rem[BSK_MAX_THR];
+    // desaturation state (full scenario with BSK_FLAG_DESAT)
+    constexpr bool FULL = is_full<FEAT>();
     int thr_t0 = 0, thr_cnt = 0;
     bool desat = false;
-    if constexpr (FEAT == FEAT_FULL) desat = a.extra.desat != 0;
+    if constexpr (FULL) desat = a.extra.desat != 0;
 
     const int steps0 = cnt.x & 0xFFFFF;
     int phase = cnt.x >> 20;
@@ -96,8 +96,10 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : BSK_MIN_WAVES
     // SGPRs its constants need) stays out of the inner loop, which holds only HotCfg.
     const int fsw_every = c.fsw_every;
     const int substeps = a.substeps;
-    WheelV<NRW> wv;
-    wv.load(c);
+    // wheel geometry: parked in VGPRs, except at the full-scenario levels where it is read from LDS at each use
+    // wheel geometry: parked in VGPRs, except at the full-scenario levels where it comes through the DPP broadcast
+    // table (bsk_device.hpp: KTab)
+    std::conditional_t<FULL, WheelDpp<NRW>, WheelV<NRW>> wv;
 #if defined(BSK_ABLATE) && BSK_ABLATE == 2
     const int substeps_eff = 0;   // loads + epilogue stores, no RK4 / FSW
 #else
@@ -109,18 +111,27 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : BSK_MIN_WAVES
     SunGeom sg;
     constexpr bool POWER = FEAT >= FEAT_POWER;
     extern __shared__ __align__(16) unsigned char lds_dyn[];
-    PowerLds* L = nullptr;
+    LdsP L = nullptr;
     const int lane = (int)(threadIdx.x & 63u);
     if constexpr (POWER) {
         sg = sun_setup(a.power, (double)tick * c.h);
-        L = reinterpret_cast<PowerLds*>(lds_dyn) + (threadIdx.x >> 6);
+        L = (LdsP)lds_dyn + (threadIdx.x >> 6);
         L->sun[0][lane] = sg.sun.x; L->sun[1][lane] = sg.sun.y; L->sun[2][lane] = sg.sun.z;
         if (lane == 0) L->qcount = 0;
     }
+    KTab kt;
+    if constexpr (FULL) {
+        // lane l of every 16-lane row fetches entry l & 15 of the three table rows (three coalesced loads)
+        const int l16 = lane & 15;
+        kt.a = cold->kt[l16]; kt.b = cold->kt[16 + l16]; kt.c = cold->kt[32 + l16];
+        wv.ta = kt.a; wv.tb = kt.b;
+    } else {
+        wv.load(c);
+    }
     Env ev;
-    if constexpr (FEAT == FEAT_FULL) {
+    if constexpr (FULL) {
         ev.cold = cold;
-        ev.inv_mass = a.extra.inv_mass;
+        ev.kt = kt;
         ev.sun_on = a.extra.mu_sun != 0.0;
         ev.drag_on = false;
         ev.rho = 0.0;
@@ -129,39 +140,28 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : BSK_MIN_WAVES
         ev.s3.sun3 = (a.extra.mu_sun * sg.ism * sg.ism * sg.ism) * sg.sun;
         ev.thr_on = false;
         ev.e2 = 0;
-        ev.facet_axis = (a.extra.base_density != 0.0) ? cold->facet_axis : 0;
+        ev.m0 = ev.m1 = ev.m2 = 0;
+        ev.FB0 = mk(0, 0, 0);
+        ev.LB0 = mk(0, 0, 0);
+        ev.facet_axis = cold->facet_axis;
 #pragma unroll
-        for (int sgn = 0; sgn < 2; ++sgn)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                ev.fa_c[sgn][k] = 0.0;
-                ev.fa_d[sgn][k] = 0.0;
-            }
-        if (ev.facet_axis == 2) {
-#pragma unroll
-            for (int sgn = 0; sgn < 2; ++sgn)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    ev.fa_c[sgn][k] = cold->fa_c[sgn][k];
-                    ev.fa_d[sgn][k] = cold->fa_r[sgn][k][k];
-                }
-        }
-#pragma unroll
-        for (int k = 0; k < BSK_MAX_THR; ++k) { ev.thr_lim[k] = 0.0; thr_rem[k] = 0.0; }
+        for (int k = 0; k < BSK_MAX_THR / 2; ++k) ev.thr_lim2[k] = 0u;
+        ev.thr_max = 0;
         if (desat) {
+            // the current burst's limits are small integers kept as doubles in the slab: packed two per register here
 #pragma unroll
             for (int k = 0; k < BSK_MAX_THR; ++k) {
-                thr_rem[k] = ldf(st + (int64_t)(TAIL + BSK_T_THR_REM + k) * S, bo);
-                ev.thr_lim[k] = ldf(st + (int64_t)(TAIL + BSK_T_THR_LIM + k) * S, bo);
+                const unsigned lim = (unsigned)ldf(st + (int64_t)(TAIL + BSK_T_THR_LIM + k) * S, bo);
+                ev.thr_lim2[k >> 1] |= lim << (16 * (k & 1));
+                ev.thr_max = max(ev.thr_max, (int)lim);
             }
             thr_t0 = (int)ldf(st + (int64_t)(TAIL + BSK_T_THR_T0) * S, bo);
             thr_cnt = (int)ldf(st + (int64_t)(TAIL + BSK_T_THR_CNT) * S, bo);
         }
-        ev.thr_max = 0.0;
-#pragma unroll
-        for (int k = 0; k < BSK_MAX_THR; ++k) ev.thr_max = fmax(ev.thr_max, ev.thr_lim[k]);
     }
     bool first_fsw = true;
+    bool drag_cfg = false;
+    if constexpr (FULL) drag_cfg = a.extra.base_density != 0.0;
     while (j < substeps_eff) {
         int m = substeps_eff - j;
         if constexpr (NRW > 0) {
@@ -184,13 +184,14 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : BSK_MIN_WAVES
                     control<NRW>(cold, g, u);
                 }
                 fsw_ran = true;
-                if constexpr (FEAT == FEAT_FULL) {
+                if constexpr (FULL) {
                     if (desat && action == 2) {
-                        desat_tick<NRW>(cold, x.Om, first_fsw, fsw_every * c.h, 2.0 / c.h, fsw_every, tick, thr_rem, ev.thr_lim,
-                                        thr_t0, thr_cnt);
-                        ev.thr_max = 0.0;
+                        desat_tick<NRW>(cold, x.Om, first_fsw, fsw_every * c.h, 2.0 / c.h, fsw_every, tick,
+                                        const_cast<double*>(st) + (int64_t)(TAIL + BSK_T_THR_REM) * S, S, bo, ev.thr_lim2, thr_t0,
+                                        thr_cnt);
+                        ev.thr_max = 0;
 #pragma unroll
-                        for (int k = 0; k < BSK_MAX_THR; ++k) ev.thr_max = fmax(ev.thr_max, ev.thr_lim[k]);
+                        for (int k = 0; k < BSK_MAX_THR; ++k) ev.thr_max = max(ev.thr_max, thr_limit(ev, k));
                     }
                 }
                 first_fsw = false;
@@ -200,27 +201,33 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : BSK_MIN_WAVES
             // The DPP-broadcast harmonics need every lane active inside the RK4 loop, so the trip count is
             // made wave-uniform: envs of one wave that sit at different FSW phases (after a masked reset)
             // advance together to the nearest FSW tick of any of them.
-            if constexpr (GRAV == BSK_GRAV_SH) m = wave_min_uniform(m);
+            // (the full-scenario levels take their wave-uniform constants through DPP broadcasts: same requirement)
+            if constexpr (GRAV == BSK_GRAV_SH || FULL) m = wave_min_uniform(m);
             phase = (phase + m == fsw_every) ? 0 : phase + m;
         }
-        if constexpr (POWER && NRW == 0) m = min(m, PEN_SLOTS);
+        if constexpr (POWER && NRW == 0) {
+            m = min(m, PEN_SLOTS);
+            if constexpr (FULL) m = wave_min_uniform(m);
+        }
         j += m;
         for (int t = 0; t < m; ++t, ++tick) {
-            if constexpr (FEAT == FEAT_FULL) {
-                if (a.extra.base_density != 0.0) {   // exponentialAtmosphere, refreshed once per dyn tick
+            if constexpr (FULL) {
+                if (drag_cfg) {   // exponentialAtmosphere, refreshed once per dyn tick
                     const double r2 = dot(x.r, x.r), rm = r2 * rsqrt_nr(r2);
-                    ev.rho = a.extra.base_density * exp(-(rm - a.power.req) * a.extra.inv_scale_height);
-                    ev.drag_on = ev.rho >= a.extra.rho_skip;   // below it |a_drag| < 1e-19 m/s^2: dropped
+                    // rho0 exp(-(|r| - Re)/H) with the exponent as one FMA on table constants: Re/H - |r|/H
+                    const double rho = mul_k<KC_RHO0>(kt.c, exp(fmac_k<KC_NIH>(get_k<KC_REQIH>(kt.c), kt.c, rm)));
+                    ev.rho = rho >= a.extra.rho_skip ? rho : 0.0;   // below it |a_drag| < 1e-19 m/s^2: dropped
+                    ev.drag_on = __builtin_amdgcn_ballot_w64(ev.rho != 0.0) != 0;   // any lane of the wave inside the atmosphere
                 }
-            }
-            if constexpr (FEAT == FEAT_FULL) {
                 if (desat) {
                     ev.e2 = 2 * (tick - thr_t0);
-                    ev.thr_on = ev.thr_max > 0.0 && (double)ev.e2 <= ev.thr_max;   // some thruster still inside its burst
+                    // some thruster of some lane still inside its burst
+                    ev.thr_on = __builtin_amdgcn_ballot_w64(ev.thr_max > 0 && ev.e2 <= ev.thr_max) != 0;
+                    if (ev.thr_on) thr_masks(ev);
                 }
             }
             rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT>(c, wv, x, u, lext, (double)tick * c.h, ev);
-            if constexpr (POWER) power_tick(a.power, sg, x.r, x.s, L, t, lane);
+            if constexpr (POWER) power_tick<FULL>(a.power, sg, x.r, x.s, L, t, lane, kt.c);
         }
         if constexpr (POWER) power_flush(a.power, L, m, lane, c.h, charge, shadow);
     }
@@ -310,13 +317,10 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : BSK_MIN_WAVES
 #pragma unroll
         for (int k = 0; k < NRW; ++k) stf(FLD(BSK_NF_BASE + k), bo, x.Om[k]);
         if constexpr (POWER) stf(FLD(TAIL + BSK_T_CHARGE), bo, charge);
-        if constexpr (FEAT == FEAT_FULL) {
+        if constexpr (FULL) {
             if (desat) {
 #pragma unroll
-                for (int k = 0; k < BSK_MAX_THR; ++k) {
-                    stf(FLD(TAIL + BSK_T_THR_REM + k), bo, thr_rem[k]);
-                    stf(FLD(TAIL + BSK_T_THR_LIM + k), bo, ev.thr_lim[k]);
-                }
+                for (int k = 0; k < BSK_MAX_THR; ++k) stf(FLD(TAIL + BSK_T_THR_LIM + k), bo, (double)thr_limit(ev, k));
                 stf(FLD(TAIL + BSK_T_THR_T0), bo, (double)thr_t0);
                 stf(FLD(TAIL + BSK_T_THR_CNT), bo, (double)thr_cnt);
             }
@@ -537,7 +541,7 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
 #undef BSK_VARIANTS_P
 #define BSK_VARIANTS_P(X, P) X(BSK_GRAV_PM_J2, 4, true, P) X(BSK_GRAV_PM_J2, 3, true, P)
 #endif
-#define BSK_VARIANTS(X) BSK_VARIANTS_P(X, 0) BSK_VARIANTS_P(X, 1) BSK_VARIANTS_P(X, 2)
+#define BSK_VARIANTS(X) BSK_VARIANTS_P(X, 0) BSK_VARIANTS_P(X, 1) BSK_VARIANTS_P(X, 2) BSK_VARIANTS_P(X, 3)
 
 hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams& p, const StepBuffers& b, int block,
                        hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
