@@ -335,7 +335,7 @@ int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool&
     }
     for (int sgn = 0; sgn < 2; ++sgn)
         for (int axis = 0; axis < 3; ++axis) {
-            k.kt[16 + bsk::KB_FAC + 3 * sgn + axis] = k.fa_c[sgn][axis];
+            k.kt[16 + bsk::KB_FAC + 3 * sgn + axis] = k.fa_c[sgn][axis] * p.ex.inv_mass;   // area table carries 1/m
             k.kt[16 + bsk::KB_FAD + 3 * sgn + axis] = k.fa_r[sgn][axis][axis];
         }
     k.kt[32 + bsk::KC_IMASS] = p.ex.inv_mass;

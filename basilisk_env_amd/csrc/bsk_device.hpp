@@ -187,12 +187,22 @@ struct WheelV {
             js_[i] = to_vgpr(c.js[i]); ijs_[i] = to_vgpr(c.ijs[i]);
         }
     }
-    // the four uses of the wheel geometry in an RK4 step
-    template <int I> __device__ __forceinline__ V3 acc_g(double a, V3 v) const { return axpy(a, mk(g_[I][0], g_[I][1], g_[I][2]), v); }   // v + a g_I
-    template <int I> __device__ __forceinline__ double js_times(double x) const { return js_[I] * x; }
-    template <int I> __device__ __forceinline__ double ijs_times(double x) const { return ijs_[I] * x; }
-    template <int I> __device__ __forceinline__ double minus_g_dot(V3 d, double base) const {   // base - g_I . d
-        return fma(-g_[I][0], d.x, fma(-g_[I][1], d.y, fma(-g_[I][2], d.z, base)));
+    // head of an RK4 step: T = sum tq_i g_i, p = sum (Js_i Om_i) g_i, tqj_i = tq_i / Js_i
+    __device__ __forceinline__ void head(const double* tq, const double* Om, V3& T, V3& p, double* tqj) const {
+        T = mk(0, 0, 0);
+        p = mk(0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NRW; ++i) {
+            const V3 g = mk(g_[i][0], g_[i][1], g_[i][2]);
+            T = axpy(tq[i], g, T);
+            p = axpy(js_[i] * Om[i], g, p);
+            tqj[i] = tq[i] * ijs_[i];
+        }
+    }
+    // tail: Om_i = base_i - g_i . dw   (accumulated z, y, x: the order of the fma chain below)
+    __device__ __forceinline__ void tail(V3 dw, const double* base, double* Om) const {
+#pragma unroll
+        for (int i = 0; i < NRW; ++i) Om[i] = fma(-g_[i][0], dw.x, fma(-g_[i][1], dw.y, fma(-g_[i][2], dw.z, base[i])));
     }
 };
 
@@ -410,32 +420,68 @@ __device__ __forceinline__ double get_k(double tab) {                           
     return r;
 }
 
-// wheel geometry through the broadcast table (rows A and B of KTab): same operations in the same order as WheelV
+// wheel geometry through the broadcast table (rows A and B of KTab): the same operations in the same order per
+// accumulator as WheelV, issued wheel-interleaved so that no DPP FMA follows the instruction that produced one of
+// its operands (the compiler pads that distance with s_nop, and every s_nop costs a one-wave SIMD an issue slot)
 template <int NRW>
 struct WheelDpp {
     double ta, tb;
-    template <int I> __device__ __forceinline__ V3 acc_g(double a, V3 v) const {
-        return mk(fmac_k<KA_G + 3 * I>(v.x, ta, a), fmac_k<KA_G + 3 * I + 1>(v.y, ta, a), fmac_k<KA_G + 3 * I + 2>(v.z, ta, a));
+    __device__ __forceinline__ void head(const double* tq, const double* Om, V3& T, V3& p, double* tqj) const {
+        double jo[NRW > 0 ? NRW : 1];
+        T = mk(0, 0, 0);
+        p = mk(0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NRW; ++i) { jo[i] = 0.0; tqj[i] = 0.0; }
+        if constexpr (NRW > 0) jo[0] = fmac_k<KA_JS + 0>(jo[0], ta, Om[0]);
+        if constexpr (NRW > 1) jo[1] = fmac_k<KA_JS + 1>(jo[1], ta, Om[1]);
+        if constexpr (NRW > 2) jo[2] = fmac_k<KA_JS + 2>(jo[2], ta, Om[2]);
+        if constexpr (NRW > 3) jo[3] = fmac_k<KA_JS + 3>(jo[3], ta, Om[3]);
+        if constexpr (NRW > 0) tqj[0] = fmac_k<KB_IJS + 0>(tqj[0], tb, tq[0]);
+        if constexpr (NRW > 1) tqj[1] = fmac_k<KB_IJS + 1>(tqj[1], tb, tq[1]);
+        if constexpr (NRW > 2) tqj[2] = fmac_k<KB_IJS + 2>(tqj[2], tb, tq[2]);
+        if constexpr (NRW > 3) tqj[3] = fmac_k<KB_IJS + 3>(tqj[3], tb, tq[3]);
+        auto wheel = [&](auto IC) {     // six independent accumulators per wheel
+            constexpr int i = decltype(IC)::value;
+            T.x = fmac_k<KA_G + 3 * i>(T.x, ta, tq[i]); T.y = fmac_k<KA_G + 3 * i + 1>(T.y, ta, tq[i]); T.z = fmac_k<KA_G + 3 * i + 2>(T.z, ta, tq[i]);
+            p.x = fmac_k<KA_G + 3 * i>(p.x, ta, jo[i]); p.y = fmac_k<KA_G + 3 * i + 1>(p.y, ta, jo[i]); p.z = fmac_k<KA_G + 3 * i + 2>(p.z, ta, jo[i]);
+        };
+        if constexpr (NRW > 0) wheel(std::integral_constant<int, 0>{});
+        if constexpr (NRW > 1) wheel(std::integral_constant<int, 1>{});
+        if constexpr (NRW > 2) wheel(std::integral_constant<int, 2>{});
+        if constexpr (NRW > 3) wheel(std::integral_constant<int, 3>{});
     }
-    template <int I> __device__ __forceinline__ double js_times(double x) const { return mul_k<KA_JS + I>(ta, x); }
-    template <int I> __device__ __forceinline__ double ijs_times(double x) const { return mul_k<KB_IJS + I>(tb, x); }
-    template <int I> __device__ __forceinline__ double minus_g_dot(V3 d, double base) const {
-        return fmac_k_neg<KA_G + 3 * I>(fmac_k_neg<KA_G + 3 * I + 1>(fmac_k_neg<KA_G + 3 * I + 2>(base, ta, d.z), ta, d.y), ta, d.x);
+    __device__ __forceinline__ void tail(V3 dw, const double* base, double* Om) const {
+#pragma unroll
+        for (int i = 0; i < NRW; ++i) Om[i] = base[i];
+        if constexpr (NRW > 0) Om[0] = fmac_k_neg<KA_G + 2>(Om[0], ta, dw.z);
+        if constexpr (NRW > 1) Om[1] = fmac_k_neg<KA_G + 5>(Om[1], ta, dw.z);
+        if constexpr (NRW > 2) Om[2] = fmac_k_neg<KA_G + 8>(Om[2], ta, dw.z);
+        if constexpr (NRW > 3) Om[3] = fmac_k_neg<KA_G + 11>(Om[3], ta, dw.z);
+        if constexpr (NRW > 0) Om[0] = fmac_k_neg<KA_G + 1>(Om[0], ta, dw.y);
+        if constexpr (NRW > 1) Om[1] = fmac_k_neg<KA_G + 4>(Om[1], ta, dw.y);
+        if constexpr (NRW > 2) Om[2] = fmac_k_neg<KA_G + 7>(Om[2], ta, dw.y);
+        if constexpr (NRW > 3) Om[3] = fmac_k_neg<KA_G + 10>(Om[3], ta, dw.y);
+        if constexpr (NRW > 0) Om[0] = fmac_k_neg<KA_G + 0>(Om[0], ta, dw.x);
+        if constexpr (NRW > 1) Om[1] = fmac_k_neg<KA_G + 3>(Om[1], ta, dw.x);
+        if constexpr (NRW > 2) Om[2] = fmac_k_neg<KA_G + 6>(Om[2], ta, dw.x);
+        if constexpr (NRW > 3) Om[3] = fmac_k_neg<KA_G + 9>(Om[3], ta, dw.x);
     }
 };
 
 // shadow factor where it is cheap (1 lit, 0 umbra), `band` where the disc is partially covered
 __device__ __forceinline__ double shadow_quick(const SunGeom& g, V3 r, bool& band) {
-    band = false;
+    // branch-free: with 64 spacecraft per wave every path is taken by some lane anyway, and each divergent branch
+    // costs exec-mask bookkeeping on the scalar unit
     const double rs = dot(r, g.sun), r2 = dot(r, r);
-    if (r2 < 2.0 * rs) return 1.0;                       // day side of the planet
     const double s0 = -rs * g.ism;
     const double c1 = s0 + g.re_sf1, c2 = s0 - g.re_sf2;
     const double l2v = fma(-s0, s0, r2);                 // squared distance from the shadow axis
     const double l1 = c1 * g.tf1, l2 = c2 * g.tf2;
-    if (l2v < l2 * l2 && c2 < 0.0) return 0.0;          // inside the umbra cone: the disc is fully covered
-    band = l2v < l2 * l2 || l2v < l1 * l1;               // penumbra / antumbra band
-    return 1.0;
+    const bool night = !(r2 < 2.0 * rs);                 // not on the day side of the planet
+    const bool in2 = l2v < l2 * l2, in1 = l2v < l1 * l1;
+    const bool umbra = night && in2 && c2 < 0.0;         // inside the umbra cone: the disc is fully covered
+    band = night && !umbra && (in2 || in1);              // penumbra / antumbra band
+    return umbra ? 0.0 : 1.0;
 }
 
 // per tick: classify, record the panel gain and (when known) the shadow factor of slot t
@@ -483,11 +529,25 @@ __device__ __forceinline__ void power_flush(const PowerCfg& pc, LdsP L, int m, i
         if (lane == 0) L->qcount = 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
+    // Replay: all the record's loads first (2 x PEN_SLOTS LDS reads in flight at once), the energy increments
+    // p_k h in parallel, then only the clamped sums are a dependent chain (three operations per tick; one wave per
+    // SIMD pays every dependent instruction's full latency).  charge + (p h) with p h rounded first is what the
+    // non-fused reference arithmetic does.
     const double draw = pc.draw, cap = pc.cap;
-    for (int k = 0; k < m; ++k) {
-        shadow = L->s[k][lane];
-        const double p = fma(L->g[k][lane], shadow, draw);
-        charge = fmin(fmax(fma(p, h, charge), 0.0), cap);
+    double sk[PEN_SLOTS], dq[PEN_SLOTS];
+#pragma unroll
+    for (int k = 0; k < PEN_SLOTS; ++k) {
+        sk[k] = L->s[k][lane];
+        dq[k] = L->g[k][lane];
+    }
+#pragma unroll
+    for (int k = 0; k < PEN_SLOTS; ++k) dq[k] = fma(dq[k], sk[k], draw) * h;
+#pragma unroll
+    for (int k = 0; k < PEN_SLOTS; ++k) {
+        if (k < m) {
+            shadow = sk[k];
+            charge = fmin(fmax(charge + dq[k], 0.0), cap);
+        }
     }
 }
 
@@ -866,14 +926,19 @@ __device__ __forceinline__ void facet_drag(const Env& ev, V3 sig, V3 vN, V3& aN,
     // -e_k ones otherwise, and |x| sel(x > 0, p, m) = |x| (p + m)/2 + x (p - m)/2 needs no select
     // (the tables hold the half sums [0] and half differences [1]; |x| is a free source modifier)
     if (!GENERIC) {
-        // facet centres on their own normal axes: 12 table values (row B of the broadcast table), same operation
-        // order as the fma chains of the generic forms
+        // facet centres on their own normal axes: 12 table values (row B of the broadcast table).  Four independent
+        // accumulators, issued interleaved (a DPP FMA right behind the instruction that wrote one of its operands
+        // is padded with s_nop); the area table carries 1/m, so Sm = S / m.
         const double tb = ev.kt.b;
-        S = fmac_k_abs<KB_FAC + 0>(fmac_k<KB_FAC + 3>(S, tb, vh.x), tb, vh.x);
-        S = fmac_k_abs<KB_FAC + 1>(fmac_k<KB_FAC + 4>(S, tb, vh.y), tb, vh.y);
-        S = fmac_k_abs<KB_FAC + 2>(fmac_k<KB_FAC + 5>(S, tb, vh.z), tb, vh.z);
-        Rc = mk(fmac_k_abs<KB_FAD + 0>(mul_k<KB_FAD + 3>(tb, vh.x), tb, vh.x), fmac_k_abs<KB_FAD + 1>(mul_k<KB_FAD + 4>(tb, vh.y), tb, vh.y),
-                fmac_k_abs<KB_FAD + 2>(mul_k<KB_FAD + 5>(tb, vh.z), tb, vh.z));
+        double rx = 0.0, ry = 0.0, rz = 0.0;
+        S = fmac_k<KB_FAC + 3>(S, tb, vh.x);       rx = fmac_k<KB_FAD + 3>(rx, tb, vh.x);
+        ry = fmac_k<KB_FAD + 4>(ry, tb, vh.y);     rz = fmac_k<KB_FAD + 5>(rz, tb, vh.z);
+        S = fmac_k_abs<KB_FAC + 0>(S, tb, vh.x);   rx = fmac_k_abs<KB_FAD + 0>(rx, tb, vh.x);
+        ry = fmac_k_abs<KB_FAD + 1>(ry, tb, vh.y); rz = fmac_k_abs<KB_FAD + 2>(rz, tb, vh.z);
+        S = fmac_k<KB_FAC + 4>(S, tb, vh.y);       Rc.x = rx;
+        S = fmac_k_abs<KB_FAC + 1>(S, tb, vh.y);   Rc.y = ry;
+        S = fmac_k<KB_FAC + 5>(S, tb, vh.z);       Rc.z = rz;
+        S = fmac_k_abs<KB_FAC + 2>(S, tb, vh.z);
     } else if (ev.facet_axis == 1) {
         const ColdCfg* cc = ev.cold;
         const double vk[3] = {vh.x, vh.y, vh.z};
@@ -897,7 +962,8 @@ __device__ __forceinline__ void facet_drag(const Env& ev, V3 sig, V3 vN, V3& aN,
     }
     const double kq = -0.5 * ev.rho * (v2 * iv);          // -1/2 rho |v|  (0 for a lane above the atmosphere)
     LB = cross(Rc, kq * vB);
-    aN = (mul_k<KC_IMASS>(ev.kt.c, S) * kq) * vN;
+    if (!GENERIC) aN = (S * kq) * vN;                               // S already carries 1/m
+    else aN = (mul_k<KC_IMASS>(ev.kt.c, S) * kq) * vN;
 }
 
 // Integration state inside one RK4 step.  The hub sees the wheels only through their total
@@ -974,21 +1040,15 @@ __device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, const WV& w
     y.r = x.r; y.v = x.v; y.s = x.s; y.w = x.w;
     y.p = mk(0, 0, 0);
     V3 T = mk(0, 0, 0);
-    double tqj[NRW > 0 ? NRW : 1];
-    auto wheel_head = [&](auto IC) {
-        constexpr int i = decltype(IC)::value;
+    double tqj[NRW > 0 ? NRW : 1], tq[NRW > 0 ? NRW : 1];
+#pragma unroll
+    for (int i = 0; i < NRW; ++i) {
         // Coulomb friction -fc sign(Om), 0 at rest; branch-free
         double fr = __builtin_copysign(c.fc, -x.Om[i]);
         fr = (x.Om[i] == 0.0) ? 0.0 : fr;
-        const double tq = u[i] + fr;
-        T = wv.template acc_g<i>(tq, T);
-        y.p = wv.template acc_g<i>(wv.template js_times<i>(x.Om[i]), y.p);
-        tqj[i] = wv.template ijs_times<i>(tq);
-    };
-    if constexpr (NRW > 0) wheel_head(std::integral_constant<int, 0>{});
-    if constexpr (NRW > 1) wheel_head(std::integral_constant<int, 1>{});
-    if constexpr (NRW > 2) wheel_head(std::integral_constant<int, 2>{});
-    if constexpr (NRW > 3) wheel_head(std::integral_constant<int, 3>{});
+        tq[i] = u[i] + fr;
+    }
+    if constexpr (NRW > 0) wv.head(tq, x.Om, T, y.p, tqj);
     const V3 rhs0 = lext - T;
     eom<GRAV, NRW, DIAG, FEAT, SPLIT>(c, y, rhs0, T, t0, ev, 0, k);
     core_axpy<NRW>(c.h6, k, y, acc);
@@ -1004,10 +1064,7 @@ __device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, const WV& w
     const V3 dw = yt.w - y.w;
 #pragma unroll
     for (int i = 0; i < NRW; ++i) tqj[i] = fma(c.h, tqj[i], x.Om[i]);
-    if constexpr (NRW > 0) x.Om[0] = wv.template minus_g_dot<0>(dw, tqj[0]);
-    if constexpr (NRW > 1) x.Om[1] = wv.template minus_g_dot<1>(dw, tqj[1]);
-    if constexpr (NRW > 2) x.Om[2] = wv.template minus_g_dot<2>(dw, tqj[2]);
-    if constexpr (NRW > 3) x.Om[3] = wv.template minus_g_dot<3>(dw, tqj[3]);
+    if constexpr (NRW > 0) wv.tail(dw, tqj, x.Om);
     x.r = yt.r; x.v = yt.v; x.s = yt.s; x.w = yt.w;
     double s2 = dot(x.s, x.s);
     if (s2 > 1.0) x.s = (-rcp_nr(s2)) * x.s;

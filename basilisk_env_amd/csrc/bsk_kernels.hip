@@ -165,7 +165,11 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : BSK_MIN_WAVES
     while (j < substeps_eff) {
         int m = substeps_eff - j;
         if constexpr (NRW > 0) {
+#if defined(BSK_ABLATE) && BSK_ABLATE == 3
+            if (false) {   // timing only: no FSW chain
+#else
             if (phase == 0) {
+#endif
                 // mrpControlTask order of the reference (MRP_Feedback before attTrackingError, ...Simulator.py:484-486;
                 // bsk_config.fsw_lag): this tick commands the torque the PREVIOUS tick's guidance maps to and
                 // leaves its own for the next one.  The pending torque comes from the slab on the launch's first
@@ -202,7 +206,9 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : BSK_MIN_WAVES
             // made wave-uniform: envs of one wave that sit at different FSW phases (after a masked reset)
             // advance together to the nearest FSW tick of any of them.
             // (the full-scenario levels take their wave-uniform constants through DPP broadcasts: same requirement)
+#if !(defined(BSK_ABLATE) && BSK_ABLATE == 5)   // 5: timing only, per-lane trip count
             if constexpr (GRAV == BSK_GRAV_SH || FULL) m = wave_min_uniform(m);
+#endif
             phase = (phase + m == fsw_every) ? 0 : phase + m;
         }
         if constexpr (POWER && NRW == 0) {
@@ -229,7 +235,9 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : BSK_MIN_WAVES
             rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT>(c, wv, x, u, lext, (double)tick * c.h, ev);
             if constexpr (POWER) power_tick<FULL>(a.power, sg, x.r, x.s, L, t, lane, kt.c);
         }
+#if !(defined(BSK_ABLATE) && BSK_ABLATE == 4)   // 4: timing only, no drain / battery replay
         if constexpr (POWER) power_flush(a.power, L, m, lane, c.h, charge, shadow);
+#endif
     }
 
     // Re-read the post-loop arguments from the kernarg segment through an opaque pointer: the
