@@ -260,6 +260,7 @@ int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool&
             for (int a = 0; a < 3; ++a) k.thr_map[i][a] = ddi[3 * a] * Dm[i][0] + ddi[3 * a + 1] * Dm[i][1] + ddi[3 * a + 2] * Dm[i][2];
     }
     p.feat = full ? bsk::FEAT_FULL : ((c.flags & BSK_FLAG_POWER) ? bsk::FEAT_POWER : bsk::FEAT_BARE);   // FEAT_FULLG: below
+    if (c.flags & BSK_FLAG_LDS_SCRATCH) p.feat = bsk::FEAT_LDSS;
     p.ex.mu_sun = (c.flags & BSK_FLAG_SUN_THIRD_BODY) ? c.mu_sun : 0.0;
     p.ex.base_density = (c.flags & BSK_FLAG_DRAG) ? c.base_density : 0.0;
     p.ex.inv_scale_height = c.scale_height > 0.0 ? 1.0 / c.scale_height : 0.0;
@@ -424,14 +425,14 @@ int validate(const bsk_config& c) {
         return fail(BSK_EINVAL, "unknown gravity_model");
     if (c.gravity_model == BSK_GRAV_SH && (c.sh_degree < 2 || c.sh_degree > BSK_MAX_SH_DEGREE))
         return fail(BSK_EINVAL, "sh_degree must be in 2..70 for BSK_GRAV_SH");
-    const uint32_t unbuilt = BSK_FLAG_LDS_SCRATCH;
     if ((c.flags & (BSK_FLAG_SUN_THIRD_BODY | BSK_FLAG_DRAG | BSK_FLAG_DESAT)) && !(c.flags & BSK_FLAG_POWER))
         return fail(BSK_EINVAL, "BSK_FLAG_SUN_THIRD_BODY / BSK_FLAG_DRAG / BSK_FLAG_DESAT are built in the full-scenario kernel: set BSK_FLAG_POWER too");
     if ((c.flags & BSK_FLAG_DESAT) && (c.n_thr < 3 || c.n_thr > BSK_MAX_THR || c.n_rw == 0 || !(c.thr_max_thrust > 0.0) || !(c.mass > 0.0)))
         return fail(BSK_EINVAL, "BSK_FLAG_DESAT needs 3..8 thrusters, wheels, thr_max_thrust > 0 and mass > 0");
     if ((c.flags & BSK_FLAG_DRAG) && (c.n_facets < 0 || c.n_facets > 8 || !(c.scale_height > 0.0) || !(c.mass > 0.0)))
         return fail(BSK_EINVAL, "BSK_FLAG_DRAG needs 0..8 facets, scale_height > 0 and mass > 0");
-    if (c.flags & unbuilt) return fail(BSK_EINVAL, "config flag requests a feature that is not built in this version");
+    if ((c.flags & BSK_FLAG_LDS_SCRATCH) && ((c.flags & BSK_FLAG_POWER) || c.gravity_model == BSK_GRAV_SH))
+        return fail(BSK_EINVAL, "BSK_FLAG_LDS_SCRATCH is built for the bare propagator (point mass / J2, no power system) only");
     if (!(c.mu > 0.0) || !(c.req > 0.0)) return fail(BSK_EINVAL, "mu and req must be positive");
     if (!(c.wheel_limit > 0.0) || !(c.power_max > 0.0)) return fail(BSK_EINVAL, "wheel_limit and power_max must be positive");
     if ((c.flags & BSK_FLAG_POWER) && !(c.storage_capacity > 0.0 && c.sun_r0[0] * c.sun_r0[0] + c.sun_r0[1] * c.sun_r0[1] + c.sun_r0[2] * c.sun_r0[2] > 0.0))
@@ -1007,7 +1008,8 @@ int bsk_kernel_info(bsk_handle* h, char* name, int name_cap, int* vgprs, int* ld
                       h->cfg.gravity_model == BSK_GRAV_PM ? "PM" : (h->cfg.gravity_model == BSK_GRAV_PM_J2 ? "PM_J2" : (h->sp.sh_form == 5 ? "SH/dpp2" : (h->sp.sh_form == 4 ? "SH/dpp" : "SH/scalar"))), h->cfg.n_rw,
                       h->sp.feat >= 2 ? (h->sp.feat == 3 ? (h->diag ? "diag,scenario/generic-facets" : "full,scenario/generic-facets")
                                                          : (h->diag ? "diag,scenario" : "full,scenario"))
-                                      : (h->sp.feat == 1 ? (h->diag ? "diag,power" : "full,power") : (h->diag ? "diag" : "full")));
+                                      : (h->sp.feat == 1 ? (h->diag ? "diag,power" : "full,power")
+                                                         : (h->sp.feat == -1 ? (h->diag ? "diag,lds-scratch" : "full,lds-scratch") : (h->diag ? "diag" : "full"))));
     if (vgprs) *vgprs = at.numRegs;
     if (lds_bytes) *lds_bytes = (int)at.sharedSizeBytes;
     // the two-wave harmonics form launches 256-thread workgroups of 2 x 64 spacecraft x 2 halves

@@ -212,7 +212,9 @@ struct WheelV {
 //   3 = level 2 for facet sets that are not "axis-aligned with every centre on its own normal axis" (the
 //   reference's eight are): tables read at each use / loop over the facet list.  Kept out of level 2 so that the
 //   kernel the drop-in env runs carries neither their code nor their registers.
-enum { FEAT_BARE = 0, FEAT_POWER = 1, FEAT_FULL = 2, FEAT_FULLG = 3 };
+//  -1 = level 0 with the RK4 accumulator staged in LDS (BSK_FLAG_LDS_SCRATCH; the north star's "per-spacecraft
+//   RK4 scratch staged in LDS"): 15 doubles per lane leave the register file between the stages.
+enum { FEAT_LDSS = -1, FEAT_BARE = 0, FEAT_POWER = 1, FEAT_FULL = 2, FEAT_FULLG = 3 };
 template <int FEAT>
 constexpr bool is_full() { return FEAT == FEAT_FULL || FEAT == FEAT_FULLG; }
 
@@ -1029,13 +1031,35 @@ __device__ __forceinline__ void core_axpy(double a, const Core& k, const Core& x
     if constexpr (NRW > 0) o.p = axpy(a, k.p, x.p);
 }
 
+// RK4 accumulator staged in LDS (FEAT_LDSS): acc[f][lane], one 512-byte row per component and wave, every lane
+// touches only its own column (conflict-free ds_read_b64 / ds_write_b64, no synchronisation).  volatile: the
+// values must really leave the registers between the stages.
+struct AccLds {
+    double v[15][64];
+};
+typedef AccLds __attribute__((address_space(3))) * AccP;
+template <int NRW>
+__device__ __forceinline__ void acc_store(AccP A, int lane, const Core& a) {
+    volatile double __attribute__((address_space(3)))* p = &A->v[0][lane];
+    p[0 * 64] = a.r.x; p[1 * 64] = a.r.y; p[2 * 64] = a.r.z; p[3 * 64] = a.v.x; p[4 * 64] = a.v.y; p[5 * 64] = a.v.z;
+    p[6 * 64] = a.s.x; p[7 * 64] = a.s.y; p[8 * 64] = a.s.z; p[9 * 64] = a.w.x; p[10 * 64] = a.w.y; p[11 * 64] = a.w.z;
+    if constexpr (NRW > 0) { p[12 * 64] = a.p.x; p[13 * 64] = a.p.y; p[14 * 64] = a.p.z; }
+}
+template <int NRW>
+__device__ __forceinline__ void acc_load(AccP A, int lane, Core& a) {
+    const volatile double __attribute__((address_space(3)))* p = &A->v[0][lane];
+    a.r = mk(p[0 * 64], p[1 * 64], p[2 * 64]); a.v = mk(p[3 * 64], p[4 * 64], p[5 * 64]);
+    a.s = mk(p[6 * 64], p[7 * 64], p[8 * 64]); a.w = mk(p[9 * 64], p[10 * 64], p[11 * 64]);
+    if constexpr (NRW > 0) a.p = mk(p[12 * 64], p[13 * 64], p[14 * 64]);
+}
+
 // classic RK4, sequential accumulation x0 + h/6 k1 + h/3 k2 + h/3 k3 + h/6 k4, then the MRP
 // shadow-set switch once per completed step.  Motor torque and Coulomb friction are evaluated
 // from the wheel speeds at the start of the step and held through its four stages (the RW
 // effector updates both once per dyn tick, outside the equations of motion).
 template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT, class WV>
 __device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, const WV& wv, State<NRW>& x,
-                                         const double* u, V3 lext, double t0, const Env& ev) {
+                                         const double* u, V3 lext, double t0, const Env& ev, AccP acc_lds = nullptr) {
     Core y, k, yt, acc;
     y.r = x.r; y.v = x.v; y.s = x.s; y.w = x.w;
     y.p = mk(0, 0, 0);
@@ -1050,16 +1074,26 @@ __device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, const WV& w
     }
     if constexpr (NRW > 0) wv.head(tq, x.Om, T, y.p, tqj);
     const V3 rhs0 = lext - T;
+    constexpr bool LDSACC = FEAT == FEAT_LDSS;
+    AccP A = nullptr;
+    int lane = 0;
+    if constexpr (LDSACC) { A = acc_lds; lane = (int)(threadIdx.x & 63u); }
     eom<GRAV, NRW, DIAG, FEAT, SPLIT>(c, y, rhs0, T, t0, ev, 0, k);
     core_axpy<NRW>(c.h6, k, y, acc);
+    if constexpr (LDSACC) acc_store<NRW>(A, lane, acc);
     core_axpy<NRW>(c.h2, k, y, yt);
     eom<GRAV, NRW, DIAG, FEAT, SPLIT>(c, yt, rhs0, T, t0 + c.h2, ev, 1, k);
+    if constexpr (LDSACC) acc_load<NRW>(A, lane, acc);
     core_axpy<NRW>(c.h3, k, acc, acc);
+    if constexpr (LDSACC) acc_store<NRW>(A, lane, acc);
     core_axpy<NRW>(c.h2, k, y, yt);
     eom<GRAV, NRW, DIAG, FEAT, SPLIT>(c, yt, rhs0, T, t0 + c.h2, ev, 1, k);
+    if constexpr (LDSACC) acc_load<NRW>(A, lane, acc);
     core_axpy<NRW>(c.h3, k, acc, acc);
+    if constexpr (LDSACC) acc_store<NRW>(A, lane, acc);
     core_axpy<NRW>(c.h, k, y, yt);
     eom<GRAV, NRW, DIAG, FEAT, SPLIT>(c, yt, rhs0, T, t0 + c.h, ev, 2, k);
+    if constexpr (LDSACC) acc_load<NRW>(A, lane, acc);
     core_axpy<NRW>(c.h6, k, acc, yt);
     const V3 dw = yt.w - y.w;
 #pragma unroll

@@ -30,11 +30,18 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 __device__ __forceinline__ int wave_min_uniform(int v) {
+    // every lane holds the same value unless a masked reset staggered the FSW phases inside this wave: one ballot
+    // settles the common case, the shuffle tree (six trips through the LDS crossbar) only runs when lanes differ
+    const int first = __builtin_amdgcn_readfirstlane(v);
+    if (__builtin_amdgcn_ballot_w64(v != first) == 0) return first;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
     return __builtin_amdgcn_readfirstlane(v);
 }
 
+#ifndef BSK_LDSS_WAVES
+#define BSK_LDSS_WAVES 3
+#endif
 #ifndef BSK_MIN_WAVES
 #define BSK_MIN_WAVES 1
 #endif
@@ -43,7 +50,7 @@ __device__ __forceinline__ int wave_min_uniform(int v) {
 // sums through LDS: twice the waves per SIMD at the same batch size, so one wave's loads and scalar
 // instructions overlap with the other's FMAs.  Only wave 0 stores.
 template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT>
-__global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : BSK_MIN_WAVES) void step_kernel(const StepArgs<NRW, DIAG> a) {
+__global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT_LDSS ? BSK_LDSS_WAVES : BSK_MIN_WAVES)) void step_kernel(const StepArgs<NRW, DIAG> a) {
     const HotCfg<NRW, DIAG>& c = a.hot;
     const ColdCfg* __restrict__ cold = a.cold;
 #if defined(BSK_ABLATE) && BSK_ABLATE == 1
@@ -99,7 +106,12 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : BSK_MIN_WAVES
     // wheel geometry: parked in VGPRs, except at the full-scenario levels where it is read from LDS at each use
     // wheel geometry: parked in VGPRs, except at the full-scenario levels where it comes through the DPP broadcast
     // table (bsk_device.hpp: KTab)
-    std::conditional_t<FULL, WheelDpp<NRW>, WheelV<NRW>> wv;
+#ifndef BSK_BARE_DPP
+#define BSK_BARE_DPP 0
+#endif
+    // (the LDS-scratch level is after a third wave per SIMD: it takes the 36 registers of the wheel geometry too)
+    constexpr bool WDPP = FULL || (FEAT == FEAT_LDSS && NRW > 0) || (BSK_BARE_DPP && FEAT == FEAT_BARE && NRW > 0);
+    std::conditional_t<WDPP, WheelDpp<NRW>, WheelV<NRW>> wv;
 #if defined(BSK_ABLATE) && BSK_ABLATE == 2
     const int substeps_eff = 0;   // loads + epilogue stores, no RK4 / FSW
 #else
@@ -119,12 +131,17 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : BSK_MIN_WAVES
         L->sun[0][lane] = sg.sun.x; L->sun[1][lane] = sg.sun.y; L->sun[2][lane] = sg.sun.z;
         if (lane == 0) L->qcount = 0;
     }
+    AccP accp = nullptr;
+    if constexpr (FEAT == FEAT_LDSS) accp = (AccP)lds_dyn + (threadIdx.x >> 6);
     KTab kt;
     if constexpr (FULL) {
         // lane l of every 16-lane row fetches entry l & 15 of the three table rows (three coalesced loads)
         const int l16 = lane & 15;
         kt.a = cold->kt[l16]; kt.b = cold->kt[16 + l16]; kt.c = cold->kt[32 + l16];
         wv.ta = kt.a; wv.tb = kt.b;
+    } else if constexpr (WDPP) {
+        const int l16 = lane & 15;
+        wv.ta = cold->kt[l16]; wv.tb = cold->kt[16 + l16];
     } else {
         wv.load(c);
     }
@@ -207,7 +224,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : BSK_MIN_WAVES
             // advance together to the nearest FSW tick of any of them.
             // (the full-scenario levels take their wave-uniform constants through DPP broadcasts: same requirement)
 #if !(defined(BSK_ABLATE) && BSK_ABLATE == 5)   // 5: timing only, per-lane trip count
-            if constexpr (GRAV == BSK_GRAV_SH || FULL) m = wave_min_uniform(m);
+            if constexpr (GRAV == BSK_GRAV_SH || WDPP) m = wave_min_uniform(m);
 #endif
             phase = (phase + m == fsw_every) ? 0 : phase + m;
         }
@@ -232,7 +249,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : BSK_MIN_WAVES
                     if (ev.thr_on) thr_masks(ev);
                 }
             }
-            rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT>(c, wv, x, u, lext, (double)tick * c.h, ev);
+            rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT>(c, wv, x, u, lext, (double)tick * c.h, ev, accp);
             if constexpr (POWER) power_tick<FULL>(a.power, sg, x.r, x.s, L, t, lane, kt.c);
         }
 #if !(defined(BSK_ABLATE) && BSK_ABLATE == 4)   // 4: timing only, no drain / battery replay
@@ -522,7 +539,8 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     if (SPLIT == 5) block = 256;
     const int grid = SPLIT == 5 ? (b.n + 127) / 128 : (b.n + block - 1) / block;
     // the power system keeps a per-wave tick record and penumbra queue in dynamic LDS (bsk_device.hpp: PowerLds)
-    const size_t lds = FEAT >= FEAT_POWER ? sizeof(PowerLds) * (size_t)(block / 64) : 0;
+    const size_t lds = FEAT >= FEAT_POWER ? sizeof(PowerLds) * (size_t)(block / 64)
+                                           : (FEAT == FEAT_LDSS ? sizeof(AccLds) * (size_t)(block / 64) : 0);
     // hipExtLaunchKernelGGL stamps ev0/ev1 from the dispatch packet itself (no marker packets), so
     // their difference is the kernel's own duration, as rocprofv3 --kernel-trace reports it.
     if (lds > 48 * 1024) {   // the two-wave harmonics form with the power system: 4 waves x 29 KB of dynamic LDS
@@ -549,7 +567,16 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
 #undef BSK_VARIANTS_P
 #define BSK_VARIANTS_P(X, P) X(BSK_GRAV_PM_J2, 4, true, P) X(BSK_GRAV_PM_J2, 3, true, P)
 #endif
-#define BSK_VARIANTS(X) BSK_VARIANTS_P(X, 0) BSK_VARIANTS_P(X, 1) BSK_VARIANTS_P(X, 2) BSK_VARIANTS_P(X, 3)
+#ifdef BSK_FAST_BUILD
+#define BSK_VARIANTS_L(X) X(BSK_GRAV_PM_J2, 4, true, -1) X(BSK_GRAV_PM_J2, 3, true, -1)
+#else
+#define BSK_VARIANTS_L(X)                                                                                   \
+    X(BSK_GRAV_PM, 0, true, -1) X(BSK_GRAV_PM, 3, true, -1) X(BSK_GRAV_PM, 4, true, -1)                      \
+    X(BSK_GRAV_PM_J2, 0, true, -1) X(BSK_GRAV_PM_J2, 3, true, -1) X(BSK_GRAV_PM_J2, 4, true, -1)             \
+    X(BSK_GRAV_PM, 0, false, -1) X(BSK_GRAV_PM, 3, false, -1) X(BSK_GRAV_PM, 4, false, -1)                   \
+    X(BSK_GRAV_PM_J2, 0, false, -1) X(BSK_GRAV_PM_J2, 3, false, -1) X(BSK_GRAV_PM_J2, 4, false, -1)
+#endif
+#define BSK_VARIANTS(X) BSK_VARIANTS_P(X, 0) BSK_VARIANTS_P(X, 1) BSK_VARIANTS_P(X, 2) BSK_VARIANTS_P(X, 3) BSK_VARIANTS_L(X)
 
 hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams& p, const StepBuffers& b, int block,
                        hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {

@@ -20,8 +20,8 @@ state are resident in HBM when the timed region starts.
 
 Timing.  ``value`` / ``ms_per_step`` come from the wall clock around EXACTLY ``--steps`` launches that
 carry no timestamps (nothing but the launches is enqueued between the two synchronisations), so they do
-not depend on ``--steps``.  ``roofline.kernel_us`` comes from a separate, shorter pass afterwards in which
-every launch is dispatch-stamped (hipExtLaunchKernelGGL start/stop events on the launch stream).
+not depend on ``--steps``.  ``roofline.kernel_us`` comes from a separate pass afterwards: dispatch stamps
+(hipExtLaunchKernelGGL start/stop events on the launch stream) on a sample of the launches of a back-to-back burst.
 
 Besides the contract keys the JSON line carries ``roofline`` (dominant kernel: HBM-bound at K = 1 with
 340 algorithmic bytes per env-step; fp64-issue-bound for K >> 1, the harmonics and the
@@ -114,23 +114,26 @@ def timed_run(prop, d_act_ptr, substeps, steps, warmup, barrier, device_sync):
     return t1 - t0
 
 
-def kernel_time(prop, d_act_ptr, substeps, launches, lead=4):
-    """Duration of the step kernel over ``launches`` dispatch-stamped launches (its own pass): -> (mean ms, n,
-    stats dict).  ``lead`` stamped launches go first and are not counted (the transition from un-stamped
-    back-to-back stepping; their events are simply re-armed)."""
+def kernel_time(prop, d_act_ptr, substeps, launches, stride=None):
+    """Duration of the step kernel from dispatch stamps, in its own pass after the wall-timed region:
+    -> (mean ms, launches counted, stats dict).
+
+    Short kernels are sampled INSIDE a back-to-back burst: a pair of launches is stamped every ``stride`` launches
+    and the second of each pair counted (bsk_profile_set_stride), ``launches`` samples in all.  Stamping every
+    launch of a pass that follows a synchronisation measures something else — each kernel then starts on an idle
+    device after the ~5 us stamping gap, and reads up to 60 % long once the clocks have settled after a long
+    burst.  Long kernels (many sub-steps per launch) are stamped one by one (stride 1)."""
+    if stride is None:
+        stride = 16 if substeps < 16 else 1
     prop.sync()
-    if lead:
-        prop.profile_begin(lead, stride=1)
-        for _ in range(lead):
-            prop.step_device(d_act_ptr, substeps)
-        prop.profile_end()
-    prop.profile_begin(launches, stride=1)
-    for _ in range(launches):
+    prop.profile_begin(launches + 2, stride=stride)
+    for _ in range(launches * stride + (2 if stride > 1 else 0)):
         prop.step_device(d_act_ptr, substeps)
     if hasattr(prop, "profile_end_samples"):
         mean_ms, samples = prop.profile_end_samples()
         srt = sorted(float(x) for x in samples)
-        stats = {"median_us": srt[len(srt) // 2] * 1e3, "min_us": srt[0] * 1e3, "max_us": srt[-1] * 1e3} if srt else {}
+        stats = {"median_us": srt[len(srt) // 2] * 1e3, "min_us": srt[0] * 1e3, "max_us": srt[-1] * 1e3,
+                 "stamp_stride": stride} if srt else {}
         return mean_ms, len(srt), stats
     mean_ms, n = prop.profile_end()
     return mean_ms, n, {}
@@ -227,7 +230,7 @@ def hbm_roofline(n, kernel_s, info, traffic_bytes, traffic_src, launches):
             "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS, "copy_ceiling": HBM_COPY_CEILING_GBS,
             "traffic": traffic_bytes, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
             "algorithmic_bytes": BYTES_PER_ENV_STEP * n, "kernel": info["name"], "kernel_us": kernel_s * 1e6,
-            "launches_timed": launches, "stamping": "separate pass after the timed region, every launch stamped",
+            "launches_timed": launches, "stamping": "separate pass after the timed region: pairs stamped inside a back-to-back burst, second of each pair counted",
             "bytes_per_env_step": BYTES_PER_ENV_STEP, "vgprs": info["vgprs"], "lds_bytes": info["lds_bytes"],
             "block": info["block"], "grid": info["grid"]}
 
@@ -380,7 +383,7 @@ def main():
         # reference-faithful env step: 180 s of sim time = 1 800 RK4 sub-steps, 180 FSW updates
         ksteps = 5
         el2 = timed_run(prop, d_act.data_ptr(), 1800, ksteps, 1, barrier, sync)
-        km2, _, _ = kernel_time(prop, d_act.data_ptr(), 1800, 3, lead=0)
+        km2, _, _ = kernel_time(prop, d_act.data_ptr(), 1800, 3)
         extra["k1800"] = {"env_steps_per_s": n * ksteps / el2, "rk4_substeps_per_s": n * ksteps * 1800 / el2,
                           "kernel_ms": km2, "ms_per_step": el2 / ksteps * 1e3,
                           "roofline": fp64_roofline("bare", float(n) * 1800, km2 * 1e-3, info)}

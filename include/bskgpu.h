@@ -48,7 +48,9 @@ enum { BSK_GRAV_PM = 0, BSK_GRAV_PM_J2 = 1, BSK_GRAV_SH = 2 };
 #define BSK_FLAG_DESAT 0x4u          /* action 2 fires the thruster octet (…Simulator.py:574-588) */
 #define BSK_FLAG_DRAG 0x8u           /* exponential atmosphere + facet drag (…Simulator.py:265-284) */
 #define BSK_FLAG_AUTO_RESET 0x10u    /* device-side masked auto-reset from a staged IC pool */
-#define BSK_FLAG_LDS_SCRATCH 0x20u   /* stage the RK4 scratch in LDS instead of VGPRs */
+#define BSK_FLAG_LDS_SCRATCH 0x20u   /* bare propagator only: stage the RK4 accumulator (15 doubles per spacecraft) in
+                                        LDS between the stages instead of VGPRs: 3 waves per SIMD instead of 2.
+                                        Same results bit for bit; timings in DESIGN.md §4 */
 
 /* State field indices of the SoA state block, bsk_get_state / bsk_set_state / bsk_reset `ic`.
  * n_fields = BSK_NF_BASE + n_rw (wheel speeds) + BSK_NF_TAIL.                                   */

@@ -87,9 +87,11 @@ def test_timed_region_is_unstamped_and_counts_exactly_k_steps():
     assert (b0, s0, s1, b1) == ("barrier", "devsync", "devsync", "barrier") and i0 == j0 and j1 - j0 == 20 and i1 == j1
     assert p.log[j0:j1] == ["step"] * 20
     q = _FakeProp()
-    ms, n, stats = b.kernel_time(q, 0, 1, 7, lead=2)
-    assert q.log[:2] == ["sync", "profile_begin(2,1)"] and q.log.count("step") == 9 and q.log[-1] == "profile_end"
-    assert q.log.index("profile_begin(7,1)") == 5
+    ms, n, stats = b.kernel_time(q, 0, 1, 7)                 # short kernel: sampled inside a burst, stride 16
+    assert q.log[:2] == ["sync", "profile_begin(9,16)"] and q.log.count("step") == 7 * 16 + 2 and q.log[-1] == "profile_end"
+    q = _FakeProp()
+    b.kernel_time(q, 0, 1800, 3)                             # long kernel: every launch stamped
+    assert q.log[:2] == ["sync", "profile_begin(5,1)"] and q.log.count("step") == 3
 
 
 def test_self_launch_composes_the_launcher_as_a_child_and_relays():
