@@ -594,11 +594,6 @@ __device__ __forceinline__ double fmac_bc(double acc, double tab, double b) {
     asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tab), "v"(b), "n"(L));
     return acc;
 }
-__device__ __forceinline__ double mul_o(double a, double b) {
-    double r;
-    asm volatile("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
 
 // chunks in flight = chunks per loop body (the host pads the stream to whole bodies + slack)
 constexpr int SH_RING = 8;
@@ -669,9 +664,10 @@ __device__ __forceinline__ V3 gravity_sh_dpp(const Hot& c, V3 p) {
     int M = m_lo, rem = (d1 - m_lo + 2) >> 1;   // chunks of column M: (d1 - M + 2) / 2
 
     // One entry = the recursion step (two dependent ops: fmac -> mul -> next entry's fmac) interleaved with
-    // the six coefficient sums of the PREVIOUS entry, so that no fp64 op waits on its predecessor's result
-    // and the compiler has no hazard to pad with s_nop (a DPP FMA must not read a VGPR written by one of the
-    // two preceding instructions, a plain VALU read of a DPP-FMA result wants five in between).
+    // the six coefficient sums of the PREVIOUS entry, so that no fp64 op waits on its predecessor's result.
+    // The DPP FMAs are pinned in this order (asm volatile); the two plain multiplies are left to the compiler's
+    // scheduler, which places them so that no hazard padding is needed (written as pinned asm, in the slots the
+    // distances seem to ask for, each chunk carried two s_nop: 267 -> 256 us at 65 536 spacecraft).
     // Bn = -rho^2 Bt_(L-2) is prepared one entry ahead; the entry opens with the instruction that needs
     // the chunk just loaded, so one s_waitcnt serves the whole chunk.
     // Bp = the previous entry's Bt (its sums are still pending), (qp, OP) = where its coefficients sit.
@@ -681,9 +677,9 @@ __device__ __forceinline__ V3 gravity_sh_dpp(const Hot& c, V3 p) {
         const double Pold = P;
         const double B = fmac_bc<oc + 0>(Bn, qc, m1);
         X1 = fmac_bc<op + 2>(X1, qp, Bp); X2 = fmac_bc<op + 3>(X2, qp, Bp);
-        Bn = mul_o(nrr, Pold);
+        Bn = nrr * Pold;
         Y1 = fmac_bc<op + 4>(Y1, qp, Bp); Y2 = fmac_bc<op + 5>(Y2, qp, Bp);
-        m1 = mul_o(ur, B);      // five instructions after B (a VALU read of a DPP-FMA result needs that distance)
+        m1 = ur * B;
         Z1 = fmac_bc<op + 6>(Z1, qp, Bp); Z2 = fmac_bc<op + 7>(Z2, qp, Bp);   // two before the next entry reads m1
         P = B;
         Bp = B;

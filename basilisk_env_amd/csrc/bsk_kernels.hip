@@ -565,7 +565,11 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     X(BSK_GRAV_PM_J2, 0, false, P) X(BSK_GRAV_PM_J2, 3, false, P) X(BSK_GRAV_PM_J2, 4, false, P)
 #ifdef BSK_FAST_BUILD   // ISA inspection / A-B builds: only the J2 + 4-wheel (bench) and J2 + 3-wheel (env) kernels
 #undef BSK_VARIANTS_P
+#if BSK_FAST_BUILD == 2  // ... or only the harmonics kernel of the config-5 bench
+#define BSK_VARIANTS_P(X, P) X(BSK_GRAV_SH, 4, true, P)
+#else
 #define BSK_VARIANTS_P(X, P) X(BSK_GRAV_PM_J2, 4, true, P) X(BSK_GRAV_PM_J2, 3, true, P)
+#endif
 #endif
 #ifdef BSK_FAST_BUILD
 #define BSK_VARIANTS_L(X) X(BSK_GRAV_PM_J2, 4, true, -1) X(BSK_GRAV_PM_J2, 3, true, -1)

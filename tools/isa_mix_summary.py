@@ -26,7 +26,7 @@ for key, sub in SUB.items():
     w = rec["SQ_WAVES"] * sub
     m = {"fma": rec["SQ_INSTS_VALU_FMA_F64"] / w, "mul": rec["SQ_INSTS_VALU_MUL_F64"] / w,
          "add": rec["SQ_INSTS_VALU_ADD_F64"] / w, "trans": rec["SQ_INSTS_VALU_TRANS_F64"] / w,
-         "substeps_per_launch": sub, "waves": rec["SQ_WAVES"]}
+         "substeps_per_launch": sub, "waves": rec["SQ_WAVES"], "lanes_per_env": rec["SQ_WAVES"] * 64.0 / 65536.0}
     if "SQ_INSTS_VALU" in rec:
         m.update({"valu": rec["SQ_INSTS_VALU"] / w, "salu": rec["SQ_INSTS_SALU"] / w,
                   "valu_active_over_wave_cycles": rec["SQ_ACTIVE_INST_VALU"] / rec["SQ_WAVE_CYCLES"],
