@@ -132,9 +132,16 @@ def kernel_time(prop, d_act_ptr, substeps, launches, stride=None):
     if hasattr(prop, "profile_end_samples"):
         mean_ms, samples = prop.profile_end_samples()
         srt = sorted(float(x) for x in samples)
-        stats = {"median_us": srt[len(srt) // 2] * 1e3, "min_us": srt[0] * 1e3, "max_us": srt[-1] * 1e3,
-                 "stamp_stride": stride} if srt else {}
-        return mean_ms, len(srt), stats
+        if not srt:
+            return mean_ms, 0, {}
+        # the average over the samples with the top and bottom tenth set aside: a handful of stamped launches read
+        # two to four times long (the stamp's own marker traffic; the un-stamped loop's wall clock per step, an upper
+        # bound of the true average, sits below the plain mean whenever one of them is in the sample)
+        cut = len(srt) // 10
+        core = srt[cut:len(srt) - cut] if len(srt) >= 10 else srt
+        stats = {"mean_all_us": mean_ms * 1e3, "median_us": srt[len(srt) // 2] * 1e3, "min_us": srt[0] * 1e3,
+                 "max_us": srt[-1] * 1e3, "stamp_stride": stride, "averaging": "mean of the middle 80 % of the samples"}
+        return sum(core) / len(core), len(srt), stats
     mean_ms, n = prop.profile_end()
     return mean_ms, n, {}
 
@@ -393,9 +400,10 @@ def main():
     extra = {}
     if world == 1 and not a.no_extra and not sh and a.scenario == "bare" and not a.lds_scratch:
         # reference-faithful env step: 180 s of sim time = 1 800 RK4 sub-steps, 180 FSW updates
-        ksteps = 5
-        el2 = timed_run(prop, d_act.data_ptr(), 1800, ksteps, 1, barrier, sync)
-        km2, _, _ = kernel_time(prop, d_act.data_ptr(), 1800, 3)
+        # (the first few 2 ms launches after the K = 1 burst run while the clocks settle: five warm-up steps)
+        ksteps = 10
+        el2 = timed_run(prop, d_act.data_ptr(), 1800, ksteps, 5, barrier, sync)
+        km2, _, _ = kernel_time(prop, d_act.data_ptr(), 1800, 5)
         extra["k1800"] = {"env_steps_per_s": n * ksteps / el2, "rk4_substeps_per_s": n * ksteps * 1800 / el2,
                           "kernel_ms": km2, "ms_per_step": el2 / ksteps * 1e3,
                           "roofline": fp64_roofline("bare", float(n) * 1800, km2 * 1e-3, info)}

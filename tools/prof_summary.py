@@ -9,6 +9,7 @@ for sub in sorted(os.listdir(d)):
     if not os.path.isdir(p):
         continue
     ks = glob.glob(os.path.join(p, "*", "*_kernel_stats.csv"))
+    ks = [k for k in ks if os.path.getsize(k) > 0]
     if ks:
         rows = list(csv.DictReader(open(ks[0])))
         out[sub] = {"kernel_stats": [{k: r[k] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs", "Percentage")} for r in rows[:4]]}

@@ -1,12 +1,41 @@
 #!/bin/bash
-# One GPU-box pass of the round's evidence: GPU tests, the default bench line, the 2-rank rehearsal of the
-# self-launch path on one card, then the profile passes.  Usage: tools/round.sh TAG
+# One GPU-box pass of the round's evidence: GPU tests, bench lines, the 2-rank rehearsal of the self-launch path on
+# one card, kernel traces and counter passes.  Usage: tools/round.sh TAG   (outputs under gpurun_out/TAG/)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r02}
-O=$R/gpurun_out
+O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-python -m pytest tests -m gpu -x -q > $O/gputest_$TAG.log 2>&1; tail -3 $O/gputest_$TAG.log
-python bench.py > $O/bench_$TAG.json 2> $O/bench_$TAG.err && echo bench ok
-python bench.py --steps 20 --warmup 5 --no-extra --no-cpu-baseline > $O/bench_${TAG}_steps20.json 2>> $O/bench_$TAG.err && echo bench20 ok
-BENCH_REHEARSAL=1 python bench.py --gpus 2 --steps 200 --warmup 20 > $O/bench_${TAG}_rehearsal2.json 2> $O/bench_${TAG}_rehearsal2.err && echo rehearsal ok
+python -m pytest tests -m gpu -x -q > $O/gputest.log 2>&1; tail -2 $O/gputest.log
+python bench.py > $O/bench_default.json 2> $O/bench.err && echo bench ok
+python bench.py --steps 20 --warmup 5 > $O/bench_steps20.json 2>> $O/bench.err && echo bench20 ok
+BENCH_REHEARSAL=1 python bench.py --gpus 2 --steps 200 --warmup 20 > $O/bench_rehearsal2.json 2> $O/bench_rehearsal2.err && echo rehearsal ok
+for sc in power full; do
+  python bench.py --no-cpu-baseline --no-extra --scenario $sc --steps 500 --warmup 50 > $O/bench_${sc}_k1.json 2>> $O/bench.err
+  python bench.py --no-cpu-baseline --no-extra --scenario $sc --substeps 1800 --steps 20 --warmup 10 > $O/bench_${sc}_k1800.json 2>> $O/bench.err
+done
+python bench.py --no-cpu-baseline --gravity sh --steps 2000 --warmup 300 > $O/bench_sh.json 2>> $O/bench.err && echo sh ok
+cd /tmp && export TMPDIR=/tmp
+B="python3 $R/bench.py --no-cpu-baseline --no-extra"
+prof() { tag=$1; shift; timeout -k 10 300 rocprofv3 "$@" > $O/$tag.log 2>&1 && echo $tag ok; }
+SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"
+prof kt_65k --kernel-trace --stats --output-format csv -d $O/kt_65k -- $B
+prof fetch_65k --pmc FETCH_SIZE --output-format csv -d $O/fetch_65k -- $B --steps 50
+prof write_65k --pmc WRITE_SIZE --output-format csv -d $O/write_65k -- $B --steps 50
+prof sq_65k --pmc $SQ --output-format csv -d $O/sq_65k -- $B --steps 50
+BL="$B --envs 4194304 --steps 20 --warmup 3"
+prof kt_4m --kernel-trace --stats --output-format csv -d $O/kt_4m -- $BL
+prof fetch_4m --pmc FETCH_SIZE --output-format csv -d $O/fetch_4m -- $BL
+prof write_4m --pmc WRITE_SIZE --output-format csv -d $O/write_4m -- $BL
+prof sq_4m --pmc $SQ --output-format csv -d $O/sq_4m -- $BL
+BK="$B --substeps 1800 --steps 20 --warmup 10"
+prof kt_k1800 --kernel-trace --stats --output-format csv -d $O/kt_k1800 -- $BK
+prof sq_k1800 --pmc $SQ --output-format csv -d $O/sq_k1800 -- $BK
+BF="$B --scenario full --substeps 1800 --steps 20 --warmup 10"
+prof kt_full_k1800 --kernel-trace --stats --output-format csv -d $O/kt_full_k1800 -- $BF
+prof sq_full_k1800 --pmc $SQ --output-format csv -d $O/sq_full_k1800 -- $BF
+BS="$B --gravity sh --steps 400 --warmup 100"
+prof kt_sh --kernel-trace --stats --output-format csv -d $O/kt_sh -- $BS
+prof sq_sh --pmc $SQ --output-format csv -d $O/sq_sh -- $BS
+cd $R
+python3 tools/prof_summary.py $O > $O/summary_latest.json 2>/dev/null && echo summary ok
