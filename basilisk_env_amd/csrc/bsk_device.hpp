@@ -71,6 +71,29 @@ __device__ __forceinline__ double rcp_nr(double x) {
     e = fma(-x, y, 1.0);
     return fma(y, e, y);
 }
+// exp(x) for the atmosphere's density (|x| far from the overflow range; underflows to 0 through ldexp): one
+// range reduction x = n ln2 + r, |r| <= ln2 / 2, and the degree-13 Taylor polynomial (truncation 4e-18): 19
+// instructions against ~35 of the library routine with its special-case handling.
+__device__ __forceinline__ double exp_fast(double x) {
+    const double n = __builtin_rint(x * 1.4426950408889634074);
+    double r = fma(-n, 6.93147180369123816490e-01, x);
+    r = fma(-n, 1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
 // sqrt(x) for x >= 0 (0 -> 0): x * rsqrt(x)
 __device__ __forceinline__ double sqrt_nr(double x) { return x > 0.0 ? x * rsqrt_nr(x) : 0.0; }
 
@@ -308,6 +331,18 @@ __device__ __forceinline__ double angle_xy(double x, double y, double a) {
     return fma(k, r, base);
 }
 
+// The reference's lens-area formula as published, for the geometries the fast path below does not cover (solar
+// disc not small against the planet's: never in LEO).  Kept out of line: its library calls (asin / acos with all
+// their range branches) would otherwise set the register allocation of the drain loop that inlines the fast path.
+__device__ __attribute__((noinline)) double percent_shadow_generic(double sa, double sb, double cc) {
+    const double PI = 3.14159265358979323846;
+    const double a = asin(sa), b = asin(sb), c = acos(cc);
+    if (c < a - b) return 1.0 - (b * b) / (a * a);                              // annular
+    const double x = (c * c + a * a - b * b) / (2.0 * c), y = sqrt(fmax(a * a - x * x, 0.0));
+    const double area = a * a * acos(x / a) + b * b * acos((c - x) / b) - c * y;
+    return 1.0 - area / (PI * a * a);
+}
+
 // visible fraction of the solar disc inside the shadow cones: total eclipse is decided on cosines
 // (no inverse trigonometry); only partial / annular phases reach the inverse functions.
 // The reference's lens-area formula is  1 - [a^2 acos(x/a) + b^2 acos((c-x)/b) - c y] / (pi a^2),
@@ -340,11 +375,7 @@ __device__ __forceinline__ double percent_shadow(const PowerCfg& pc, V3 r_HB, V3
         const double area = fma(a2, th1, fma(b * b, t2, -(d * y)));
         return 1.0 - area * rcp_nr(PI * a2);
     }
-    const double a = asin(sa), b = asin(sb), c = acos(cc);
-    if (c < a - b) return 1.0 - (b * b) / (a * a);                              // annular
-    const double x = (c * c + a * a - b * b) / (2.0 * c), y = sqrt(fmax(a * a - x * x, 0.0));
-    const double area = a * a * acos(x / a) + b * b * acos((c - x) / b) - c * y;
-    return 1.0 - area / (PI * a * a);
+    return percent_shadow_generic(sa, sb, cc);
 }
 
 __device__ __forceinline__ double shadow_factor(const PowerCfg& pc, const SunGeom& g, V3 r) {

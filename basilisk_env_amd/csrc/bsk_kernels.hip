@@ -238,7 +238,14 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
                 if (drag_cfg) {   // exponentialAtmosphere, refreshed once per dyn tick
                     const double r2 = dot(x.r, x.r), rm = r2 * rsqrt_nr(r2);
                     // rho0 exp(-(|r| - Re)/H) with the exponent as one FMA on table constants: Re/H - |r|/H
+#ifndef BSK_EXP_FAST
+#define BSK_EXP_FAST 1
+#endif
+#if BSK_EXP_FAST
+                    const double rho = mul_k<KC_RHO0>(kt.c, exp_fast(fmac_k<KC_NIH>(get_k<KC_REQIH>(kt.c), kt.c, rm)));
+#else
                     const double rho = mul_k<KC_RHO0>(kt.c, exp(fmac_k<KC_NIH>(get_k<KC_REQIH>(kt.c), kt.c, rm)));
+#endif
                     ev.rho = rho >= a.extra.rho_skip ? rho : 0.0;   // below it |a_drag| < 1e-19 m/s^2: dropped
                     ev.drag_on = __builtin_amdgcn_ballot_w64(ev.rho != 0.0) != 0;   // any lane of the wave inside the atmosphere
                 }
