@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Small-batch latency of the drop-in env path (the reference itself runs ONE environment): wall time of one 180 s
+env step (1 800 RK4 sub-steps, full scenario) for N = 1 ... 65 536 spacecraft through the Python binding, and of
+leoPowerAttEnv.reset() with the pooled device handle.  Usage (GPU box): python tools/latency.py"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from basilisk_env_amd._lib import FLAG_DESAT, FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY, GRAV_PM  # noqa: E402
+from basilisk_env_amd.envs import leoPowerAttEnv  # noqa: E402
+from basilisk_env_amd.simulators.dynamics import BatchedPropagator, default_config  # noqa: E402
+from basilisk_env_amd.simulators.initial_conditions.batch import sample_ic_batch  # noqa: E402
+
+out = {"env_step_ms": {}}
+for n in (1, 64, 1024, 8192, 65536):
+    cfg = default_config(3, GRAV_PM)
+    cfg.flags |= FLAG_POWER | FLAG_SUN_THIRD_BODY | FLAG_DRAG | FLAG_DESAT
+    p = BatchedPropagator(cfg, n)
+    p.reset(sample_ic_batch(n, 3, seed=1))
+    act = np.zeros(n, np.int32)
+    p.step(act, 1800)
+    p.get_obs()
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        p.step(act, 1800)
+        p.get_obs()
+        ts.append(time.perf_counter() - t0)
+    out["env_step_ms"][n] = round(min(ts) * 1e3, 3)
+    p.close()
+env = leoPowerAttEnv()
+env.seed(1)
+t0 = time.perf_counter()
+env.reset()
+first = time.perf_counter() - t0
+ts = []
+for _ in range(10):
+    t0 = time.perf_counter()
+    env.reset()
+    ts.append(time.perf_counter() - t0)
+t0 = time.perf_counter()
+for _ in range(5):
+    env.step(0)
+out["single_env"] = {"first_reset_ms": round(first * 1e3, 3), "pooled_reset_ms": round(min(ts) * 1e3, 3),
+                     "step_ms": round((time.perf_counter() - t0) / 5 * 1e3, 3)}
+env.close()
+print(json.dumps(out))
