@@ -304,7 +304,9 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    # under a launcher (WORLD_SIZE set) the process group is initialised even for a single rank, so that the
+    # collective legs below run on the real RCCL backend wherever the bench is launched the multi-GPU way
+    if world > 1 or "WORLD_SIZE" in os.environ:
         import torch.distributed as dist
         if rehearsal:
             dist.init_process_group("gloo")
@@ -418,7 +420,7 @@ def main():
         extra["large_n"] = {"envs": nl, "env_steps_per_s": nl * 50 / el3,
                             "roofline": hbm_roofline(nl, km3 * 1e-3, big.kernel_info(), tb, ts, nl3)}
         big.close()
-    if world > 1 and not a.no_extra and not sh and a.scenario == "bare":
+    if dist is not None and not a.no_extra and not sh and a.scenario == "bare" and not a.lds_scratch:
         # BASELINE configs[3]: 131 072 envs per GPU (1 048 576 on 8), config-3 physics, + the observation exchange
         n3 = 131072
         p3 = BatchedPropagator(cfg, n3, device=local)

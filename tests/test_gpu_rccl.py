@@ -44,3 +44,29 @@ def test_rccl_gather_single_rank(tmp_path):
     assert np.abs(full - obs).max() < 1e-11
     assert np.array_equal(np.load(tmp_path / "obs_root.npy"), full)
     assert abs(np.load(tmp_path / "rew_sum.npy")[0] - rew.sum()) < 1e-10
+
+
+def test_bench_collective_legs_on_rccl_single_rank(tmp_path):
+    """bench.py under torch.distributed.run with ONE rank: the process group is RCCL (backend nccl), so the
+    observation-exchange legs (gather to rank 0, all-gather, direct D2H) and the configs[3] / strong-scaling extras
+    run on the real backend — the N > 1 control flow itself is rehearsed over gloo (BENCH_REHEARSAL) and in the
+    CPU tests."""
+    import json
+    root = os.path.dirname(HERE)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "50", "--warmup", "5",
+           "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("BENCH_REHEARSAL", None)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    g = d["gather"]
+    assert g["gather_to_rank0_ms"] > 0 and g["all_gather_ms"] > 0 and g["direct_d2h_per_gpu_ms"] > 0
+    assert g["shard_bytes"] == 5 * 65536 * 8
+    x = d["extra"]
+    assert "1048576" not in x["config3"]["workload"] and "131072 per GPU" in x["config3"]["workload"]
+    assert x["config3"]["gather"]["shard_bytes"] == 5 * 131072 * 8
+    assert x["strong_65536_total"]["k1800_env_steps_per_s"] > 1e6
