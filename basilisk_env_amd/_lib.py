@@ -6,7 +6,7 @@ visible, the product raises (:class:`BskGpuUnavailable`); there is no CPU or PyT
 import ctypes as C
 import os
 
-BSK_ABI_VERSION = 3
+BSK_ABI_VERSION = 4
 BSK_MAX_RW = 4
 BSK_MAX_THR = 8
 
@@ -16,7 +16,7 @@ DONE_LENGTH, DONE_WHEELS, DONE_BATTERY, DONE_ORBIT = 1, 2, 4, 8
 
 # state field offsets (include/bskgpu.h)
 F_R, F_V, F_SIGMA, F_OMEGA, NF_BASE = 0, 3, 6, 9, 12
-T_LEXT, T_UCMD, T_CHARGE, T_THR_REM, T_THR_LIM, T_THR_T0, T_THR_CNT, T_UPEND, NF_TAIL = 0, 3, 7, 8, 16, 24, 25, 26, 30
+T_LEXT, T_UCMD, T_CHARGE, T_THR_REM, T_THR_LIM, T_THR_T0, T_THR_CNT, T_UPEND, T_SBR, NF_TAIL = 0, 3, 7, 8, 16, 24, 25, 26, 30, 31
 
 
 def n_fields(n_rw):
@@ -41,7 +41,7 @@ class BskConfig(C.Structure):
     _fields_ = [
         ("abi_version", u32), ("struct_size", u32),
         ("dt", d), ("fsw_every", i32), ("gravity_model", i32), ("sh_degree", i32), ("n_rw", i32),
-        ("flags", u32), ("max_length", i32), ("fsw_lag", i32), ("pad1_", i32),
+        ("flags", u32), ("max_length", i32), ("fsw_lag", i32), ("nav_lag", i32),
         ("mu", d), ("req", d), ("j2", d), ("planet_rate", d),
         ("inertia", d * 9), ("mass", d),
         ("gs", (d * 3) * BSK_MAX_RW), ("js", d * BSK_MAX_RW), ("u_max", d), ("u_min", d), ("f_coulomb", d),

@@ -227,6 +227,7 @@ int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool&
     p.f_coulomb = c.f_coulomb;
     p.fsw_every = c.fsw_every;
     p.fsw_lag = c.fsw_lag;
+    p.nav_lag = c.nav_lag;
     p.req = c.req;
     p.planet_rate = c.planet_rate;
     p.sh_tab = nullptr;
@@ -244,6 +245,7 @@ int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool&
     k.thr_min_on_time = c.thr_min_on_time;
     k.thr_max_counter = c.thr_max_counter;
     k.fsw_lag = c.fsw_lag;
+    k.nav_lag = c.nav_lag;
     for (int i = 0; i < c.n_rw; ++i) { k.js[i] = c.js[i]; for (int j = 0; j < 3; ++j) k.gs[i][j] = c.gs[i][j]; }
     if (c.flags & BSK_FLAG_DESAT) {
         double dd[9] = {0}, ddi[9], Dm[BSK_MAX_THR][3];
@@ -420,6 +422,7 @@ int validate(const bsk_config& c) {
     if (c.fsw_every < 1 || c.fsw_every > 2047) return fail(BSK_EINVAL, "fsw_every must be in 1..2047");
     if (c.max_length < 0 || c.max_length > 1000000) return fail(BSK_EINVAL, "max_length must be in 0..1000000");
     if (c.fsw_lag != 0 && c.fsw_lag != 1) return fail(BSK_EINVAL, "fsw_lag must be 0 or 1");
+    if (c.nav_lag != 0 && c.nav_lag != 1) return fail(BSK_EINVAL, "nav_lag must be 0 or 1");
     if (c.n_rw != 0 && c.n_rw != 3 && c.n_rw != 4) return fail(BSK_EINVAL, "n_rw must be 0, 3 or 4");
     if (c.gravity_model != BSK_GRAV_PM && c.gravity_model != BSK_GRAV_PM_J2 && c.gravity_model != BSK_GRAV_SH)
         return fail(BSK_EINVAL, "unknown gravity_model");
@@ -525,6 +528,7 @@ int bsk_default_config(bsk_config* c, int n_rw, int gravity_model) {
     c->flags = 0;
     c->max_length = 540;
     c->fsw_lag = 1;
+    c->nav_lag = 1;
     c->mu = 0.3986004415e15;
     c->req = 6378136.6;
     c->j2 = std::sqrt(5.0) * 4.841693e-4;

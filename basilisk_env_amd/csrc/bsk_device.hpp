@@ -168,6 +168,7 @@ struct ColdCfg {
     double gs[BSK_MAX_RW][3], js[BSK_MAX_RW];
     int32_t thr_max_counter;
     int32_t fsw_lag;   // bsk_config.fsw_lag: MRP_Feedback consumes the previous FSW tick's att_guidance
+    int32_t nav_lag, pad3_;   // bsk_config.nav_lag: FSW ticks run before the dynamics task of their time
     // wave-uniform constants of the full-scenario kernels: three rows of 16 doubles, fetched lane-wise into three
     // VGPR pairs (lane l holds entry l & 15 of each row) and fed to the FMAs through the DPP row broadcast (KTab)
     double kt[48];
@@ -1197,17 +1198,22 @@ struct Guid {
 template <int NRW>
 __device__ __forceinline__ Guid guidance(const double* __restrict__ sigma_R0N, const State<NRW>& x, int action) {
     V3 sRN, wRN_N, dwRN_N;
+    // a navigation message nobody has written yet (all zeros: the FSW tick at t = 0 with bsk_config.nav_lag): hillPoint's
+    // unit vectors normalise to zero, the zero DCM maps to the zero MRP and its radius guard zeroes the rates
+    const bool znav = dot(x.r, x.r) == 0.0;
     if (action == 0) {
-        double ir = rsqrt_nr(dot(x.r, x.r));
-        V3 h = cross(x.r, x.v);
+        const V3 xr = znav ? mk(1, 0, 0) : x.r, xv = znav ? mk(0, 1, 0) : x.v;   // keeps the arithmetic finite
+        double ir = rsqrt_nr(dot(xr, xr));
+        V3 h = cross(xr, xv);
         double h2 = dot(h, h), ih = rsqrt_nr(h2), hm = h2 * ih;
-        V3 e_r = ir * x.r, e_h = ih * h, e_t = cross(e_h, e_r);
+        V3 e_r = ir * xr, e_h = ih * h, e_t = cross(e_h, e_r);
         double C[9] = {e_r.x, e_r.y, e_r.z, e_t.x, e_t.y, e_t.z, e_h.x, e_h.y, e_h.z};
         sRN = c2mrp(C);
         double dfdt = hm * ir * ir;
-        double ddfdt2 = -2.0 * dot(x.v, e_r) * ir * dfdt;
+        double ddfdt2 = -2.0 * dot(xv, e_r) * ir * dfdt;
         wRN_N = dfdt * e_h;
         dwRN_N = ddfdt2 * e_h;
+        if (znav) { sRN = mk(0, 0, 0); wRN_N = mk(0, 0, 0); dwRN_N = mk(0, 0, 0); }
     } else {
         sRN = mk(sigma_R0N[0], sigma_R0N[1], sigma_R0N[2]);
         wRN_N = mk(0, 0, 0);
@@ -1248,8 +1254,8 @@ __device__ __forceinline__ void control(const ColdCfg* __restrict__ c, const Gui
 // thruster's MinOnTime).  thr_lim is the new burst in half dyn steps.
 template <int NRW>
 __device__ __forceinline__ void desat_tick(const ColdCfg* __restrict__ cc, const double* Om, bool first, double Tc,
-                                           double two_over_dt, int fsw_every, int tick, double* __restrict__ rem_base,
-                                           int64_t S, uint32_t bo, unsigned* thr_lim2, int& thr_t0, int& thr_cnt) {
+                                           double two_over_dt, int fsw_every, double* __restrict__ rem_base,
+                                           int64_t S, uint32_t bo, unsigned* lim2_new, bool& fired, int& thr_cnt) {
     // on-time still owed per thruster lives in the state slab and is touched only here (one request per mode entry,
     // one burst every thr_max_counter + 1 control periods): nothing of it is held across the RK4 loop
     double thr_rem[BSK_MAX_THR];
@@ -1288,8 +1294,9 @@ __device__ __forceinline__ void desat_tick(const ColdCfg* __restrict__ cc, const
             }
         }
 #pragma unroll
-        for (int i = 0; i < BSK_MAX_THR / 2; ++i) thr_lim2[i] = lim[2 * i] | (lim[2 * i + 1] << 16);
-        thr_t0 = tick;
+        // the on-time command message: the thruster set latches it (and the burst starts) when the dynamics task runs
+        for (int i = 0; i < BSK_MAX_THR / 2; ++i) lim2_new[i] = lim[2 * i] | (lim[2 * i + 1] << 16);
+        fired = true;
         thr_cnt = cc->thr_max_counter;
 #pragma unroll
         for (int i = 0; i < BSK_MAX_THR; ++i)

@@ -80,6 +80,8 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
     double charge = ldf(FLD(TAIL + BSK_T_CHARGE), bo);
     const int2 cnt = *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(a.cnt) + bo);  // {steps | phase << 20, ticks}
     const int action = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(a.act) + (bo >> 1));
+    // |sigma_BR| of the att_guidance message the last FSW tick wrote (obs[0] with bsk_config.nav_lag)
+    double sbr = ldf(FLD(TAIL + BSK_T_SBR), bo);
     double u[NRW > 0 ? NRW : 1], up[NRW > 0 ? NRW : 1];
 #pragma unroll
     for (int k = 0; k < (NRW > 0 ? NRW : 1); ++k) up[k] = 0.0;
@@ -179,45 +181,107 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
     bool first_fsw = true;
     bool drag_cfg = false;
     if constexpr (FULL) drag_cfg = a.extra.base_density != 0.0;
+    // ---- FSW task timing (bsk_config.nav_lag) -------------------------------------------------------------------
+    // The reference creates its FSW tasks with priorities 100 / 50 and its dynamics tasks with the default
+    // (...Simulator.py:383-386, :101-103); Basilisk runs higher priorities first at equal time.  So the FSW tick of
+    // time k F dt executes BEFORE the dynamics task integrates to that time: on the navigation / wheel-speed messages
+    // of one integrator step earlier, and the effectors latch its commands when the dynamics task runs, i.e. they act
+    // from k F dt on.  In loop terms: the chain runs at phase F-1 on the current state and opens a chunk of up to F
+    // ticks whose first RK4 step still runs with the old commands; the new ones are latched after that step.  The
+    // tick at t = 0 finds messages nobody has written (zeros); a tick that coincides with the end of a launch belongs
+    // to that launch (ExecuteSimulation runs the tasks scheduled at its stop time).  nav_lag = 0: the chain runs at
+    // phase 0 on the state of its own time, latched at once.
+    bool navlag = false;
+#ifndef BSK_NO_NAVLAG
+    if constexpr (NRW > 0) navlag = a.nav_lag != 0;
+#endif
+    // The FSW output messages: the newest wheel torque command and thruster burst.  The effectors' copies (u, ev.thr_*,
+    // thr_t0) are refreshed from them by plain moves (`latch`) - idempotent, so no "new message" flags are carried.
+    double un[NRW > 0 ? NRW : 1];
+#pragma unroll
+    for (int k = 0; k < NRW; ++k) un[k] = u[k];
+    unsigned lim2n[BSK_MAX_THR / 2] = {0u, 0u, 0u, 0u};
+    int thr_maxn = 0, thr_t0n = 0;
+    if constexpr (FULL) {
+#pragma unroll
+        for (int k = 0; k < BSK_MAX_THR / 2; ++k) lim2n[k] = ev.thr_lim2[k];
+        thr_maxn = ev.thr_max;
+        thr_t0n = thr_t0;
+    }
+    auto fsw_tick = [&](const State<NRW>& nav, int t_latch) {
+        // mrpControlTask order of the reference (MRP_Feedback before attTrackingError, ...Simulator.py:484-486;
+        // bsk_config.fsw_lag): this tick commands the torque the PREVIOUS tick's guidance maps to and
+        // leaves its own for the next one.  The pending torque comes from the slab on the launch's first
+        // FSW tick (issued here, consumed after the guidance arithmetic) and stays in registers afterwards.
+        const bool lag = cold->fsw_lag != 0;
+        if (lag && first_fsw) {
+#pragma unroll
+            for (int k = 0; k < NRW; ++k) up[k] = ldf(st + (int64_t)(TAIL + BSK_T_UPEND + k) * S, bo);
+        }
+        Guid g = guidance<NRW>(cold->sigma_R0N, nav, action);
+        sbr = sqrt_nr(dot(g.sigma_BR, g.sigma_BR));
+        if (lag) {
+#pragma unroll
+            for (int k = 0; k < NRW; ++k) un[k] = up[k];
+            control<NRW>(cold, g, up);
+        } else {
+            control<NRW>(cold, g, un);
+        }
+        fsw_ran = true;
+        if constexpr (FULL) {
+            if (desat && action == 2) {
+                bool fired = false;
+                desat_tick<NRW>(cold, nav.Om, first_fsw, fsw_every * c.h, 2.0 / c.h, fsw_every,
+                                const_cast<double*>(st) + (int64_t)(TAIL + BSK_T_THR_REM) * S, S, bo, lim2n, fired, thr_cnt);
+                if (fired) {   // the burst starts when the thruster set latches the on-time message
+                    thr_maxn = 0;
+#pragma unroll
+                    for (int k = 0; k < BSK_MAX_THR; ++k) thr_maxn = max(thr_maxn, (int)((lim2n[k >> 1] >> (16 * (k & 1))) & 0xFFFFu));
+                    thr_t0n = t_latch;
+                }
+            }
+        }
+        first_fsw = false;
+    };
+    // the dynamics task's effectors read the FSW output messages: the newest torque / burst act from the current tick on
+    auto latch = [&]() {
+#pragma unroll
+        for (int k = 0; k < NRW; ++k) u[k] = un[k];
+        if constexpr (FULL) {
+#pragma unroll
+            for (int k = 0; k < BSK_MAX_THR / 2; ++k) ev.thr_lim2[k] = lim2n[k];
+            ev.thr_max = thr_maxn;
+            thr_t0 = thr_t0n;
+        }
+    };
+    // the FSW tasks of t = 0 (nav_lag): nothing has written their inputs yet.  Handled as a chunk of zero ticks at the head
+    // of the loop (wave-uniform: the other lanes of the wave wait), so that the FSW chain is instantiated once.
+    bool z0 = false;
+    if constexpr (NRW > 0) z0 = navlag && tick == 0 && substeps_eff > 0;
+    int np = 0;   // power system: ticks recorded since the last flush (per lane)
     while (j < substeps_eff) {
         int m = substeps_eff - j;
         if constexpr (NRW > 0) {
-#if defined(BSK_ABLATE) && BSK_ABLATE == 3
-            if (false) {   // timing only: no FSW chain
-#else
-            if (phase == 0) {
-#endif
-                // mrpControlTask order of the reference (MRP_Feedback before attTrackingError, ...Simulator.py:484-486;
-                // bsk_config.fsw_lag): this tick commands the torque the PREVIOUS tick's guidance maps to and
-                // leaves its own for the next one.  The pending torque comes from the slab on the launch's first
-                // FSW tick (issued here, consumed after the guidance arithmetic) and stays in registers afterwards.
-                const bool lag = cold->fsw_lag != 0;
-                if (lag && first_fsw) {
+            const int trig = navlag ? fsw_every - 1 : 0;
+            int dist = trig - phase;                   // ticks to the next FSW tick of this lane
+            if (dist <= 0) dist += fsw_every;
+#if !(defined(BSK_ABLATE) && BSK_ABLATE == 3)   // 3: timing only, no FSW chain
+            const bool anyz = navlag && __builtin_amdgcn_ballot_w64(z0) != 0;
+            if (z0 || (!anyz && phase == trig)) {
+                State<NRW> nav = x;
+                if (z0) {
+                    nav.r = mk(0, 0, 0); nav.v = mk(0, 0, 0); nav.s = mk(0, 0, 0); nav.w = mk(0, 0, 0);
 #pragma unroll
-                    for (int k = 0; k < NRW; ++k) up[k] = ldf(st + (int64_t)(TAIL + BSK_T_UPEND + k) * S, bo);
+                    for (int k = 0; k < NRW; ++k) nav.Om[k] = 0.0;
                 }
-                Guid g = guidance<NRW>(cold->sigma_R0N, x, action);
-                if (lag) {
-#pragma unroll
-                    for (int k = 0; k < NRW; ++k) u[k] = up[k];
-                    control<NRW>(cold, g, up);
-                } else {
-                    control<NRW>(cold, g, u);
-                }
-                fsw_ran = true;
-                if constexpr (FULL) {
-                    if (desat && action == 2) {
-                        desat_tick<NRW>(cold, x.Om, first_fsw, fsw_every * c.h, 2.0 / c.h, fsw_every, tick,
-                                        const_cast<double*>(st) + (int64_t)(TAIL + BSK_T_THR_REM) * S, S, bo, ev.thr_lim2, thr_t0,
-                                        thr_cnt);
-                        ev.thr_max = 0;
-#pragma unroll
-                        for (int k = 0; k < BSK_MAX_THR; ++k) ev.thr_max = max(ev.thr_max, thr_limit(ev, k));
-                    }
-                }
-                first_fsw = false;
+                fsw_tick(nav, tick + ((navlag && !z0) ? 1 : 0));
+                if (!navlag) latch();
+                else dist = fsw_every;                 // latched inside the chunk, after its first RK4 step
             }
-            m = min(m, fsw_every - phase);
+            if (anyz) dist = 0;                        // t = 0 tick: latched below without a step in between
+            z0 = false;
+#endif
+            m = min(m, dist);
             if constexpr (POWER) m = min(m, PEN_SLOTS);   // the power system's per-wave tick record holds PEN_SLOTS ticks
             // The DPP-broadcast harmonics need every lane active inside the RK4 loop, so the trip count is
             // made wave-uniform: envs of one wave that sit at different FSW phases (after a masked reset)
@@ -226,12 +290,22 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
 #if !(defined(BSK_ABLATE) && BSK_ABLATE == 5)   // 5: timing only, per-lane trip count
             if constexpr (GRAV == BSK_GRAV_SH || WDPP) m = wave_min_uniform(m);
 #endif
-            phase = (phase + m == fsw_every) ? 0 : phase + m;
+            phase += m;
+            if (phase >= fsw_every) phase -= fsw_every;
         }
         if constexpr (POWER && NRW == 0) {
             m = min(m, PEN_SLOTS);
             if constexpr (FULL) m = wave_min_uniform(m);
         }
+#if !(defined(BSK_ABLATE) && BSK_ABLATE == 4)   // 4: timing only, no drain / battery replay
+        if constexpr (POWER) {
+            // the tick record is flushed (queue drained cooperatively, battery replayed) when some lane's would overflow
+            if (__builtin_amdgcn_ballot_w64(np + m > PEN_SLOTS) != 0) {
+                power_flush(a.power, L, np, lane, c.h, charge, shadow);
+                np = 0;
+            }
+        }
+#endif
         j += m;
         for (int t = 0; t < m; ++t, ++tick) {
             if constexpr (FULL) {
@@ -257,12 +331,19 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
                 }
             }
             rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT>(c, wv, x, u, lext, (double)tick * c.h, ev, accp);
-            if constexpr (POWER) power_tick<FULL>(a.power, sg, x.r, x.s, L, t, lane, kt.c);
+            if constexpr (POWER) power_tick<FULL>(a.power, sg, x.r, x.s, L, np + t, lane, kt.c);
+            // after a chunk's first step the new commands act; plain moves, no-ops on every later step (measured
+            // against a conditional latch and against splitting the chunk: profiles/r02/fsw_timing_cost.txt)
+            if constexpr (NRW > 0) latch();
         }
-#if !(defined(BSK_ABLATE) && BSK_ABLATE == 4)   // 4: timing only, no drain / battery replay
-        if constexpr (POWER) power_flush(a.power, L, m, lane, c.h, charge, shadow);
-#endif
+        np += m;
+        if constexpr (NRW > 0) latch();        // the t = 0 chunk has no step
     }
+#if !(defined(BSK_ABLATE) && BSK_ABLATE == 4)
+    if constexpr (POWER) {
+        if (__builtin_amdgcn_ballot_w64(np > 0) != 0) power_flush(a.power, L, np, lane, c.h, charge, shadow);
+    }
+#endif
 
     // Re-read the post-loop arguments from the kernarg segment through an opaque pointer: the
     // compiler cannot hoist these scalar loads above the loop, so they cost it no SGPRs.
@@ -275,9 +356,14 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
     const bool valid2 = gid < n2;
 
     // observation: [|sigma_BR|, |omega_BN|, |Omega|/limit, charge/3600/power_max, shadow]
-    double sR0N[3] = {tp->obs_cfg.sigma_R0N[0], tp->obs_cfg.sigma_R0N[1], tp->obs_cfg.sigma_R0N[2]};
-    const Guid g = guidance<NRW>(sR0N, x, action);
-    const double o0 = sqrt_nr(dot(g.sigma_BR, g.sigma_BR));
+    // obs[0] is the logged att_guidance message: with nav_lag the one the last FSW tick wrote (held in `sbr`),
+    // otherwise the tracking error of the end-of-step state under the step's mode
+    double o0 = sbr;
+    if (!(NRW > 0 && tp->nav_lag != 0)) {
+        double sR0N[3] = {tp->obs_cfg.sigma_R0N[0], tp->obs_cfg.sigma_R0N[1], tp->obs_cfg.sigma_R0N[2]};
+        const Guid g = guidance<NRW>(sR0N, x, action);
+        o0 = sqrt_nr(dot(g.sigma_BR, g.sigma_BR));
+    }
     const double o1 = sqrt_nr(dot(x.w, x.w));
     double om2 = 0.0;
 #pragma unroll
@@ -365,6 +451,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
 #pragma unroll
                     for (int k = 0; k < NRW; ++k) stf(FLD(TAIL + BSK_T_UPEND + k), bo, up[k]);
                 }
+                stf(FLD(TAIL + BSK_T_SBR), bo, sbr);
             }
         }
         // int2 {steps | phase << 20, ticks} written as one 8-byte word
@@ -535,6 +622,7 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     fill_hot<GRAV, NRW, DIAG>(p, a.hot);
     a.cold = b.cold; a.st = b.st; a.cnt = b.cnt; a.act = b.act;
     a.stride = b.stride; a.n = b.n; a.substeps = b.substeps;
+    a.nav_lag = p.nav_lag; a.pad_ = 0;
     a.power = p.pc;
     a.extra = p.ex;
     a.tail.obs_cfg = p.obs; a.tail.st = b.st; a.tail.cnt = b.cnt; a.tail.obs = b.obs; a.tail.reward = b.reward;
@@ -542,7 +630,7 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     a.tail.stride = b.stride; a.tail.n = b.n; a.tail.substeps = b.substeps;
     a.tail.pool = b.pool; a.tail.term_obs = b.term_obs; a.tail.episodes = b.episodes;
     a.tail.n_pool = b.n_pool; a.tail.n_fields = b.n_fields;
-    a.tail.fsw_lag = p.fsw_lag; a.tail.pad_ = 0;
+    a.tail.fsw_lag = p.fsw_lag; a.tail.nav_lag = p.nav_lag;
     if (SPLIT == 5) block = 256;
     const int grid = SPLIT == 5 ? (b.n + 127) / 128 : (b.n + block - 1) / block;
     // the power system keeps a per-wave tick record and penumbra queue in dynamic LDS (bsk_device.hpp: PowerLds)

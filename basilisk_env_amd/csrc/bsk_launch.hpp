@@ -29,7 +29,7 @@ struct TailArgs {
     int* episodes;                 // [stride]
     int n_pool;
     int n_fields;
-    int fsw_lag, pad_;
+    int fsw_lag, nav_lag;
 };
 
 // Passed by value to step_kernel (kernarg segment -> SGPRs).
@@ -43,6 +43,7 @@ struct StepArgs {
     int64_t stride;
     int n;
     int substeps;
+    int nav_lag, pad_;
     PowerCfg power;               // read only by FEAT >= FEAT_POWER
     ExtraCfg extra;               // read only by FEAT_FULL
     TailArgs tail;
@@ -64,7 +65,7 @@ struct StepParams {
     int32_t sh_bodies, sh_bodies0, sh_bodies1, sh_chunk1;   // DPP stream: bodies (whole / per half), first chunk of half 1
     int sh_form;            // 1 scalar-load stream, 4 DPP broadcast, 5 DPP broadcast over two cooperating waves
     int feat;               // FEAT_BARE / FEAT_POWER / FEAT_FULL
-    int fsw_lag;
+    int fsw_lag, nav_lag;
     PowerCfg pc;
     ExtraCfg ex;
 };

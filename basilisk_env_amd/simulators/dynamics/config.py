@@ -60,6 +60,7 @@ def default_config(n_rw=3, gravity_model=GRAV_PM, mass=330.0, width=1.38, depth=
     c.n_rw = n_rw
     c.max_length = 540
     c.fsw_lag = 1   # mrpControlTask order of the reference (...Simulator.py:484-486): control lags guidance by one FSW tick
+    c.nav_lag = 1   # FSW task priorities 100 / 50 against the dynamics tasks' default (:383-386, :101-103): FSW runs first
     c.mu = MU_EARTH
     c.req = REQ_EARTH_KM * 1000.0
     c.j2 = math.sqrt(5.0) * -CBAR_20

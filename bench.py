@@ -59,6 +59,9 @@ def parse(argv=None):
                    help="bare = BASELINE configs[2] as named (headline); power / full add the reference scenario's "
                         "power system / + Sun third body, drag and desaturation (what the drop-in env runs)")
     p.add_argument("--lds-scratch", action="store_true", help="BSK_FLAG_LDS_SCRATCH kernel variant (RK4 accumulator in LDS)")
+    p.add_argument("--fsw-timing", choices=["reference", "same-tick"], default="reference",
+                   help="reference: bsk_config.fsw_lag = nav_lag = 1 (the reference's task order and priorities); "
+                        "same-tick: both 0 (measurement A/B only)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true")
     return p.parse_args(argv)
@@ -337,6 +340,8 @@ def main():
         cfg.flags |= FLAG_POWER | ((FLAG_SUN_THIRD_BODY | FLAG_DRAG | FLAG_DESAT) if a.scenario == "full" else 0)
     if a.lds_scratch:
         cfg.flags |= FLAG_LDS_SCRATCH
+    if a.fsw_timing == "same-tick":
+        cfg.fsw_lag = cfg.nav_lag = 0
     n = a.envs
     ic = sample_ic_batch(n, n_rw, seed=rank)       # rank r owns env indices [r*n, (r+1)*n)
     prop = BatchedPropagator(cfg if not sh else _with_degree(cfg, 70), n, device=local)
@@ -372,10 +377,10 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "BASELINE configs[%s]: %d envs/GPU, %s gravity + 4 reaction wheels (pyramid) + "
                                "nadir-pointing reward, fp64, dt 0.1 s, %d RK4 sub-step(s) per env step, fsw every 10 "
-                               "sub-steps (reference task order: fsw_lag 1), synthetic random-orbit batch PCG64(rank)"
+                               "sub-steps (reference FSW task order and priorities: fsw_lag = nav_lag = 1), synthetic random-orbit batch PCG64(rank)"
                                % ("4" if sh else "2", n, "degree-70 spherical-harmonic (synthetic Kaula field)" if sh else "J2",
                                   a.substeps),
-                   "envs_per_gpu": n, "substeps": a.substeps, "scenario": a.scenario, "lds_scratch": bool(a.lds_scratch),
+                   "envs_per_gpu": n, "substeps": a.substeps, "scenario": a.scenario, "lds_scratch": bool(a.lds_scratch), "fsw_timing": a.fsw_timing,
                    "sharding": "env ranges, no step-path collective"},
         "roofline": fp64 if fp64_bound else hbm,
         "rk4_substeps_per_s": value * a.substeps,

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BSK_ABI_VERSION 3u
+#define BSK_ABI_VERSION 4u
 #define BSK_MAX_RW 4
 #define BSK_MAX_THR 8
 #define BSK_MAX_SH_DEGREE 70
@@ -74,7 +74,8 @@ enum {
     /* FSW task order (bsk_config.fsw_lag): the wheel torque that the NEXT FSW tick will apply, i.e.
      * rwMotorTorque(MRP_Feedback(att_guidance of the last tick)); zero after a reset (empty message) */
     BSK_T_UPEND = 26,   /* BSK_MAX_RW fields                                                           */
-    BSK_NF_TAIL = 30,
+    BSK_T_SBR = 30,     /* |sigma_BR| of the att_guidance message the last FSW tick wrote (bsk_config.nav_lag) */
+    BSK_NF_TAIL = 31,
 };
 
 typedef struct bsk_config {
@@ -95,7 +96,16 @@ typedef struct bsk_config {
      * the first tick after a reset commands zero (empty message).  0: guidance and control on the
      * same tick (the order the module names suggest).                                           */
     int32_t fsw_lag;
-    int32_t pad1_;
+    /* 1 (default, reference priorities): the FSW tasks are created with priorities 100 / 50 (…Simulator.py:383-386),
+     * the dynamics tasks with the default (:101-103), and Basilisk runs higher priorities first at equal time: the
+     * FSW tick at time k*fsw_every*dt executes BEFORE the dynamics task integrates to that time — on the navigation
+     * and wheel-speed messages of one integrator step earlier — and its commands (wheel torque, thruster burst) are
+     * latched when the dynamics task runs, i.e. act from that time on.  The tick at t = 0 finds messages nobody has
+     * written yet (zeros); a tick that coincides with the end of an env step belongs to that step, with its mode
+     * (ExecuteSimulation runs the tasks scheduled at its stop time); obs[0] is the att_guidance message as the last
+     * FSW tick left it.  0: an FSW tick works on the state of its own time, belongs to the env step that starts
+     * there, and obs[0] is the tracking error of the end-of-step state.                                          */
+    int32_t nav_lag;
 
     /* gravity constants (leo_orbit.py:30; REQ_EARTH at …Simulator.py:146) */
     double mu;      /* m^3/s^2 */

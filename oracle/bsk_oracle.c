@@ -367,7 +367,12 @@ typedef struct { double sigma_BR[3], omega_BR_B[3], omega_RN_B[3], domega_RN_B[3
 static void guidance(orc_ctx* ctx, const double x[NX], int action, att_guid* g) {
     const bsk_config* c = ctx->c;
     double sigma_RN[3], omega_RN_N[3], domega_RN_N[3];
-    if (action == 0) {
+    if (action == 0 && v3norm(x) == 0.0) {
+        /* hillPoint on a navigation message nobody has written yet (all zeros; the FSW tasks' first tick, see
+           orc_step): its unit vectors normalise to zero, the DCM of zeros maps to the zero MRP and the module's
+           radius guard zeroes the rates [BSK-recall] */
+        v3set(0, 0, 0, sigma_RN); v3set(0, 0, 0, omega_RN_N); v3set(0, 0, 0, domega_RN_N);
+    } else if (action == 0) {
         /* hillPoint (…Simulator.py:414-419): Hill frame {i_r, i_theta, i_h} */
         const double *r = x, *v = x + 3;
         double rm = v3norm(r), h[3], dcm[9];
@@ -541,59 +546,91 @@ int orc_step(const bsk_config* c, int n, double* state, int32_t* steps, int32_t*
            held over the step, like the 180 s SPICE task (…Simulator.py:102,357) */
         double sun[3];
         for (int k = 0; k < 3; ++k) sun[k] = (c->sun_r0[k] + c->sun_v[k] * sim_time0) + c->sun_v[k] * (tick * c->dt);
-        for (int j = 0; j < substeps; ++j, ++tick) {
-            if (nrw > 0 && tick % c->fsw_every == 0) {
-                /* mrpControlTask runs MRP_Feedback, attTrackingError, rwMotorTorque in THAT order
-                   (AddModelToTask calls, …Simulator.py:484-486): the controller reads the att_guidance
-                   message the previous FSW tick wrote, then this tick's guidance overwrites it.  Holding
-                   the message or holding the torque it maps to is the same thing (MRP_Feedback without
-                   integral term and rwMotorTorque are pure functions of the message), so the slab keeps
-                   the 4 torques rather than the 12 message entries. */
-                att_guid g;
-                guidance(&ctx, x, act, &g);
-                if (c->fsw_lag) {
-                    for (int i = 0; i < BSK_MAX_RW; ++i) u[i] = upend[i];
-                    control(&ctx, &g, upend);
-                } else {
-                    control(&ctx, &g, u);
-                }
-                if (desat && act == 2) {
-                    /* rwDesatTask (…Simulator.py:452-478, 488-490; enabled in mode 2 only, :574-588) */
-                    const double Tc = c->fsw_every * c->dt;
-                    if (first_fsw) {
-                        /* thrMomentumManagement: one request per mode entry (its Reset, :580).  Wheel
-                           momentum h_s = sum Js Om g; dump everything above hs_min (:183). */
-                        double hs[3] = {0, 0, 0};
-                        for (int i = 0; i < nrw; ++i)
-                            for (int k = 0; k < 3; ++k) hs[k] += c->js[i] * x[12 + i] * c->gs[i][k];
-                        double hm = v3norm(hs), dH[3] = {0, 0, 0};
-                        if (hm > c->hs_min) v3scale(-(hm - c->hs_min) / hm, hs, dH);
-                        /* thrForceMapping, on-pulsing (thrForceSign +1, :186): minimum-norm impulses
-                           F = D^T (D D^T)^-1 dH, then subtract the smallest so that all are >= 0 */
-                        double F[BSK_MAX_THR], fmin = 0.0;
-                        for (int i = 0; i < c->n_thr; ++i) { F[i] = v3dot(ctx.thr_map[i], dH); if (i == 0 || F[i] < fmin) fmin = F[i]; }
-                        /* thrMomentumDumping: a new request resets the schedule (Reset, :581) */
-                        for (int i = 0; i < c->n_thr; ++i) thr_rem[i] = (F[i] - fmin) / c->thr_max_thrust;
-                        thr_cnt = 0;
-                    }
-                    if (thr_cnt <= 0) {
-                        /* fire: each thruster for min(remaining, control period); pulses shorter than
-                           thrMinFireTime (:190) are dropped; the thruster stretches a pulse to its MinOnTime */
-                        for (int i = 0; i < c->n_thr; ++i) {
-                            double on = thr_rem[i] < Tc ? thr_rem[i] : Tc;
-                            if (on < c->thr_min_fire_time) { on = 0.0; thr_rem[i] = 0.0; thr_lim[i] = 0.0; continue; }
-                            thr_rem[i] -= on;
-                            if (on >= Tc) thr_lim[i] = 2.0 * c->fsw_every;
-                            else { if (on < c->thr_min_on_time) on = c->thr_min_on_time; thr_lim[i] = floor(on * (2.0 / c->dt)); }
-                        }
-                        thr_t0 = tick;
-                        thr_cnt = c->thr_max_counter;
-                    } else {
-                        thr_cnt -= 1;
-                    }
-                }
-                first_fsw = 0;
-            }
+        /* What the dynamics task has latched from the FSW tasks' output messages: wheel torque command u and the
+           thruster burst (thr_lim, thr_t0).  The FSW chain itself works on `u_cmd_msg` / `lim_msg`; with nav_lag the
+           effectors see them one integrator step later (below). */
+        double sbr = S(tail + BSK_T_SBR, e);          /* |sigma_BR| of the att_guidance message */
+        double u_msg[BSK_MAX_RW], lim_msg[BSK_MAX_THR];
+        int have_msg = 0, lim_changed = 0;
+#define FSW_TICK(NAV)                                                                                                    \
+        do {                                                                                                             \
+            /* mrpControlTask runs MRP_Feedback, attTrackingError, rwMotorTorque in THAT order (AddModelToTask calls,     \
+               …Simulator.py:484-486): the controller reads the att_guidance message the previous FSW tick wrote, then  \
+               this tick's guidance overwrites it.  MRP_Feedback without integral term and rwMotorTorque are pure        \
+               functions of the message, so the slab keeps the 4 torques it maps to rather than its 12 entries. */       \
+            att_guid g;                                                                                                  \
+            guidance(&ctx, (NAV), act, &g);                                                                              \
+            sbr = v3norm(g.sigma_BR);                                                                                    \
+            if (c->fsw_lag) {                                                                                            \
+                for (int i = 0; i < BSK_MAX_RW; ++i) u_msg[i] = upend[i];                                                \
+                control(&ctx, &g, upend);                                                                                \
+            } else {                                                                                                     \
+                control(&ctx, &g, u_msg);                                                                                \
+            }                                                                                                            \
+            have_msg = 1;                                                                                                \
+            if (desat && act == 2) {                                                                                     \
+                /* rwDesatTask (…Simulator.py:452-478, 488-490; enabled in mode 2 only, :574-588) */                     \
+                const double Tc = c->fsw_every * c->dt;                                                                  \
+                if (first_fsw) {                                                                                         \
+                    /* thrMomentumManagement: one request per mode entry (its Reset, :580).  Wheel momentum              \
+                       h_s = sum Js Om g from the wheel-speed message; dump everything above hs_min (:183). */           \
+                    double hs[3] = {0, 0, 0};                                                                            \
+                    for (int i = 0; i < nrw; ++i)                                                                        \
+                        for (int k = 0; k < 3; ++k) hs[k] += c->js[i] * (NAV)[12 + i] * c->gs[i][k];                     \
+                    double hm = v3norm(hs), dH[3] = {0, 0, 0};                                                           \
+                    if (hm > c->hs_min) v3scale(-(hm - c->hs_min) / hm, hs, dH);                                         \
+                    /* thrForceMapping, on-pulsing (thrForceSign +1, :186): minimum-norm impulses                        \
+                       F = D^T (D D^T)^-1 dH, then subtract the smallest so that all are >= 0 */                         \
+                    double F[BSK_MAX_THR], fmin = 0.0;                                                                   \
+                    for (int i = 0; i < c->n_thr; ++i) { F[i] = v3dot(ctx.thr_map[i], dH); if (i == 0 || F[i] < fmin) fmin = F[i]; } \
+                    /* thrMomentumDumping: a new request resets the schedule (Reset, :581) */                            \
+                    for (int i = 0; i < c->n_thr; ++i) thr_rem[i] = (F[i] - fmin) / c->thr_max_thrust;                   \
+                    thr_cnt = 0;                                                                                         \
+                }                                                                                                        \
+                if (thr_cnt <= 0) {                                                                                      \
+                    /* fire: each thruster for min(remaining, control period); pulses shorter than thrMinFireTime       \
+                       (:190) are dropped; the thruster stretches a pulse to its MinOnTime */                           \
+                    for (int i = 0; i < BSK_MAX_THR; ++i) lim_msg[i] = thr_lim[i];                                       \
+                    for (int i = 0; i < c->n_thr; ++i) {                                                                 \
+                        double on = thr_rem[i] < Tc ? thr_rem[i] : Tc;                                                   \
+                        if (on < c->thr_min_fire_time) { on = 0.0; thr_rem[i] = 0.0; lim_msg[i] = 0.0; continue; }       \
+                        thr_rem[i] -= on;                                                                                \
+                        if (on >= Tc) lim_msg[i] = 2.0 * c->fsw_every;                                                   \
+                        else { if (on < c->thr_min_on_time) on = c->thr_min_on_time; lim_msg[i] = floor(on * (2.0 / c->dt)); } \
+                    }                                                                                                    \
+                    lim_changed = 1;                                                                                     \
+                    thr_cnt = c->thr_max_counter;                                                                        \
+                } else {                                                                                                 \
+                    thr_cnt -= 1;                                                                                        \
+                }                                                                                                        \
+            }                                                                                                            \
+            first_fsw = 0;                                                                                               \
+        } while (0)
+        /* the dynamics task's effectors read the FSW output messages after the integration to the current tick:
+           the new torque / burst act from tick `tick` on */
+#define LATCH()                                                                                                          \
+        do {                                                                                                             \
+            if (have_msg) for (int i = 0; i < BSK_MAX_RW; ++i) u[i] = u_msg[i];                                          \
+            if (lim_changed) { for (int i = 0; i < BSK_MAX_THR; ++i) thr_lim[i] = lim_msg[i]; thr_t0 = tick; }           \
+            have_msg = 0; lim_changed = 0;                                                                               \
+        } while (0)
+        /* Task priorities (bsk_config.nav_lag): the reference gives its FSW tasks priorities 100 / 50 (…Simulator.py:
+           383-386) and leaves the dynamics tasks at the default (:101-103), and Basilisk runs higher priorities first
+           at equal time [BSK-recall]: an FSW tick at time k dt executes BEFORE the dynamics task integrates to that
+           time, on the navigation / wheel-speed messages of time (k-1) dt; its commands are latched when the dynamics
+           task runs (from time k dt on).  The tick at t = 0 finds messages nobody has written (zeros); a tick that
+           coincides with the end of an env step belongs to THAT step (ExecuteSimulation runs the tasks scheduled at
+           its stop time).  nav_lag = 0: the FSW tick at time k dt works on the state at k dt and belongs to the env
+           step that starts there. */
+        const int navlag = c->nav_lag && nrw > 0;
+        if (navlag && tick == 0) {
+            double nav0[NX] = {0};
+            FSW_TICK(nav0);
+            LATCH();
+        }
+        for (int j = 0; j < substeps; ++j) {
+            if (nrw > 0 && !navlag && tick % c->fsw_every == 0) { FSW_TICK(x); LATCH(); }
+            if (navlag && (tick + 1) % c->fsw_every == 0) FSW_TICK(x);
             double t = tick * c->dt;
             thr_state th = {0, 0, thr_lim};
             if (desat) {
@@ -601,6 +638,8 @@ int orc_step(const bsk_config* c, int n, double* state, int32_t* steps, int32_t*
                 for (int i = 0; i < c->n_thr; ++i) if (thr_lim[i] > 0.0 && (double)th.e2 <= thr_lim[i]) th.active = 1;
             }
             rk4_step(&ctx, x, u, lext, t, c->dt, sun, desat ? &th : 0);
+            ++tick;
+            if (navlag) LATCH();
             if (c->flags & BSK_FLAG_POWER) {
                 /* EnvTask at the dyn rate (…Simulator.py:363-366): eclipse -> panel -> battery */
                 shadow = shadow_factor(c, x, sun);
@@ -621,9 +660,11 @@ int orc_step(const bsk_config* c, int n, double* state, int32_t* steps, int32_t*
             }
         }
         /* observation (…Simulator.py:636-638, leoPowerAttitudeEnvironment.py:107-108) */
+        /* obs[0] is the logged att_guidance message (…Simulator.py:605,611): with nav_lag the one the last FSW tick
+           wrote; otherwise the tracking error of the end-of-step state under the step's mode */
         att_guid g;
         guidance(&ctx, x, act, &g);
-        double o0 = v3norm(g.sigma_BR), o1 = v3norm(x + 9), o2 = 0;
+        double o0 = navlag ? sbr : v3norm(g.sigma_BR), o1 = v3norm(x + 9), o2 = 0;
         for (int i = 0; i < nrw; ++i) o2 += x[12 + i] * x[12 + i];
         o2 = sqrt(o2) / c->wheel_limit;
         double o3 = charge / 3600.0 / c->power_max;
@@ -643,6 +684,7 @@ int orc_step(const bsk_config* c, int n, double* state, int32_t* steps, int32_t*
         for (int f = 0; f < 12 + nrw; ++f) S(f, e) = x[f];
         for (int i = 0; i < BSK_MAX_RW; ++i) S(tail + BSK_T_UCMD + i, e) = u[i];
         for (int i = 0; i < BSK_MAX_RW; ++i) S(tail + BSK_T_UPEND + i, e) = upend[i];
+        S(tail + BSK_T_SBR, e) = sbr;
         S(tail + BSK_T_CHARGE, e) = charge;
         if (desat) {
             for (int i = 0; i < BSK_MAX_THR; ++i) { S(tail + BSK_T_THR_REM + i, e) = thr_rem[i]; S(tail + BSK_T_THR_LIM + i, e) = thr_lim[i]; }
@@ -653,6 +695,8 @@ int orc_step(const bsk_config* c, int n, double* state, int32_t* steps, int32_t*
         ticks[e] = tick;
     }
 #undef S
+#undef FSW_TICK
+#undef LATCH
     ctx_free(&ctx);
     return 0;
 }

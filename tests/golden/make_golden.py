@@ -140,6 +140,7 @@ class Model(object):
         self.dt = M(float(c["dt"]))
         self.fsw_every = int(c["fsw_every"])
         self.fsw_lag = int(c["fsw_lag"])
+        self.nav_lag = int(c["nav_lag"]) if int(c["n_rw"]) else 0
         self.mu, self.req, self.j2 = M(float(c["mu"])), M(float(c["req"])), M(float(c["j2"]))
         self.I = [[M(float(c["inertia"][3 * i + j])) for j in range(3)] for i in range(3)]
         self.gs = [[M(float(c["gs"][i][k])) for k in range(3)] for i in range(self.n_rw)]
@@ -266,14 +267,16 @@ class Model(object):
             env["thr_rem"] = [(F[i] - fmin) / self.fmax for i in range(self.n_thr)] + [M(0)] * (8 - self.n_thr)
             env["thr_cnt"] = 0
         if env["thr_cnt"] <= 0:   # fire: at most one control period per burst, short pulses dropped / stretched
+            msg = list(env["thr_lim"])
             for i in range(self.n_thr):
                 on = min(env["thr_rem"][i], Tc)
                 if on < self.min_fire:
-                    env["thr_rem"][i], env["thr_lim"][i] = M(0), M(0)
+                    env["thr_rem"][i], msg[i] = M(0), M(0)
                     continue
                 env["thr_rem"][i] -= on
-                env["thr_lim"][i] = M(2 * self.fsw_every) if on >= Tc else mp.floor(max(on, self.min_on) * 2 / self.dt)
-            env["thr_t0"], env["thr_cnt"] = env["ticks"], self.max_counter
+                msg[i] = M(2 * self.fsw_every) if on >= Tc else mp.floor(max(on, self.min_on) * 2 / self.dt)
+            env["thr_msg"] = msg            # thruster on-time command message; the thruster set reads it when it runs
+            env["thr_cnt"] = self.max_counter
         else:
             env["thr_cnt"] -= 1
 
@@ -411,7 +414,11 @@ class Model(object):
 
     def guidance(self, x, action):
         r, v, s, w = x[0:3], x[3:6], x[6:9], x[9:12]
-        if action == 0:
+        if action == 0 and norm(r) == 0:
+            # hillPoint on a navigation message nobody has written yet: zero unit vectors, zero DCM -> zero MRP,
+            # rates zeroed by the module's radius guard
+            sRN, wRN, dwRN = [M(0)] * 3, [M(0)] * 3, [M(0)] * 3
+        elif action == 0:
             rm = norm(r)
             h = cross(r, v)
             hm = norm(h)
@@ -450,32 +457,57 @@ class Model(object):
         x, u = env["x"], env["u"]
         sun = self.sun_at(env["ticks"]) if (self.power or self.sun3) else None   # held over the env step
         shadow = M(1)
-        first_fsw = True
+        state = {"first": True}
+
+        def fsw_tick(nav):
+            """every enabled FSW task once, in priority / insertion order, on the navigation message `nav`"""
+            g = self.guidance(nav, action)              # hillPoint | inertial3D (priority 100) ... attTrackingError
+            env["sbr"] = norm(g[0])
+            if self.fsw_lag:
+                # mrpControlTask: MRP_Feedback was added BEFORE attTrackingError: it reads the att_guidance message as
+                # the previous FSW tick left it (all zeros = never written), then this tick's tracking error overwrites it
+                env["cmd_msg"] = self.control(env["guid"])
+                env["guid"] = g
+            else:
+                env["cmd_msg"] = self.control(g)
+            if self.desat and action == 2:
+                self.desat_tick(env, nav, state["first"])
+            state["first"] = False
+
+        def latch(u):
+            """the dynamics task's effectors read the FSW output messages after integrating to the current time"""
+            if env.get("cmd_msg") is not None:
+                u = env.pop("cmd_msg")
+            if env.get("thr_msg") is not None:
+                env["thr_lim"], env["thr_t0"] = env.pop("thr_msg"), env["ticks"]
+            return u
+
+        if self.nav_lag and env["ticks"] == 0:
+            # FSW priorities 100 / 50 against the dynamics tasks' default: the FSW tasks of t = 0 run before any
+            # dynamics task has written a message (zeros)
+            fsw_tick([M(0)] * len(x))
+            u = latch(u)
         for _ in range(substeps):
-            if self.n_rw and env["ticks"] % self.fsw_every == 0:
-                if self.fsw_lag:
-                    # the reference adds MRP_Feedback to mrpControlTask BEFORE attTrackingError: the controller
-                    # reads the att_guidance message as the previous FSW tick left it (all zeros = never
-                    # written, after a reset), then this tick's tracking error overwrites the message
-                    u = self.control(env["guid"])
-                    env["guid"] = self.guidance(x, action)
-                else:
-                    u = self.control(self.guidance(x, action))
-                if self.desat and action == 2:
-                    self.desat_tick(env, x, first_fsw)
-                first_fsw = False
+            if self.n_rw and not self.nav_lag and env["ticks"] % self.fsw_every == 0:
+                fsw_tick(x)
+                u = latch(u)
+            if self.nav_lag and (env["ticks"] + 1) % self.fsw_every == 0:
+                fsw_tick(x)      # the FSW tasks of the NEXT time run before the dynamics task integrates to it
             thr = None
             if self.desat:
                 e2 = 2 * (env["ticks"] - env["thr_t0"])
                 if any(l > 0 and e2 <= l for l in env["thr_lim"]):
                     thr = (env["thr_lim"], e2)
             x = self.rk4(x, u, env["lext"], env["ticks"] * self.dt, sun, thr)
+            env["ticks"] += 1
+            if self.nav_lag:
+                u = latch(u)
             if self.power:
                 env["charge"], shadow = self.power_tick(x, sun, env["charge"])
-            env["ticks"] += 1
         env["x"], env["u"] = x, u
-        sBR = self.guidance(x, action)[0]
-        o0, o1 = norm(sBR), norm(x[9:12])
+        # obs[0]: the logged att_guidance message — the last FSW tick's with nav_lag, else the end state's tracking error
+        o0 = env["sbr"] if self.nav_lag else norm(self.guidance(x, action)[0])
+        o1 = norm(x[9:12])
         o2 = mp.sqrt(sum(v * v for v in x[12:])) / self.wheel_limit if self.n_rw else M(0)
         o3 = env["charge"] / 3600 / self.power_max
         why = 0
@@ -512,7 +544,7 @@ def run_case(name, n_rw, grav, n_envs, seed, schedule, cfg_edit=None, sh=None, i
         envs.append({"x": [M(float(ic[f, e])) for f in range(12 + n_rw)], "u": [M(0)] * n_rw,
                      "lext": [M(float(ic[t + k, e])) for k in range(3)], "charge": M(float(ic[t + 7, e])),
                      "steps": 0, "ticks": 0, "thr_rem": [M(0)] * 8, "thr_lim": [M(0)] * 8, "thr_t0": 0, "thr_cnt": 0,
-                     "guid": ([M(0)] * 3, [M(0)] * 3, [M(0)] * 3, [M(0)] * 3)})   # att_guidance message, never written yet
+                     "guid": ([M(0)] * 3, [M(0)] * 3, [M(0)] * 3, [M(0)] * 3), "sbr": M(0)})   # att_guidance message, never written yet
     calls = []
     for ci, (actions, substeps) in enumerate(schedule):
         obs, rews, whys = [], [], []
@@ -530,6 +562,7 @@ def run_case(name, n_rw, grav, n_envs, seed, schedule, cfg_edit=None, sh=None, i
             if model.fsw_lag and n_rw:
                 # the slab keeps the torque the held message maps to (BSK_T_UPEND), not the message itself
                 state[t + 26:t + 26 + n_rw, e] = [float(v) for v in model.control(env["guid"])]
+            state[t + 30, e] = float(env["sbr"])
             if model.desat:
                 state[t + 8:t + 16, e] = [float(v) for v in env["thr_rem"]]
                 state[t + 16:t + 24, e] = [float(v) for v in env["thr_lim"]]
@@ -569,8 +602,13 @@ def main():
         cfg.base_density, cfg.scale_height = 1e-9, 100e3
 
     def nolag_edit(cfg):
-        """guidance and control on the same FSW tick (bsk_config.fsw_lag = 0)"""
+        """guidance and control on the same FSW tick, on the state of that tick (fsw_lag = nav_lag = 0)"""
         cfg.fsw_lag = 0
+        cfg.nav_lag = 0
+
+    def navnow_edit(cfg):
+        """the reference's model order inside mrpControlTask, but FSW ticks on the state of their own time (nav_lag = 0)"""
+        cfg.nav_lag = 0
 
     def desat_edit(cfg):
         from basilisk_env_amd._lib import FLAG_DESAT, FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY
@@ -597,6 +635,8 @@ def main():
         # the same with fsw_lag = 0 (first three checkpoints)
         ("j2_rw4_nolag", lambda: run_case("j2_rw4_nolag", 4, GRAV_PM_J2, n, 12, [(np.arange(n) % 2, k) for k in (1, 9, 90)],
                                           cfg_edit=nolag_edit)),
+        ("j2_rw4_navnow", lambda: run_case("j2_rw4_navnow", 4, GRAV_PM_J2, n, 12, [(np.arange(n) % 2, k) for k in (1, 9, 90)],
+                                           cfg_edit=navnow_edit)),
         # reference wiring: point mass + 3-wheel triad, mode switches between calls, odd call lengths
         ("pm_rw3_modes", lambda: run_case("pm_rw3_modes", 3, GRAV_PM, n, 13, sched)),
         # rows f1 / f3: power system (with penumbra crossings), Sun third body, facet drag; J2 + 3 wheels

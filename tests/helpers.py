@@ -8,6 +8,7 @@ def field_groups(n_rw):
         g["Omega"] = slice(12, 12 + n_rw)
         g["u"] = slice(12 + n_rw + 3, 12 + n_rw + 3 + n_rw)
         g["u_pend"] = slice(12 + n_rw + 26, 12 + n_rw + 26 + n_rw)
+        g["sigma_BR_msg"] = slice(12 + n_rw + 30, 12 + n_rw + 31)
     return g
 
 
@@ -33,6 +34,9 @@ def cfg_for_case(case):
         cfg.flags |= FLAG_POWER | FLAG_SUN_THIRD_BODY | FLAG_DRAG | FLAG_DESAT
     if case.get("cfg_edit") == "nolag_edit":
         cfg.fsw_lag = 0
+        cfg.nav_lag = 0
+    if case.get("cfg_edit") == "navnow_edit":
+        cfg.nav_lag = 0
     if "sh_degree" in case:
         cfg.sh_degree = case["sh_degree"]
     return cfg

@@ -37,6 +37,7 @@ def test_random_configuration_matches_oracle(seed, monkeypatch):
     cfg.flags |= flags
     cfg.fsw_every = int(rng.choice([1, 3, 10, 25]))      # 25 > the power system's 10-tick record: chunked FSW periods
     cfg.fsw_lag = int(rng.random() < 0.7)        # reference task order (default) or guidance+control on one tick
+    cfg.nav_lag = int(rng.random() < 0.7)        # reference task priorities (default) or FSW ticks on the state of their time
     cbar = sbar = None
     if grav == GRAV_SH:
         cfg.sh_degree = int(rng.integers(2, 21))
@@ -66,7 +67,7 @@ def test_random_configuration_matches_oracle(seed, monkeypatch):
         prop.step(act, k)
         obs, rew, done, why = prop.get_obs()
         errs = max_group_err(prop.get_state(), st, n_rw)
-        tag = (seed, n, n_rw, grav, hex(flags), int(cfg.fsw_every), int(cfg.fsw_lag), call, k)
+        tag = (seed, n, n_rw, grav, hex(flags), int(cfg.fsw_every), int(cfg.fsw_lag), int(cfg.nav_lag), call, k)
         assert max(errs.values()) < 1e-11, (tag, errs)
         assert np.abs(obs[:4] - o[0][:4]).max() < 1e-11 and np.abs(obs[4] - o[0][4]).max() < 2e-8, tag
         assert np.abs(rew - o[1]).max() < 1e-12 and (why == o[3]).all(), tag

@@ -58,7 +58,7 @@ def test_batch_sampler_ranges_and_reproducibility():
     b = sample_ic_batch(n, n_rw, seed=0)
     c = sample_ic_batch(n, n_rw, seed=1)
     assert np.array_equal(a, b) and not np.array_equal(a, c)
-    assert a.shape == (12 + n_rw + 30, n)
+    assert a.shape == (12 + n_rw + 31, n)
     r = np.linalg.norm(a[0:3], axis=0)
     assert r.min() > 6871e3 * 0.95 - 1 and r.max() < 6871e3 * 1.05 + 1
     assert a[6:9].min() >= 0 and a[6:9].max() < 1

@@ -7,9 +7,13 @@ from basilisk_env_amd.simulators.initial_conditions.batch import sample_ic_batch
 from oracle import oracle
 
 
-def desat_cfg(n_rw=3):
+def desat_cfg(n_rw=3, nav_lag=0):
+    """nav_lag = 0 for the tests of the chain's mechanics (request, mapping, bursts): an FSW tick then works on the
+    state of its own time and the first one of a call coincides with its start.  The task-priority timing has its own
+    test below."""
     cfg = default_config(n_rw, GRAV_PM)
     cfg.flags |= FLAG_POWER | FLAG_DESAT
+    cfg.nav_lag = nav_lag
     return cfg
 
 
@@ -99,3 +103,36 @@ def test_angular_impulse_bookkeeping():
     H1 = C.T @ (I @ st[9:12, 0] + wheel_h(cfg, st)[:, 0])
     assert np.abs((H1 - H0) - impulse).max() < 2e-2 * np.linalg.norm(impulse)     # body-fixed torques: the hub turns ~0.01 rad meanwhile
     assert np.linalg.norm(impulse) > 0.5
+
+
+def test_desat_under_the_reference_task_priorities():
+    """nav_lag = 1 (FSW tasks before the dynamics task of their time): the momentum request of a mode-2 env step is made
+    at its first FSW tick — one FSW period after its start — from the wheel speeds of one integrator step earlier, and
+    the burst starts when the dynamics task latches the command, at the FSW tick's own time.  At t = 0 the wheel-speed
+    message has not been written: a first env step in mode 2 spends its one request on zeros and dumps nothing."""
+    n, t = 1, 12 + 3
+    ic = sample_ic_batch(n, 3, seed=3)
+    ic[t:t + 3] = 0.0
+    ic[12:15] = np.array([[220.0, -180.0, 150.0]]).T
+    cfg = desat_cfg(nav_lag=1)
+    cfg.f_coulomb = 0.0
+    # (a) mode 2 from t = 0: nothing is ever owed or fired during that env step
+    st = ic.copy()
+    steps, ticks = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    oracle.step(cfg, st, steps, ticks, [2], 300)
+    assert np.all(st[t + T_THR_REM:t + T_THR_REM + 8] == 0.0) and np.all(st[t + T_THR_LIM:t + T_THR_LIM + 8] == 0.0)
+    # (b) a later env step in mode 2: request at its first FSW tick (tick 310), from the wheel speeds at tick 309
+    before = st.copy()
+    oracle.step(cfg, st, steps, ticks, [2], 9)
+    assert np.all(st[t + T_THR_REM:t + T_THR_REM + 8] == 0.0)                       # no FSW tick yet in this step
+    at309 = st.copy()
+    oracle.step(cfg, st, steps, ticks, [2], 1)                                       # FSW tick of time 310 runs before this step
+    rem, lim = st[t + T_THR_REM:t + T_THR_REM + 8, 0], st[t + T_THR_LIM:t + T_THR_LIM + 8, 0]
+    assert st[t + 24, 0] == 310 and (lim > 0).any()                                  # burst latched at tick 310
+    hs = wheel_h(cfg, at309)[:, 0]
+    dH = -hs * (np.linalg.norm(hs) - cfg.hs_min) / np.linalg.norm(hs)
+    D = np.array([np.cross(cfg.thr_pos[i], cfg.thr_dir[i]) for i in range(8)])
+    total_on = rem + lim * cfg.dt / 2
+    assert np.abs(D.T @ (total_on * cfg.thr_max_thrust) - dH).max() < 1e-9 * np.linalg.norm(dH) + 0.05 * 0.9 * 1.3
+    # the step in between ran without thrust: the wheels' momentum moved only by the attitude loop's torque
+    assert np.isfinite(st).all() and not np.array_equal(before[12:15], at309[12:15])

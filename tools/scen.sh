@@ -1,12 +1,13 @@
 #!/bin/bash
-# Scenario-level kernel times (65 536 envs): power / full at K = 1 and K = 1800.  Usage: tools/scen.sh TAG
+# Scenario-level kernel times (65 536 envs): power / full at K = 1 and K = 1800.  Usage: tools/scen.sh TAG ["extra bench.py flags"]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-x}
+EXTRA=${2:-}
 O=$R/gpurun_out
 cd $R
 for sc in bare power full; do
-  python bench.py --no-cpu-baseline --no-extra --scenario $sc --steps 200 --warmup 20 > $O/scen_${TAG}_${sc}_k1.json 2>> $O/scen_$TAG.err
-  python bench.py --no-cpu-baseline --no-extra --scenario $sc --substeps 1800 --steps 4 --warmup 1 > $O/scen_${TAG}_${sc}_k1800.json 2>> $O/scen_$TAG.err
+  python bench.py --no-cpu-baseline --no-extra $EXTRA --scenario $sc --steps 200 --warmup 20 > $O/scen_${TAG}_${sc}_k1.json 2>> $O/scen_$TAG.err
+  python bench.py --no-cpu-baseline --no-extra $EXTRA --scenario $sc --substeps 1800 --steps 4 --warmup 1 > $O/scen_${TAG}_${sc}_k1800.json 2>> $O/scen_$TAG.err
 done
 python - <<PY
 import json,glob
