@@ -24,7 +24,7 @@ def run_oracle(cfg, ic, schedule):
     return outs, steps, ticks
 
 
-@pytest.mark.parametrize("name", ["pm_norw", "j2_rw4", "j2_rw4_nolag", "pm_rw3_modes"])
+@pytest.mark.parametrize("name", ["pm_norw", "j2_rw4", "j2_rw4_nolag", "j2_rw4_navnow", "pm_rw3_modes"])
 def test_hip_matches_golden(golden, name):
     case = [c for c in golden["cases"] if c["name"] == name][0]
     cfg = cfg_for_case(case)

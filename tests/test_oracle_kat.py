@@ -290,8 +290,9 @@ def test_fsw_task_order_lag():
     act = np.array([0, 1, 2, 0, 1, 0], np.int32)
     t = 12 + n_rw
     lag, nolag = default_config(n_rw, GRAV_PM_J2), default_config(n_rw, GRAV_PM_J2)
-    assert lag.fsw_lag == 1
+    assert lag.fsw_lag == 1 and lag.nav_lag == 1
     nolag.fsw_lag = 0
+    lag.nav_lag = nolag.nav_lag = 0          # FSW ticks on the state of their own time: isolates the model order
     # first FSW period: zero torque, and the pending torque is exactly what the un-lagged chain applies now
     s1, _ = run(lag, ic, act, 1)
     s0, _ = run(nolag, ic, act, 1)
@@ -305,6 +306,7 @@ def test_fsw_task_order_lag():
     # a wheel-free torque-free first second: lagged hub is untouched by the controller (only L_ext acts)
     free = default_config(n_rw, GRAV_PM_J2)
     free.K = free.P = 0.0
+    free.nav_lag = 0
     sf, _ = run(free, ic, act, 10)
     s1c, _ = run(lag, ic, act, 10)
     assert np.array_equal(sf[:12 + n_rw], s1c[:12 + n_rw])
@@ -314,3 +316,52 @@ def test_fsw_task_order_lag():
     oracle.step(lag, st, steps, ticks, act, 4)
     oracle.step(lag, st, steps, ticks, act, 7)
     assert np.array_equal(st, s1b)
+
+
+def test_fsw_task_priorities_nav_lag():
+    """FSW tasks at priority 100 / 50, dynamics tasks at the default (reference leoPowerAttitudeSimulator.py:383-386,
+    :101-103): with nav_lag = 1 the FSW tick of time k F dt runs before the dynamics task of that time - on the state
+    of tick k F - 1 - and its torque acts from tick k F on; the tick at t = 0 reads messages nobody has written."""
+    n, n_rw, F = 5, 4, 10
+    ic = sample_ic_batch(n, n_rw, seed=33)
+    act = np.array([0, 1, 2, 0, 1], np.int32)
+    t = 12 + n_rw
+    nav, now = default_config(n_rw, GRAV_PM_J2), default_config(n_rw, GRAV_PM_J2)
+    nav.fsw_lag = now.fsw_lag = 0            # guidance and control on one tick: isolates the task timing
+    now.nav_lag = 0
+    assert nav.fsw_every == F
+    # t = 0 tick on an all-zero navigation message: hillPoint gives the zero reference (no torque for mode 0), the
+    # inertial modes steer a spacecraft "at sigma_BN = 0" to sigma_R0N; the logged |sigma_BR| is that of the message
+    s9, o9 = run(nav, ic, act, F - 1)
+    u0 = s9[t + 3:t + 3 + n_rw]
+    assert np.all(u0[:, act == 0] == 0.0) and np.all(np.abs(u0[:, act != 0]).max(axis=0) > 0)
+    assert np.all(s9[t + 30, act == 0] == 0.0)
+    sR = np.linalg.norm(np.asarray(nav.sigma_R0N[:3], float))
+    assert np.allclose(s9[t + 30, act != 0], sR, rtol=1e-14)
+    assert np.array_equal(o9[0][0], s9[t + 30])                                  # obs[0] is the message, not the end state
+    # every env with the same mode got the same command out of the zero message, whatever its true state
+    assert np.ptp(u0[:, act == 1], axis=1).max() == 0.0
+    # the first real tick: on the state of tick F - 1, acting from tick F.  The same-tick chain started from that state
+    # commands the same torque, bit for bit
+    s10, _ = run(nav, ic, act, F)
+    st = s9.copy()
+    st[t:] = 0.0
+    st[t:t + 3] = s9[t:t + 3]
+    ref, _ = run(now, st, act, 1)
+    assert np.array_equal(s10[t + 3:t + 3 + n_rw], ref[t + 3:t + 3 + n_rw])
+    assert not np.array_equal(s10[t + 3:t + 3 + n_rw], u0)
+    # ... and step F - 1 -> F itself still ran with the old command: the hub state at tick F is the un-updated one
+    hold = default_config(n_rw, GRAV_PM_J2)
+    hold.fsw_lag, hold.fsw_every = 0, 1000                                       # nav_lag = 1: only the t = 0 tick ever runs
+    sh, _ = run(hold, ic, act, F)
+    assert np.array_equal(sh[:12 + n_rw], s10[:12 + n_rw])
+    s11, _ = run(nav, ic, act, F + 1)
+    sh11, _ = run(hold, ic, act, F + 1)
+    assert not np.array_equal(sh11[9:12], s11[9:12])                             # from tick F on the new torque acts
+    # a launch is a launch: 23 = 9 + 1 + 13 (a boundary right before and right after the FSW tick's step)
+    whole, ow = run(nav, ic, act, 23)
+    st = ic.copy()
+    steps, ticks = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    for k in (9, 1, 13):
+        o = oracle.step(nav, st, steps, ticks, act, k)
+    assert np.array_equal(st, whole) and np.array_equal(o[0], ow[0])
