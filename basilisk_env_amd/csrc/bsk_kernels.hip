@@ -154,9 +154,9 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
         ev.sun_on = a.extra.mu_sun != 0.0;
         ev.drag_on = false;
         ev.rho = 0.0;
-        ev.s3.sun = sg.sun;
-        ev.s3.mu = a.extra.mu_sun;
-        ev.s3.sun3 = (a.extra.mu_sun * sg.ism * sg.ism * sg.ism) * sg.sun;
+        ev.s3.sh = sg.ism * sg.sun;
+        ev.s3.k = a.extra.mu_sun * sg.ism * sg.ism * sg.ism;
+        ev.s3.A0 = mk(0, 0, 0);
         ev.thr_on = false;
         ev.e2 = 0;
         ev.m0 = ev.m1 = ev.m2 = 0;
@@ -307,6 +307,9 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
         }
 #endif
         j += m;
+        if constexpr (FULL) {
+            if (ev.sun_on) third_body_anchor(ev.s3, sg.sun, a.extra.mu_sun, x.r);   // exact at the chunk's first position
+        }
         for (int t = 0; t < m; ++t, ++tick) {
             if constexpr (FULL) {
                 if (drag_cfg) {   // exponentialAtmosphere, refreshed once per dyn tick
