@@ -41,7 +41,10 @@ __device__ __forceinline__ double dot(V3 a, V3 b) { return fma(a.x, b.x, fma(a.y
 __device__ __forceinline__ V3 cross(V3 a, V3 b) {
     return V3{fma(a.y, b.z, -(a.z * b.y)), fma(a.z, b.x, -(a.x * b.z)), fma(a.x, b.y, -(a.y * b.x))};
 }
-// c - a x b, folded into FMA chains (6 ops)
+// c + a x b and c - a x b, folded into FMA chains (6 ops)
+__device__ __forceinline__ V3 add_cross(V3 c, V3 a, V3 b) {
+    return V3{fma(a.y, b.z, fma(-a.z, b.y, c.x)), fma(a.z, b.x, fma(-a.x, b.z, c.y)), fma(a.x, b.y, fma(-a.y, b.x, c.z))};
+}
 __device__ __forceinline__ V3 sub_cross(V3 c, V3 a, V3 b) {
     return V3{fma(-a.y, b.z, fma(a.z, b.y, c.x)), fma(-a.z, b.x, fma(a.x, b.z, c.y)), fma(-a.x, b.y, fma(a.y, b.x, c.z))};
 }
@@ -868,8 +871,10 @@ __device__ __forceinline__ void third_body_anchor(Sun3& s3, V3 sun, double mu, V
     s3.A0 = a - g;
 }
 
+// `base` is added to the result (the third body's constant part at the full-scenario levels: one FMA instead of a
+// multiply and an add per component)
 template <int GRAV, int SPLIT, class Hot>
-__device__ __forceinline__ V3 gravity(const Hot& c, V3 r, double tsim) {
+__device__ __forceinline__ V3 gravity(const Hot& c, V3 r, double tsim, V3 base) {
     if constexpr (GRAV == BSK_GRAV_SH) {
         double sn, cs;
         sincos(c.planet_rate * tsim, &sn, &cs);
@@ -878,7 +883,7 @@ __device__ __forceinline__ V3 gravity(const Hot& c, V3 r, double tsim) {
         if constexpr (SPLIT == 4) af = gravity_sh_dpp<false>(c, pf);
         else if constexpr (SPLIT == 5) af = gravity_sh_dpp<true>(c, pf);
         else af = gravity_sh(c, pf);
-        return mk(fma(cs, af.x, -sn * af.y), fma(sn, af.x, cs * af.y), af.z);
+        return mk(fma(cs, af.x, fma(-sn, af.y, base.x)), fma(sn, af.x, fma(cs, af.y, base.y)), af.z + base.z);
     } else {
         double zz = r.z * r.z;
         double r2 = fma(r.x, r.x, fma(r.y, r.y, zz));
@@ -891,9 +896,9 @@ __device__ __forceinline__ V3 gravity(const Hot& c, V3 r, double tsim) {
             double kj = c.j2k * (ir3 * ir2);    // 1.5 J2 mu Re^2 / r^5
             double kxy = fma(kj, fma(5.0, z2, -1.0), k0);
             double kz = fma(-2.0, kj, kxy);     // k0 + kj (5 z2 - 3)
-            return V3{kxy * r.x, kxy * r.y, kz * r.z};
+            return V3{fma(kxy, r.x, base.x), fma(kxy, r.y, base.y), fma(kz, r.z, base.z)};
         } else {
-            return k0 * r;
+            return axpy(k0, r, base);
         }
     }
 }
@@ -961,6 +966,7 @@ __device__ __forceinline__ void thrusters(const Env& ev, int de2, V3 sig, V3& aN
 // the inertial velocity.  Only the projected-area sum S = sum c_i (n_i . v)+ and its moment
 // Rc = sum c_i (n_i . v)+ r_i need the body frame; the force is along -v in ANY frame, so the
 // inertial acceleration is -(1/2 rho S / m) v_N with no rotation back, and L_B = Rc x (-1/2 rho v_B).
+// Accumulates the acceleration into aN and the torque into LB.
 template <bool GENERIC>
 __device__ __forceinline__ void facet_drag(const Env& ev, V3 sig, V3 vN, V3& aN, V3& LB) {
     const double q2 = dot(sig, sig), op = 1.0 + q2, iop2 = rcp_nr(op * op);
@@ -1010,9 +1016,9 @@ __device__ __forceinline__ void facet_drag(const Env& ev, V3 sig, V3 vN, V3& aN,
         }
     }
     const double kq = -0.5 * ev.rho;                      // 0 for a lane above the atmosphere
-    LB = cross(Rc, kq * vB);
-    if (!GENERIC) aN = (S * kq) * vN;                               // S already carries 1/m
-    else aN = (mul_k<KC_IMASS>(ev.kt.c, S) * kq) * vN;
+    LB = add_cross(LB, Rc, kq * vB);
+    if (!GENERIC) aN = axpy(S * kq, vN, aN);                        // S already carries 1/m
+    else aN = axpy(mul_k<KC_IMASS>(ev.kt.c, S) * kq, vN, aN);
 }
 
 // Integration state inside one RK4 step.  The hub sees the wheels only through their total
@@ -1030,21 +1036,18 @@ template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT>
 __device__ __forceinline__ void eom(const HotCfg<NRW, DIAG>& c, const Core& x, V3 rhs0, V3 T, double tsim, const Env& ev,
                                     int de2, Core& d) {
     d.r = x.v;
-    d.v = gravity<GRAV, SPLIT>(c, x.r, tsim);
     if constexpr (is_full<FEAT>()) {
-        if (ev.sun_on) d.v = tidal(ev.s3, x.r, d.v + ev.s3.A0);
-        if (ev.drag_on) {
-            V3 aN, LB;
-            facet_drag<FEAT == FEAT_FULLG>(ev, x.s, x.v, aN, LB);
-            d.v = d.v + aN;
-            rhs0 = rhs0 + LB;
-        }
+        // Sun third body, unconditionally: with the flag off k and A0 are zero and both FMAs return their addend
+        d.v = tidal(ev.s3, x.r, gravity<GRAV, SPLIT>(c, x.r, tsim, ev.s3.A0));
+        if (ev.drag_on) facet_drag<FEAT == FEAT_FULLG>(ev, x.s, x.v, d.v, rhs0);
         if (ev.thr_on) {
             V3 aN, LB;
             thrusters(ev, de2, x.s, aN, LB);
             d.v = d.v + aN;
             rhs0 = rhs0 + LB;
         }
+    } else {
+        d.v = gravity<GRAV, SPLIT>(c, x.r, tsim, mk(0, 0, 0));
     }
     // sigma' = 1/4 [(1 - s^2) w + 2 s x w + 2 (s.w) s],  with hw = w/2:
     //        = (1 - s^2)/2 hw + s x hw + (s.hw) s

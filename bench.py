@@ -59,6 +59,9 @@ def parse(argv=None):
                    help="bare = BASELINE configs[2] as named (headline); power / full add the reference scenario's "
                         "power system / + Sun third body, drag and desaturation (what the drop-in env runs)")
     p.add_argument("--lds-scratch", action="store_true", help="BSK_FLAG_LDS_SCRATCH kernel variant (RK4 accumulator in LDS)")
+    p.add_argument("--features", default=None,
+                   help="measurement only: comma list out of power,sun,drag,desat replacing the scenario's feature flags "
+                        "(any of sun/drag/desat selects the full-scenario kernel)")
     p.add_argument("--fsw-timing", choices=["reference", "same-tick"], default="reference",
                    help="reference: bsk_config.fsw_lag = nav_lag = 1 (the reference's task order and priorities); "
                         "same-tick: both 0 (measurement A/B only)")
@@ -338,6 +341,12 @@ def main():
     if a.scenario != "bare":
         from basilisk_env_amd._lib import FLAG_DESAT, FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY
         cfg.flags |= FLAG_POWER | ((FLAG_SUN_THIRD_BODY | FLAG_DRAG | FLAG_DESAT) if a.scenario == "full" else 0)
+    if a.features is not None:
+        from basilisk_env_amd._lib import FLAG_DESAT, FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY
+        names = {"power": FLAG_POWER, "sun": FLAG_SUN_THIRD_BODY, "drag": FLAG_DRAG, "desat": FLAG_DESAT}
+        cfg.flags &= ~(FLAG_POWER | FLAG_SUN_THIRD_BODY | FLAG_DRAG | FLAG_DESAT)
+        for f in filter(None, a.features.split(",")):
+            cfg.flags |= names[f]
     if a.lds_scratch:
         cfg.flags |= FLAG_LDS_SCRATCH
     if a.fsw_timing == "same-tick":
@@ -380,7 +389,7 @@ def main():
                                "sub-steps (reference FSW task order and priorities: fsw_lag = nav_lag = 1), synthetic random-orbit batch PCG64(rank)"
                                % ("4" if sh else "2", n, "degree-70 spherical-harmonic (synthetic Kaula field)" if sh else "J2",
                                   a.substeps),
-                   "envs_per_gpu": n, "substeps": a.substeps, "scenario": a.scenario, "lds_scratch": bool(a.lds_scratch), "fsw_timing": a.fsw_timing,
+                   "envs_per_gpu": n, "substeps": a.substeps, "scenario": a.scenario, "lds_scratch": bool(a.lds_scratch), "fsw_timing": a.fsw_timing, "features": a.features,
                    "sharding": "env ranges, no step-path collective"},
         "roofline": fp64 if fp64_bound else hbm,
         "rk4_substeps_per_s": value * a.substeps,
