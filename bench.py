@@ -152,6 +152,21 @@ def kernel_time(prop, d_act_ptr, substeps, launches, stride=None):
     return mean_ms, n, {}
 
 
+def bound_by_wall(kernel_ms, kstats, elapsed_s, steps):
+    """Launches of one stream run one after the other, so the wall time per launch of the un-stamped loop is an upper
+    bound of the kernel's average duration.  A stamped pass that reads above it caught more than a tenth of slow
+    stamped launches (the trimmed mean sets aside a tenth on each side): the bound is reported then, the stamped
+    figures stay beside it."""
+    wall_ms = elapsed_s / steps * 1e3
+    kstats = dict(kstats)
+    if kernel_ms > wall_ms:
+        kstats["stamped_trimmed_mean_us"] = kernel_ms * 1e3
+        kstats["kernel_us_source"] = "wall time per launch of the un-stamped timed loop (upper bound of the average duration)"
+        return wall_ms, kstats
+    kstats["kernel_us_source"] = "stamped pass"
+    return kernel_ms, kstats
+
+
 def cpu_baseline(cfg, n_rw, substeps, budget_s=12.0, n=8192):
     """The CPU oracle (plain-C restatement, oracle/bsk_oracle.c) on the host cores of this box:
     OpenMP over spacecraft, bounded to ~budget_s.  A reported baseline, not the target."""
@@ -362,8 +377,10 @@ def main():
     torch.cuda.synchronize()
     sync = torch.cuda.synchronize
 
-    el = max_over_ranks(timed_run(prop, d_act.data_ptr(), a.substeps, a.steps, a.warmup, barrier, sync))
+    el_local = timed_run(prop, d_act.data_ptr(), a.substeps, a.steps, a.warmup, barrier, sync)
+    el = max_over_ranks(el_local)
     kernel_ms, n_launch, kstats = kernel_time(prop, d_act.data_ptr(), a.substeps, min(STAMPED_LAUNCHES, max(a.steps, 4)))
+    kernel_ms, kstats = bound_by_wall(kernel_ms, kstats, el_local, a.steps)
     obs, rew, done, why = prop.get_obs()
     assert np.isfinite(obs).all() and np.isfinite(rew).all()
     info = prop.kernel_info()

@@ -183,3 +183,14 @@ def test_committed_bench_line_has_the_contract_keys():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     with open(os.path.join(ROOT, "BASELINE.json")) as f:
         assert d["metric"] == json.load(f)["metric"]
+
+
+def test_kernel_time_is_bounded_by_the_wall_time_per_launch():
+    """bench.bound_by_wall: serialized launches of one stream cannot average longer than the loop's wall time per
+    launch; a stamped pass that reads above it is replaced by the bound and kept beside it."""
+    import bench
+    k, st = bench.bound_by_wall(7.8e-3, {"median_us": 7.1}, 7.36e-6 * 10000, 10000)
+    assert abs(k - 7.36e-3) < 1e-9 and abs(st["stamped_trimmed_mean_us"] - 7.8) < 1e-9 and "wall" in st["kernel_us_source"]
+    assert st["median_us"] == 7.1
+    k, st = bench.bound_by_wall(7.2e-3, {}, 8.2e-6 * 20, 20)             # cold 20-step loop: the stamped pass stands
+    assert k == 7.2e-3 and st["kernel_us_source"] == "stamped pass"
