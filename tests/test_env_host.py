@@ -386,3 +386,31 @@ def test_single_env_reuses_its_device_handle_across_resets():
     assert steps[0] == 0 and ticks[0] == 0
     env.close()
     assert not S._IDLE_PROPAGATORS
+
+
+def test_info_list_is_a_list_of_distinct_dicts_made_on_demand():
+    """leoPowerAttitudeVecEnv.InfoList: what step_wait returns as ``infos``.  It must behave as the plain list of one
+    dict per env that stable-baselines' wrappers index, slice, iterate, copy and write into, without building the
+    dicts nobody looks at (65 536 of them cost more than the step kernel)."""
+    import copy
+    import pickle
+    from basilisk_env_amd.envs.leoPowerAttitudeVecEnv import InfoList
+    infos = InfoList(5)
+    infos[3] = {"episode": {"r": 1.0, "l": 2}}
+    assert isinstance(infos, list) and len(infos) == 5
+    assert infos[0] == {} and infos[0] is infos[0] and infos[0] is not infos[1]      # made once, never shared
+    infos[1]["x"] = 1                                                               # a wrapper writing into info
+    assert infos[1] == {"x": 1} and infos[2] == {} and infos[-1] == {}
+    assert [i.get("episode") for i in infos] == [None, None, None, {"r": 1.0, "l": 2}, None]
+    assert infos[1:4] == [{"x": 1}, {}, {"episode": {"r": 1.0, "l": 2}}] and type(infos[:]) is list
+    assert list(infos)[1] is infos[1] and list(reversed(infos))[0] is infos[4]
+    assert infos == [{}, {"x": 1}, {}, {"episode": {"r": 1.0, "l": 2}}, {}] and {"x": 1} in infos
+    for clone in (copy.copy(infos), copy.deepcopy(infos), pickle.loads(pickle.dumps(infos)), infos.copy(), infos + []):
+        assert type(clone) is list and clone == list(infos)
+    assert len({id(d) for d in infos}) == 5
+    with pytest.raises(TypeError):
+        infos * 2
+    assert InfoList(1)[0] == {} and len(InfoList(0)) == 0
+    # untouched slots cost nothing: no dict exists until somebody asks
+    big = InfoList(100000)
+    assert list.__getitem__(big, 99999) is None and big[99999] == {} and list.__getitem__(big, 99999) is big[99999]

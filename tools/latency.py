@@ -48,4 +48,20 @@ for _ in range(5):
 out["single_env"] = {"first_reset_ms": round(first * 1e3, 3), "pooled_reset_ms": round(min(ts) * 1e3, 3),
                      "step_ms": round((time.perf_counter() - t0) / 5 * 1e3, 3)}
 env.close()
+# the batched sibling as an RL loop drives it: LeoPowerAttVecEnv.step() = H2D of the actions, the step kernel, D2H of
+# obs / reward / done, the (N,5,1) observation array and the per-env infos (wall time per 180 s env step)
+from basilisk_env_amd.envs import LeoPowerAttVecEnv  # noqa: E402
+out["vec_env_step_ms"] = {}
+for n, pool in ((1024, 0), (65536, 0), (65536, 4096)):
+    venv = LeoPowerAttVecEnv(n, device_reset_pool=pool)
+    venv.reset()
+    acts = np.zeros(n, dtype=np.int64)
+    venv.step(acts)
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        venv.step(acts)
+        ts.append(time.perf_counter() - t0)
+    out["vec_env_step_ms"]["%d%s" % (n, "_device_reset" if pool else "")] = round(min(ts) * 1e3, 3)
+    venv.close()
 print(json.dumps(out))
