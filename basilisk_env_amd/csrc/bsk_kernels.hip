@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
         if constexpr (FULL) {
             if (ev.sun_on) third_body_anchor(ev.s3, sg.sun, a.extra.mu_sun, x.r);   // exact at the chunk's first position
         }
-        for (int t = 0; t < m; ++t, ++tick) {
+        auto one_tick = [&](int t) __attribute__((always_inline)) {
             if constexpr (FULL) {
                 if (drag_cfg) {   // exponentialAtmosphere, refreshed once per dyn tick
                     const double r2 = dot(x.r, x.r), rm = r2 * rsqrt_nr(r2);
@@ -338,6 +338,15 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
             // after a chunk's first step the new commands act; plain moves, no-ops on every later step (measured
             // against a conditional latch and against splitting the chunk: profiles/r02/fsw_timing_cost.txt)
             if constexpr (NRW > 0) latch();
+        };
+        if constexpr (FEAT == 0 && GRAV != BSK_GRAV_SH) {
+            // two ticks per trip at the bare level: the RK4 step's register rotation (16 moves per step) disappears
+            // between the copies, -2 % at K = 1800; the levels above it lose as much to their larger bodies (and a
+            // `#pragma unroll 1` there is not neutral either: it moved SGPR spill reloads into the power level's loop)
+#pragma unroll 2
+            for (int t = 0; t < m; ++t, ++tick) one_tick(t);
+        } else {
+            for (int t = 0; t < m; ++t, ++tick) one_tick(t);
         }
         np += m;
         if constexpr (NRW > 0) latch();        // the t = 0 chunk has no step
