@@ -347,6 +347,7 @@ int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool&
     k.kt[32 + bsk::KC_RHO0] = p.ex.base_density;
     k.kt[32 + bsk::KC_NIH] = -p.ex.inv_scale_height;
     k.kt[32 + bsk::KC_REQIH] = c.req * p.ex.inv_scale_height;
+    k.kt[32 + bsk::KC_RSKIP] = p.ex.rho_skip;
     // thruster subset table: row m = sums over the set bits of m, ascending thruster index
     for (int m = 0; m < (1 << BSK_MAX_THR); ++m) {
         double f[6] = {0, 0, 0, 0, 0, 0};

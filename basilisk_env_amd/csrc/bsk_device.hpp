@@ -30,6 +30,17 @@
 
 namespace bsk {
 
+// A taken branch costs a wave that runs alone on its SIMD ~55 clocks of instruction fetch (SQ_WAIT_ANY of the
+// full-scenario level: 12 taken branches per tick = 15 % of its cycles).  Blocks that are rarely entered are marked so
+// that the compiler lays them out of line and the common path falls through.
+#ifdef BSK_NO_EXPECT
+#define BSK_UNLIKELY(x) (x)
+#define BSK_LIKELY(x) (x)
+#else
+#define BSK_LIKELY(x) __builtin_expect(!!(x), 1)
+#define BSK_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#endif
+
 struct V3 {
     double x, y, z;
 };
@@ -183,7 +194,7 @@ struct ColdCfg {
 // entries of the broadcast table (ColdCfg::kt): row A, row B, row C
 enum { KA_G = 0, KA_JS = 12 };                                 // wheel spin axes g[i][k] at 3 i + k, Js_i
 enum { KB_IJS = 0, KB_FAC = 4, KB_FAD = 10 };                  // 1/Js_i, facet half sums / differences (6 + 6)
-enum { KC_IMASS = 0, KC_NB = 1, KC_KFLUX = 4, KC_RHO0 = 5, KC_NIH = 6, KC_REQIH = 7 };   // 1/m, panel normal, ...
+enum { KC_IMASS = 0, KC_NB = 1, KC_KFLUX = 4, KC_RHO0 = 5, KC_NIH = 6, KC_REQIH = 7, KC_RSKIP = 8 };   // 1/m, panel normal, ...
 
 // Guidance / observation / reward constants: by value in the kernarg (used once per launch, outside
 // the RK4 loop, so they may be parked in VGPR lanes across it at no cost to the loop).
@@ -540,7 +551,7 @@ __device__ __forceinline__ void power_tick(const PowerCfg& pc, const SunGeom& g,
         const double proj = fmax(fma(pc.nB[0], sB.x, fma(pc.nB[1], sB.y, pc.nB[2] * sB.z)), 0.0);
         L->g[t][lane] = pc.kflux * (id * id) * proj;
     }
-    if (band) {
+    if (BSK_UNLIKELY(band)) {
         const int e = __hip_atomic_fetch_add(&L->qcount, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         L->qr[0][e] = r.x; L->qr[1][e] = r.y; L->qr[2][e] = r.z;
         L->qown[e] = lane | (t << 8);
@@ -1032,15 +1043,17 @@ struct Core {
     V3 r, v, s, w, p;
 };
 
-template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT>
+// THR: the step runs inside a thruster burst of some lane of the wave (the tick loop picks the instantiation, so the
+// steps outside bursts - nearly all - carry no thruster code and no branch around it)
+template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT, bool THR>
 __device__ __forceinline__ void eom(const HotCfg<NRW, DIAG>& c, const Core& x, V3 rhs0, V3 T, double tsim, const Env& ev,
                                     int de2, Core& d) {
     d.r = x.v;
     if constexpr (is_full<FEAT>()) {
         // Sun third body, unconditionally: with the flag off k and A0 are zero and both FMAs return their addend
         d.v = tidal(ev.s3, x.r, gravity<GRAV, SPLIT>(c, x.r, tsim, ev.s3.A0));
-        if (ev.drag_on) facet_drag<FEAT == FEAT_FULLG>(ev, x.s, x.v, d.v, rhs0);
-        if (ev.thr_on) {
+        if (BSK_LIKELY(ev.drag_on)) facet_drag<FEAT == FEAT_FULLG>(ev, x.s, x.v, d.v, rhs0);
+        if constexpr (THR) {
             V3 aN, LB;
             thrusters(ev, de2, x.s, aN, LB);
             d.v = d.v + aN;
@@ -1107,7 +1120,7 @@ __device__ __forceinline__ void acc_load(AccP A, int lane, Core& a) {
 // shadow-set switch once per completed step.  Motor torque and Coulomb friction are evaluated
 // from the wheel speeds at the start of the step and held through its four stages (the RW
 // effector updates both once per dyn tick, outside the equations of motion).
-template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT, class WV>
+template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT, bool THR = false, class WV>
 __device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, const WV& wv, State<NRW>& x,
                                          const double* u, V3 lext, double t0, const Env& ev, AccP acc_lds = nullptr) {
     Core y, k, yt, acc;
@@ -1128,21 +1141,21 @@ __device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, const WV& w
     AccP A = nullptr;
     int lane = 0;
     if constexpr (LDSACC) { A = acc_lds; lane = (int)(threadIdx.x & 63u); }
-    eom<GRAV, NRW, DIAG, FEAT, SPLIT>(c, y, rhs0, T, t0, ev, 0, k);
+    eom<GRAV, NRW, DIAG, FEAT, SPLIT, THR>(c, y, rhs0, T, t0, ev, 0, k);
     core_axpy<NRW>(c.h6, k, y, acc);
     if constexpr (LDSACC) acc_store<NRW>(A, lane, acc);
     core_axpy<NRW>(c.h2, k, y, yt);
-    eom<GRAV, NRW, DIAG, FEAT, SPLIT>(c, yt, rhs0, T, t0 + c.h2, ev, 1, k);
+    eom<GRAV, NRW, DIAG, FEAT, SPLIT, THR>(c, yt, rhs0, T, t0 + c.h2, ev, 1, k);
     if constexpr (LDSACC) acc_load<NRW>(A, lane, acc);
     core_axpy<NRW>(c.h3, k, acc, acc);
     if constexpr (LDSACC) acc_store<NRW>(A, lane, acc);
     core_axpy<NRW>(c.h2, k, y, yt);
-    eom<GRAV, NRW, DIAG, FEAT, SPLIT>(c, yt, rhs0, T, t0 + c.h2, ev, 1, k);
+    eom<GRAV, NRW, DIAG, FEAT, SPLIT, THR>(c, yt, rhs0, T, t0 + c.h2, ev, 1, k);
     if constexpr (LDSACC) acc_load<NRW>(A, lane, acc);
     core_axpy<NRW>(c.h3, k, acc, acc);
     if constexpr (LDSACC) acc_store<NRW>(A, lane, acc);
     core_axpy<NRW>(c.h, k, y, yt);
-    eom<GRAV, NRW, DIAG, FEAT, SPLIT>(c, yt, rhs0, T, t0 + c.h, ev, 2, k);
+    eom<GRAV, NRW, DIAG, FEAT, SPLIT, THR>(c, yt, rhs0, T, t0 + c.h, ev, 2, k);
     if constexpr (LDSACC) acc_load<NRW>(A, lane, acc);
     core_axpy<NRW>(c.h6, k, acc, yt);
     const V3 dw = yt.w - y.w;
@@ -1151,7 +1164,7 @@ __device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, const WV& w
     if constexpr (NRW > 0) wv.tail(dw, tqj, x.Om);
     x.r = yt.r; x.v = yt.v; x.s = yt.s; x.w = yt.w;
     double s2 = dot(x.s, x.s);
-    if (s2 > 1.0) x.s = (-rcp_nr(s2)) * x.s;
+    if (BSK_UNLIKELY(s2 > 1.0)) x.s = (-rcp_nr(s2)) * x.s;
 }
 
 // --------------------------------------------------------------------------------------------

@@ -323,17 +323,24 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
 #else
                     const double rho = mul_k<KC_RHO0>(kt.c, exp(fmac_k<KC_NIH>(get_k<KC_REQIH>(kt.c), kt.c, rm)));
 #endif
-                    ev.rho = rho >= a.extra.rho_skip ? rho : 0.0;   // below it |a_drag| < 1e-19 m/s^2: dropped
+                    // below the skip density |a_drag| < 1e-19 m/s^2: dropped.  (The threshold comes from the broadcast
+                    // table: as a kernel argument it was re-read by a scalar load, and waited for, on every tick.)
+                    ev.rho = rho >= get_k<KC_RSKIP>(kt.c) ? rho : 0.0;
                     ev.drag_on = __builtin_amdgcn_ballot_w64(ev.rho != 0.0) != 0;   // any lane of the wave inside the atmosphere
                 }
                 if (desat) {
                     ev.e2 = 2 * (tick - thr_t0);
                     // some thruster of some lane still inside its burst
                     ev.thr_on = __builtin_amdgcn_ballot_w64(ev.thr_max > 0 && ev.e2 <= ev.thr_max) != 0;
-                    if (ev.thr_on) thr_masks(ev);
+                    if (BSK_UNLIKELY(ev.thr_on)) thr_masks(ev);
                 }
             }
-            rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT>(c, wv, x, u, lext, (double)tick * c.h, ev, accp);
+            if constexpr (FULL) {
+                if (BSK_LIKELY(!ev.thr_on)) rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT, false>(c, wv, x, u, lext, (double)tick * c.h, ev, accp);
+                else rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT, true>(c, wv, x, u, lext, (double)tick * c.h, ev, accp);
+            } else {
+                rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT, false>(c, wv, x, u, lext, (double)tick * c.h, ev, accp);
+            }
             if constexpr (POWER) power_tick<FULL>(a.power, sg, x.r, x.s, L, np + t, lane, kt.c);
             // after a chunk's first step the new commands act; plain moves, no-ops on every later step (measured
             // against a conditional latch and against splitting the chunk: profiles/r02/fsw_timing_cost.txt)
