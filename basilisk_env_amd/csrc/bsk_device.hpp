@@ -1130,10 +1130,20 @@ __device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, const WV& w
     double tqj[NRW > 0 ? NRW : 1], tq[NRW > 0 ? NRW : 1];
 #pragma unroll
     for (int i = 0; i < NRW; ++i) {
-        // Coulomb friction -fc sign(Om), 0 at rest; branch-free
+        // Coulomb friction -fc sign(Om), 0 at rest, as three fp64 instructions: fc sign(Om) = clamp(2^1000 Om, -fc, fc)
+        // (exactly +-fc for every |Om| >= fc 2^-1000 - wheel speeds are 1e-10 rad/s and up - and exactly 0 at rest;
+        // the sign-copy + compare + two selects it replaces took six)
+#ifndef BSK_FRICTION_CLAMP
+#define BSK_FRICTION_CLAMP 1
+#endif
+#if BSK_FRICTION_CLAMP
+        const double fs = fmin(fmax(x.Om[i] * 0x1p1000, -c.fc), c.fc);
+        tq[i] = u[i] - fs;
+#else
         double fr = __builtin_copysign(c.fc, -x.Om[i]);
         fr = (x.Om[i] == 0.0) ? 0.0 : fr;
         tq[i] = u[i] + fr;
+#endif
     }
     if constexpr (NRW > 0) wv.head(tq, x.Om, T, y.p, tqj);
     const V3 rhs0 = lext - T;

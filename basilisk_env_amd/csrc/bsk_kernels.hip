@@ -269,10 +269,12 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
             const bool anyz = navlag && __builtin_amdgcn_ballot_w64(z0) != 0;
             if (z0 || (!anyz && phase == trig)) {
                 State<NRW> nav = x;
-                if (z0) {
-                    nav.r = mk(0, 0, 0); nav.v = mk(0, 0, 0); nav.s = mk(0, 0, 0); nav.w = mk(0, 0, 0);
+                if (BSK_UNLIKELY(anyz)) {              // wave-uniform: the per-lane selects only exist at t = 0
+                    if (z0) {
+                        nav.r = mk(0, 0, 0); nav.v = mk(0, 0, 0); nav.s = mk(0, 0, 0); nav.w = mk(0, 0, 0);
 #pragma unroll
-                    for (int k = 0; k < NRW; ++k) nav.Om[k] = 0.0;
+                        for (int k = 0; k < NRW; ++k) nav.Om[k] = 0.0;
+                    }
                 }
                 fsw_tick(nav, tick + ((navlag && !z0) ? 1 : 0));
                 if (!navlag) latch();
