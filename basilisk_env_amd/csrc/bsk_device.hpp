@@ -1274,18 +1274,38 @@ __device__ __forceinline__ Guid guidance(const double* __restrict__ sigma_R0N, c
     return g;
 }
 
+// The FSW chain's constants: the head of the cold block (28 doubles), fetched in ONE batch when an FSW tick starts.
+// Read where they are used they cost the chain two dependent memory round trips (sigma_R0N inside the guidance
+// branch, the gains after it), and a wave that is alone on its SIMD waits each of them out.
+struct FswCfg {
+    double inertia[9];
+    double map[BSK_MAX_RW][3];
+    double u_max, u_min, K, P;
+    double sigma_R0N[3];
+};
+static_assert(offsetof(ColdCfg, sigma_R0N) + sizeof(double[3]) == sizeof(FswCfg) && offsetof(ColdCfg, map) == offsetof(FswCfg, map) &&
+              offsetof(ColdCfg, K) == offsetof(FswCfg, K), "FswCfg mirrors the head of ColdCfg");
+__device__ __forceinline__ FswCfg load_fsw(const ColdCfg* __restrict__ c) {
+    FswCfg f;
+    const double* __restrict__ src = (const double*)c;
+    double* dst = (double*)&f;
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(FswCfg) / sizeof(double)); ++k) dst[k] = src[k];
+    return f;
+}
+
 // MRP_Feedback -> rwMotorTorque -> wheel saturation / dead-band
 template <int NRW>
-__device__ __forceinline__ void control(const ColdCfg* __restrict__ c, const Guid& g, double* u) {
+__device__ __forceinline__ void control(const FswCfg& c, const Guid& g, double* u) {
     V3 wBN = g.omega_BR_B + g.omega_RN_B;
-    V3 Lr = c->K * g.sigma_BR + c->P * g.omega_BR_B;
-    Lr = Lr - cross(g.omega_RN_B, mv(c->inertia, wBN));
-    Lr = Lr + mv(c->inertia, cross(wBN, g.omega_RN_B) - g.domega_RN_B);
+    V3 Lr = c.K * g.sigma_BR + c.P * g.omega_BR_B;
+    Lr = Lr - cross(g.omega_RN_B, mv(c.inertia, wBN));
+    Lr = Lr + mv(c.inertia, cross(wBN, g.omega_RN_B) - g.domega_RN_B);
     // module output is -Lr (torque on the body); wheels need u_s = -map * (-Lr) = map * Lr
-    const double u_max = c->u_max, u_min = c->u_min;
+    const double u_max = c.u_max, u_min = c.u_min;
 #pragma unroll
     for (int i = 0; i < NRW; ++i) {
-        double us = fma(c->map[i][0], Lr.x, fma(c->map[i][1], Lr.y, c->map[i][2] * Lr.z));
+        double us = fma(c.map[i][0], Lr.x, fma(c.map[i][1], Lr.y, c.map[i][2] * Lr.z));
         if (u_max > 0.0) us = fmin(fmax(us, -u_max), u_max);
         if (fabs(us) < u_min) us = 0.0;
         u[i] = us;

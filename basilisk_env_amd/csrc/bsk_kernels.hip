@@ -213,19 +213,20 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
         // bsk_config.fsw_lag): this tick commands the torque the PREVIOUS tick's guidance maps to and
         // leaves its own for the next one.  The pending torque comes from the slab on the launch's first
         // FSW tick (issued here, consumed after the guidance arithmetic) and stays in registers afterwards.
-        const bool lag = cold->fsw_lag != 0;
+        const bool lag = a.fsw_lag != 0;   // (a kernel argument: read from the cold block it cost the chain a memory round trip of its own)
         if (lag && first_fsw) {
 #pragma unroll
             for (int k = 0; k < NRW; ++k) up[k] = ldf(st + (int64_t)(TAIL + BSK_T_UPEND + k) * S, bo);
         }
-        Guid g = guidance<NRW>(cold->sigma_R0N, nav, action);
+        const FswCfg fc = load_fsw(cold);
+        Guid g = guidance<NRW>(fc.sigma_R0N, nav, action);
         sbr = sqrt_nr(dot(g.sigma_BR, g.sigma_BR));
         if (lag) {
 #pragma unroll
             for (int k = 0; k < NRW; ++k) un[k] = up[k];
-            control<NRW>(cold, g, up);
+            control<NRW>(fc, g, up);
         } else {
-            control<NRW>(cold, g, un);
+            control<NRW>(fc, g, un);
         }
         fsw_ran = true;
         if constexpr (FULL) {
@@ -643,7 +644,7 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     fill_hot<GRAV, NRW, DIAG>(p, a.hot);
     a.cold = b.cold; a.st = b.st; a.cnt = b.cnt; a.act = b.act;
     a.stride = b.stride; a.n = b.n; a.substeps = b.substeps;
-    a.nav_lag = p.nav_lag; a.pad_ = 0;
+    a.nav_lag = p.nav_lag; a.fsw_lag = p.fsw_lag;
     a.power = p.pc;
     a.extra = p.ex;
     a.tail.obs_cfg = p.obs; a.tail.st = b.st; a.tail.cnt = b.cnt; a.tail.obs = b.obs; a.tail.reward = b.reward;

@@ -43,7 +43,7 @@ struct StepArgs {
     int64_t stride;
     int n;
     int substeps;
-    int nav_lag, pad_;
+    int nav_lag, fsw_lag;   // both also in TailArgs (post-loop re-read); here for the FSW block inside the loop
     PowerCfg power;               // read only by FEAT >= FEAT_POWER
     ExtraCfg extra;               // read only by FEAT_FULL
     TailArgs tail;
