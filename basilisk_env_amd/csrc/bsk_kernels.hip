@@ -373,16 +373,20 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
     TailPtr tp = (TailPtr)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() +
                            offsetof(StepArgs<NRW __COMMA__ DIAG>, tail));
     asm volatile("" : "+s"(tp));
-    const int64_t S2 = uniform64(tp->stride);
-    const int n2 = tp->n;
+    // ... and in ONE batch: fetched field by field where they are used, the ~11 scalar loads of the epilogue were
+    // eleven dependent round trips on the critical path of a K = 1 launch (a wave alone on its SIMD waits each out)
+    TailArgs ta;
+    __builtin_memcpy(&ta, (const TailArgs*)tp, sizeof(TailArgs));
+    const int64_t S2 = uniform64(ta.stride);
+    const int n2 = ta.n;
     const bool valid2 = gid < n2;
 
     // observation: [|sigma_BR|, |omega_BN|, |Omega|/limit, charge/3600/power_max, shadow]
     // obs[0] is the logged att_guidance message: with nav_lag the one the last FSW tick wrote (held in `sbr`),
     // otherwise the tracking error of the end-of-step state under the step's mode
     double o0 = sbr;
-    if (!(NRW > 0 && tp->nav_lag != 0)) {
-        double sR0N[3] = {tp->obs_cfg.sigma_R0N[0], tp->obs_cfg.sigma_R0N[1], tp->obs_cfg.sigma_R0N[2]};
+    if (!(NRW > 0 && ta.nav_lag != 0)) {
+        double sR0N[3] = {ta.obs_cfg.sigma_R0N[0], ta.obs_cfg.sigma_R0N[1], ta.obs_cfg.sigma_R0N[2]};
         const Guid g = guidance<NRW>(sR0N, x, action);
         o0 = sqrt_nr(dot(g.sigma_BR, g.sigma_BR));
     }
@@ -390,17 +394,17 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
     double om2 = 0.0;
 #pragma unroll
     for (int k = 0; k < NRW; ++k) om2 = fma(x.Om[k], x.Om[k], om2);
-    const double o2 = sqrt_nr(om2) * tp->obs_cfg.inv_wheel_limit;
-    const double o3 = charge * tp->obs_cfg.charge_scale;
+    const double o2 = sqrt_nr(om2) * ta.obs_cfg.inv_wheel_limit;
+    const double o3 = charge * ta.obs_cfg.charge_scale;
     const double o4 = shadow;
 
     // reward and termination
     int why = 0;
-    double rew = (action == 0) ? tp->obs_cfg.reward_mult * rcp_nr(fma(o0, o0, 1.0)) : 0.0;
-    if (steps0 >= tp->obs_cfg.max_length) why |= BSK_DONE_LENGTH;
-    if (o2 > 1.0) { why |= BSK_DONE_WHEELS; rew -= tp->obs_cfg.failure_penalty; }
-    if (o3 == 0.0) { why |= BSK_DONE_BATTERY; rew -= tp->obs_cfg.failure_penalty; }
-    if (dot(x.r, x.r) < tp->obs_cfg.r_min2) why |= BSK_DONE_ORBIT;
+    double rew = (action == 0) ? ta.obs_cfg.reward_mult * rcp_nr(fma(o0, o0, 1.0)) : 0.0;
+    if (steps0 >= ta.obs_cfg.max_length) why |= BSK_DONE_LENGTH;
+    if (o2 > 1.0) { why |= BSK_DONE_WHEELS; rew -= ta.obs_cfg.failure_penalty; }
+    if (o3 == 0.0) { why |= BSK_DONE_BATTERY; rew -= ta.obs_cfg.failure_penalty; }
+    if (dot(x.r, x.r) < ta.obs_cfg.r_min2) why |= BSK_DONE_ORBIT;
 
     if constexpr (SPLIT == 5) {
         if (threadIdx.x & 64) return;    // the second wave of each pair only helped with the harmonics
@@ -409,28 +413,28 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
     const unsigned long long dmask = __ballot(valid2 && why != 0);
     const double rsum = wave_sum(valid2 ? rew : 0.0);
     if ((threadIdx.x & 63) == 0) {
-        tp->done_mask[gid >> 6] = dmask;
-        tp->wave_reward[gid >> 6] = rsum;
+        ta.done_mask[gid >> 6] = dmask;
+        ta.wave_reward[gid >> 6] = rsum;
     }
 
     // Tail lanes shadow env n-1 and computed bit-identical results from identical inputs, so their
     // stores (same address, same value) need no mask.
-    gptr<double> so = uniform_ptr(tp->st);
-    gptr<double> ob = uniform_ptr(tp->obs);
+    gptr<double> so = uniform_ptr(ta.st);
+    gptr<double> ob = uniform_ptr(ta.obs);
 #define FLD(f) (so + (int64_t)(f) * S2)
-    const int n_pool = tp->n_pool;
+    const int n_pool = ta.n_pool;
     if (n_pool > 0 && why != 0) {
       if (valid2) {   // tail lanes shadow env n-1: its own lane performs the reset, they must not repeat it
         // Device-side auto-reset (rare, divergent): reload this env from the staged IC pool, keep the
         // finished episode's observation as terminal observation, report the new episode's first one.
-        gptr<double> tob = uniform_ptr(tp->term_obs);
+        gptr<double> tob = uniform_ptr(ta.term_obs);
         stf(tob + 0 * S2, bo, o0); stf(tob + 1 * S2, bo, o1); stf(tob + 2 * S2, bo, o2); stf(tob + 3 * S2, bo, o3);
         stf(tob + 4 * S2, bo, o4);
-        const int ep = tp->episodes[i];
-        tp->episodes[i] = ep + 1;
+        const int ep = ta.episodes[i];
+        ta.episodes[i] = ep + 1;
         const unsigned slot = ((unsigned)i * 2654435761u + (unsigned)ep * 40503u + 12345u) % (unsigned)n_pool;
-        const double* __restrict__ pool = tp->pool;
-        const int nf = tp->n_fields;
+        const double* __restrict__ pool = ta.pool;
+        const int nf = ta.n_fields;
         for (int f = 0; f < nf; ++f) stf(FLD(f), bo, pool[(int64_t)f * n_pool + slot]);
         const V3 ps = mk(pool[(int64_t)(BSK_F_SIGMA + 0) * n_pool + slot], pool[(int64_t)(BSK_F_SIGMA + 1) * n_pool + slot],
                          pool[(int64_t)(BSK_F_SIGMA + 2) * n_pool + slot]);
@@ -444,10 +448,10 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
         }
         stf(ob + 0 * S2, bo, sqrt_nr(dot(ps, ps)));
         stf(ob + 1 * S2, bo, sqrt_nr(dot(pw, pw)));
-        stf(ob + 2 * S2, bo, sqrt_nr(pom2) * tp->obs_cfg.inv_wheel_limit);
-        stf(ob + 3 * S2, bo, pool[(int64_t)(TAIL + BSK_T_CHARGE) * n_pool + slot] * tp->obs_cfg.charge_scale);
+        stf(ob + 2 * S2, bo, sqrt_nr(pom2) * ta.obs_cfg.inv_wheel_limit);
+        stf(ob + 3 * S2, bo, pool[(int64_t)(TAIL + BSK_T_CHARGE) * n_pool + slot] * ta.obs_cfg.charge_scale);
         stf(ob + 4 * S2, bo, 1.0);
-        *(gptr<unsigned long long>)((gptr<char>)uniform_ptr(tp->cnt) + bo) = 0ull;
+        *(gptr<unsigned long long>)((gptr<char>)uniform_ptr(ta.cnt) + bo) = 0ull;
       }
     } else {
         stf(FLD(BSK_F_R + 0), bo, x.r.x); stf(FLD(BSK_F_R + 1), bo, x.r.y); stf(FLD(BSK_F_R + 2), bo, x.r.z);
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
             if (fsw_ran) {
 #pragma unroll
                 for (int k = 0; k < NRW; ++k) stf(FLD(TAIL + BSK_T_UCMD + k), bo, u[k]);
-                if (tp->fsw_lag) {
+                if (ta.fsw_lag) {
 #pragma unroll
                     for (int k = 0; k < NRW; ++k) stf(FLD(TAIL + BSK_T_UPEND + k), bo, up[k]);
                 }
@@ -479,14 +483,14 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
         // int2 {steps | phase << 20, ticks} written as one 8-byte word
         // the step count saturates at 2^20 - 1 so that it can never spill into the phase bits
         const unsigned long long packed = (unsigned long long)(unsigned)(min(steps0 + 1, 0xFFFFF) | (phase << 20)) |
-                                          ((unsigned long long)(unsigned)(cnt.y + tp->substeps) << 32);
-        *(gptr<unsigned long long>)((gptr<char>)uniform_ptr(tp->cnt) + bo) = packed;
+                                          ((unsigned long long)(unsigned)(cnt.y + ta.substeps) << 32);
+        *(gptr<unsigned long long>)((gptr<char>)uniform_ptr(ta.cnt) + bo) = packed;
         stf(ob + 0 * S2, bo, o0); stf(ob + 1 * S2, bo, o1); stf(ob + 2 * S2, bo, o2); stf(ob + 3 * S2, bo, o3);
         stf(ob + 4 * S2, bo, o4);
     }
 #undef FLD
-    stf(uniform_ptr(tp->reward), bo, rew);
-    tp->reason[i] = (unsigned char)why;
+    stf(uniform_ptr(ta.reward), bo, rew);
+    ta.reason[i] = (unsigned char)why;
 }
 
 // Deterministic batch scalars from the per-wave partials: one 256-thread workgroup, fixed order.
