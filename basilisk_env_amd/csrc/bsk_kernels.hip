@@ -90,6 +90,11 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
 #pragma unroll
     for (int k = 0; k < NRW; ++k) u[k] = ldf(FLD(TAIL + BSK_T_UCMD + k), bo);
 #undef FLD
+#ifndef BSK_NO_EARLY_SCALARS
+    // The loop's first scalar constants, fetched while the state's loads are in flight: left to the compiler their
+    // scalar loads sit behind the wait for the state - one more round trip on a K = 1 launch's critical path.
+    asm volatile("" ::"s"(c.fsw_every), "s"(c.h), "s"(c.h2), "s"(c.h3), "s"(c.h6), "s"(c.nmu), "s"(c.j2k), "s"(c.I[0]), "s"(c.I[1]));
+#endif
 
     // desaturation state (full scenario with BSK_FLAG_DESAT)
     constexpr bool FULL = is_full<FEAT>();
