@@ -218,7 +218,8 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
         // bsk_config.fsw_lag): this tick commands the torque the PREVIOUS tick's guidance maps to and
         // leaves its own for the next one.  The pending torque comes from the slab on the launch's first
         // FSW tick (issued here, consumed after the guidance arithmetic) and stays in registers afterwards.
-        const bool lag = a.fsw_lag != 0;   // (a kernel argument: read from the cold block it cost the chain a memory round trip of its own)
+        // (fsw_lag is a kernel argument: read from the cold block it cost the chain a memory round trip of its own)
+        const bool lag = a.fsw_lag != 0;
         if (lag && first_fsw) {
 #pragma unroll
             for (int k = 0; k < NRW; ++k) up[k] = ldf(st + (int64_t)(TAIL + BSK_T_UPEND + k) * S, bo);
