@@ -38,7 +38,9 @@ class InfoList(list):
     A step of 65 536 envs ends with a handful of finished episodes; building 65 536 empty dicts for the others takes
     longer (4 ms) than the step kernel.  Slots of envs with nothing to report hold ``None`` internally and are
     replaced by a fresh ``{}`` — one per env, never shared — the first time the slot is read through indexing,
-    slicing or iteration, so wrappers that write into ``infos[i]`` see exactly the list-of-dicts they expect."""
+    slicing or iteration, so wrappers that write into ``infos[i]`` see exactly the list-of-dicts they expect.
+    (Consumers that read a list's storage from C without going through ``__getitem__`` / ``__iter__`` — ``json.dumps``,
+    ``numpy.array``, ``pandas.DataFrame`` — would see ``None`` in untouched slots: hand them ``list(infos)``.)"""
 
     __slots__ = ()
 
