@@ -21,7 +21,10 @@ state are resident in HBM when the timed region starts.
 Timing.  ``value`` / ``ms_per_step`` come from the wall clock around EXACTLY ``--steps`` launches that
 carry no timestamps (nothing but the launches is enqueued between the two synchronisations), so they do
 not depend on ``--steps``.  ``roofline.kernel_us`` comes from a separate pass afterwards: dispatch stamps
-(hipExtLaunchKernelGGL start/stop events on the launch stream) on a sample of the launches of a back-to-back burst.
+(hipExtLaunchKernelGGL start/stop events on the launch stream) on a sample of the launches of a back-to-back burst,
+bounded from above by the timed loop's wall time per launch (launches of one stream cannot overlap; ``kernel_us_source``
+says which of the two is reported).  ``--scenario`` / ``--features`` / ``--fsw-timing`` / ``--lds-scratch`` select
+other kernels of the same path for measurement; the default line is the contract's.
 
 Besides the contract keys the JSON line carries ``roofline`` (dominant kernel: HBM-bound at K = 1 with
 340 algorithmic bytes per env-step; fp64-issue-bound for K >> 1, the harmonics and the
