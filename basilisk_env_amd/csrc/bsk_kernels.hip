@@ -295,9 +295,11 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
             // The DPP-broadcast harmonics need every lane active inside the RK4 loop, so the trip count is
             // made wave-uniform: envs of one wave that sit at different FSW phases (after a masked reset)
             // advance together to the nearest FSW tick of any of them.
-            // (the full-scenario levels take their wave-uniform constants through DPP broadcasts: same requirement)
+            // (the full-scenario levels take their wave-uniform constants through DPP broadcasts: same requirement;
+            // and every level with the power system: the penumbra queue is drained cooperatively - entry e by lane
+            // e mod 64, whoever owns it - so a flush must find all 64 lanes in the same loop iteration)
 #if !(defined(BSK_ABLATE) && BSK_ABLATE == 5)   // 5: timing only, per-lane trip count
-            if constexpr (GRAV == BSK_GRAV_SH || WDPP) m = wave_min_uniform(m);
+            if constexpr (GRAV == BSK_GRAV_SH || WDPP || POWER) m = wave_min_uniform(m);
 #endif
             phase += m;
             if (phase >= fsw_every) phase -= fsw_every;

@@ -17,7 +17,12 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("BSK_FUZZ_SEEDS", "24"))))   # BSK_FUZZ_SEEDS=N for a longer hunt
+# seeds that found something once: 978 = power level, staggered FSW phases after a masked reset (per-lane trip counts)
+# and a spacecraft in the penumbra, whose queue entries fell to lanes that had already left the loop
+REGRESSION_SEEDS = [978]
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("BSK_FUZZ_SEEDS", "24")))) + REGRESSION_SEEDS)   # BSK_FUZZ_SEEDS=N for a longer hunt
 def test_random_configuration_matches_oracle(seed, monkeypatch):
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 200, 257, 511, 600]))
@@ -69,6 +74,9 @@ def test_random_configuration_matches_oracle(seed, monkeypatch):
         errs = max_group_err(prop.get_state(), st, n_rw)
         tag = (seed, n, n_rw, grav, hex(flags), int(cfg.fsw_every), int(cfg.fsw_lag), int(cfg.nav_lag), call, k)
         assert max(errs.values()) < 1e-11, (tag, errs)
+        if flags & FLAG_POWER:     # battery charge [W s]: the oracle's published penumbra formula carries ~1e-9 of noise per tick
+            t_charge = 12 + n_rw + 7
+            assert np.abs(prop.get_state()[t_charge] - st[t_charge]).max() < 1e-6, tag
         assert np.abs(obs[:4] - o[0][:4]).max() < 1e-11 and np.abs(obs[4] - o[0][4]).max() < 2e-8, tag
         assert np.abs(rew - o[1]).max() < 1e-12 and (why == o[3]).all(), tag
         gs, gt = prop.get_counters()

@@ -1,0 +1,77 @@
+import os, sys, numpy as np
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
+from basilisk_env_amd._lib import (FLAG_DESAT, FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY, GRAV_PM, GRAV_PM_J2, GRAV_SH)
+from basilisk_env_amd.simulators.dynamics import BatchedPropagator, default_config
+from basilisk_env_amd.simulators.initial_conditions.batch import sample_ic_batch
+from helpers import max_group_err
+from oracle import oracle
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 978
+rng = np.random.default_rng(1000 + seed)
+n = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 200, 257, 511, 600]))
+n_rw = int(rng.choice([0, 3, 4]))
+grav = int(rng.choice([GRAV_PM, GRAV_PM_J2, GRAV_SH]))
+cfg = default_config(n_rw, grav)
+flags = 0
+if rng.random() < 0.6:
+    flags |= FLAG_POWER
+    if rng.random() < 0.6: flags |= FLAG_SUN_THIRD_BODY
+    if rng.random() < 0.6:
+        flags |= FLAG_DRAG; cfg.base_density, cfg.scale_height = 1e-9, 100e3
+    if n_rw and rng.random() < 0.6: flags |= FLAG_DESAT
+cfg.flags |= flags
+cfg.fsw_every = int(rng.choice([1, 3, 10, 25]))
+cfg.fsw_lag = int(rng.random() < 0.7)
+cfg.nav_lag = int(rng.random() < 0.7)
+print("n", n, "n_rw", n_rw, "grav", grav, "flags", hex(flags), "F", cfg.fsw_every, "lag", cfg.fsw_lag, cfg.nav_lag)
+ic = sample_ic_batch(n, n_rw, seed=seed)
+if n_rw: ic[12:12 + n_rw] *= rng.uniform(0.5, 2.5)
+prop = BatchedPropagator(cfg, n); prop.reset(ic)
+st = ic.copy(); steps, ticks = np.zeros(n, np.int32), np.zeros(n, np.int32)
+ncalls = int(rng.integers(3, 6))
+snap = None
+for call in range(ncalls):
+    if call and rng.random() < 0.4:
+        mask = (rng.random(n) < 0.3).astype(np.uint8)
+        fresh = sample_ic_batch(n, n_rw, seed=100 * seed + call)
+        prop.reset(fresh, mask=mask); m = mask.astype(bool)
+        st[:, m] = fresh[:, m]; steps[m] = 0; ticks[m] = 0
+        print("call", call, "masked reset of", int(m.sum()))
+    k = int(rng.integers(1, 48)); act = rng.integers(0, 3, n).astype(np.int32)
+    snap = (st.copy(), steps.copy(), ticks.copy(), act.copy(), k)
+    o = oracle.step(cfg, st, steps, ticks, act, k)
+    prop.step(act, k)
+    obs, rew, done, why = prop.get_obs()
+    d = np.abs(obs - o[0])
+    print("call", call, "k", k, "state err", max(max_group_err(prop.get_state(), st, n_rw).values()), "obs row max", d.max(axis=1))
+    j = int(np.argmax(d[0])); 
+    j3 = int(np.argmax(d[3]))
+    if d[3].max() > 1e-11:
+        T = 12 + n_rw
+        gs = prop.get_state()
+        bad = np.flatnonzero(d[3] > 1e-11)
+        print("  obs3 bad envs", bad[:20], "n_bad", bad.size, "charge gpu/oracle", gs[T + 7, j3], st[T + 7, j3], "ticks", ticks[j3], "steps", steps[j3], "act", act[j3], "shadow gpu/or", obs[4, j3], o[0][4, j3])
+        print("  lanes of bad envs", bad[:20] % 64, "waves", bad[:20] // 64)
+    if d[0].max() > 1e-11:
+        print("  env", j, "obs0 gpu", obs[0, j], "oracle", o[0][0, j], "act", act[j], "ticks", ticks[j], "sbr tail gpu", prop.get_state()[12 + n_rw + 30, j], "oracle", st[12 + n_rw + 30, j])
+
+
+# ---- the worst env of the last call, alone, tick by tick ------------------------------------------------------------
+if d[3].max() > 1e-11:
+    j = int(np.argmax(d[3]))
+    st0, steps0, ticks0, act0, k0 = snap
+    one = BatchedPropagator(cfg, 1)
+    s1 = st0[:, j:j + 1].copy(); one.reset(s1); one.set_counters(steps0[j:j + 1], ticks0[j:j + 1])
+    so = s1.copy(); so_steps = steps0[j:j + 1].copy(); so_ticks = ticks0[j:j + 1].copy()
+    a1 = act0[j:j + 1].copy()
+    T = 12 + n_rw
+    # whole call at once, alone
+    oracle.step(cfg, so, so_steps, so_ticks, a1, k0); one.step(a1, k0)
+    print("alone, one call of", k0, ": charge gpu/oracle", one.get_state()[T + 7, 0], so[T + 7, 0])
+    # tick by tick (each launch = 1 tick; env steps counter differs but not the physics)
+    one.reset(s1); one.set_counters(steps0[j:j + 1], ticks0[j:j + 1])
+    so = s1.copy(); so_steps = steps0[j:j + 1].copy(); so_ticks = ticks0[j:j + 1].copy()
+    for t in range(k0):
+        co, cg = so[T + 7, 0], one.get_state()[T + 7, 0]
+        o1 = oracle.step(cfg, so, so_steps, so_ticks, a1, 1); one.step(a1, 1)
+        ob = one.get_obs()[0]
+        print("tick %2d  dcharge gpu %.9f oracle %.9f  diff %.3e  shadow gpu %.12f oracle %.12f" % (t, one.get_state()[T + 7, 0] - cg, so[T + 7, 0] - co, (one.get_state()[T + 7, 0] - cg) - (so[T + 7, 0] - co), ob[4, 0], o1[0][4, 0]))
