@@ -478,21 +478,27 @@ static void ctx_free(orc_ctx* ctx) { free(ctx->abar); free(ctx->n1); free(ctx->n
  * eclipse (conical Earth shadow) -> simpleSolarPanel -> simpleBattery <- simplePowerSink
  * (…Simulator.py:286-288, 326-345; parameters :158-167), Euler-integrated at the dyn rate. */
 static double safe_asin(double x) { return x >= 1.0 ? M_PI / 2 : (x <= -1.0 ? -M_PI / 2 : asin(x)); }
-static double safe_acos(double x) { return x >= 1.0 ? 0.0 : (x <= -1.0 ? M_PI : acos(x)); }
 
 /* fraction of the solar disc left visible, from the apparent radii a (Sun), b (planet) and the
-   apparent separation c of their centres as seen from the spacecraft */
+   apparent separation c of their centres as seen from the spacecraft.  The formula is the published one; it is
+   evaluated in extended precision (x87 long double) because in fp64 the lens area `a^2 acos(x/a) + b^2 acos((c-x)/b)
+   - c y` cancels catastrophically near first and last contact - up to 6e-8 of the factor (seed 7777 of
+   tests/test_gpu_fuzz.py; 50-digit value on the kernel's side), 1e-9 typically.  Basilisk's own fp64 evaluation
+   carries that noise too: it is not something to reproduce. */
 static double percent_shadow(double req, const double r_HB[3], const double s_BP[3]) {
-    const double REQ_SUN = 695000.0e3;
-    double nh = v3norm(r_HB), ns = v3norm(s_BP);
-    double a = safe_asin(REQ_SUN / nh), b = safe_asin(req / ns);
-    double c = safe_acos(-v3dot(s_BP, r_HB) / (ns * nh));
-    if (c < b - a) return 0.0;                       /* total */
-    if (c < a - b) return 1.0 - (b * b) / (a * a);   /* annular */
-    if (c < a + b) {                                 /* partial: lens area of two discs */
-        double x = (c * c + a * a - b * b) / (2.0 * c), y = sqrt(a * a - x * x);
-        double area = a * a * acos(x / a) + b * b * acos((c - x) / b) - c * y;
-        return 1.0 - area / (M_PI * a * a);
+    const long double REQ_SUN = 695000.0e3L, PI_L = 3.14159265358979323846264338327950288L;
+    long double nh = sqrtl((long double)r_HB[0] * r_HB[0] + (long double)r_HB[1] * r_HB[1] + (long double)r_HB[2] * r_HB[2]);
+    long double ns = sqrtl((long double)s_BP[0] * s_BP[0] + (long double)s_BP[1] * s_BP[1] + (long double)s_BP[2] * s_BP[2]);
+    long double sa = REQ_SUN / nh, sb = (long double)req / ns;
+    long double a = sa >= 1.0L ? PI_L / 2 : asinl(sa), b = sb >= 1.0L ? PI_L / 2 : asinl(sb);
+    long double cc = -((long double)s_BP[0] * r_HB[0] + (long double)s_BP[1] * r_HB[1] + (long double)s_BP[2] * r_HB[2]) / (ns * nh);
+    long double c = cc >= 1.0L ? 0.0L : (cc <= -1.0L ? PI_L : acosl(cc));
+    if (c < b - a) return 0.0;                                   /* total */
+    if (c < a - b) return (double)(1.0L - (b * b) / (a * a));    /* annular */
+    if (c < a + b) {                                             /* partial: lens area of two discs */
+        long double x = (c * c + a * a - b * b) / (2.0L * c), y = sqrtl(a * a - x * x);
+        long double area = a * a * acosl(x / a) + b * b * acosl((c - x) / b) - c * y;
+        return (double)(1.0L - area / (PI_L * a * a));
     }
     return 1.0;
 }

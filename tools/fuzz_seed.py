@@ -22,10 +22,18 @@ cfg.flags |= flags
 cfg.fsw_every = int(rng.choice([1, 3, 10, 25]))
 cfg.fsw_lag = int(rng.random() < 0.7)
 cfg.nav_lag = int(rng.random() < 0.7)
+cbar = sbar = None
+if grav == GRAV_SH:
+    from basilisk_env_amd.simulators.dynamics.gravity_sh import synthetic_sh_coefficients
+    cfg.sh_degree = int(rng.integers(2, 21))
+    cbar, sbar = synthetic_sh_coefficients(cfg.sh_degree, seed=seed)
+    os.environ["BSKGPU_SH_FORM"] = str(rng.choice([4, 5]))
 print("n", n, "n_rw", n_rw, "grav", grav, "flags", hex(flags), "F", cfg.fsw_every, "lag", cfg.fsw_lag, cfg.nav_lag)
 ic = sample_ic_batch(n, n_rw, seed=seed)
 if n_rw: ic[12:12 + n_rw] *= rng.uniform(0.5, 2.5)
-prop = BatchedPropagator(cfg, n); prop.reset(ic)
+prop = BatchedPropagator(cfg, n)
+if grav == GRAV_SH: prop.set_gravity_sh(cfg.sh_degree, cbar, sbar)
+prop.reset(ic)
 st = ic.copy(); steps, ticks = np.zeros(n, np.int32), np.zeros(n, np.int32)
 ncalls = int(rng.integers(3, 6))
 snap = None
@@ -38,12 +46,17 @@ for call in range(ncalls):
         print("call", call, "masked reset of", int(m.sum()))
     k = int(rng.integers(1, 48)); act = rng.integers(0, 3, n).astype(np.int32)
     snap = (st.copy(), steps.copy(), ticks.copy(), act.copy(), k)
-    o = oracle.step(cfg, st, steps, ticks, act, k)
+    o = oracle.step(cfg, st, steps, ticks, act, k, cbar=cbar, sbar=sbar)
     prop.step(act, k)
     obs, rew, done, why = prop.get_obs()
     d = np.abs(obs - o[0])
     print("call", call, "k", k, "state err", max(max_group_err(prop.get_state(), st, n_rw).values()), "obs row max", d.max(axis=1))
     j = int(np.argmax(d[0])); 
+    j4 = int(np.argmax(d[4]))
+    if d[4].max() > 2e-8:
+        gs = prop.get_state()
+        print("  obs4 worst env", j4, "gpu %.15f oracle %.15f" % (obs[4, j4], o[0][4, j4]), "ticks", ticks[j4])
+        print("  r =", repr(gs[0:3, j4].tolist()), " r_oracle =", repr(st[0:3, j4].tolist()))
     j3 = int(np.argmax(d[3]))
     if d[3].max() > 1e-11:
         T = 12 + n_rw
