@@ -1,0 +1,85 @@
+"""GPU: a second randomized sweep over what tests/test_gpu_fuzz.py leaves fixed — facet geometries (all three
+evaluation paths), workgroup sizes, the LDS-scratch variant, the integrator step, termination pressure (short
+episodes, batteries near empty, wheels near their limit: done reasons must match bit for bit), and a checkpoint /
+restore round trip in the middle of a run — again through the C-ABI against the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from basilisk_env_amd._lib import (FLAG_DESAT, FLAG_DRAG, FLAG_LDS_SCRATCH, FLAG_POWER, FLAG_SUN_THIRD_BODY, GRAV_PM, GRAV_PM_J2)
+from basilisk_env_amd.simulators.dynamics import BatchedPropagator, default_config
+from basilisk_env_amd.simulators.initial_conditions.batch import sample_ic_batch
+from helpers import max_group_err
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BSK_FUZZ_SEEDS", "16"))))
+def test_random_variant_matches_oracle(seed, monkeypatch):
+    rng = np.random.default_rng(50000 + seed)
+    n = int(rng.choice([1, 64, 65, 200, 257, 1000, 1025]))
+    n_rw = int(rng.choice([0, 3, 4]))
+    grav = int(rng.choice([GRAV_PM, GRAV_PM_J2]))
+    cfg = default_config(n_rw, grav)
+    level = int(rng.choice([0, 1, 2, 3]))           # bare, power, full, full with another facet geometry
+    flags = 0
+    if level >= 1:
+        flags |= FLAG_POWER
+    if level >= 2:
+        flags |= FLAG_SUN_THIRD_BODY | FLAG_DRAG | (FLAG_DESAT if n_rw else 0)
+        cfg.base_density, cfg.scale_height = 1e-9, 100e3
+    if level == 3:
+        kind = int(rng.choice([0, 1, 2]))
+        if kind == 0:                               # axis-aligned normals, centres off their axes
+            for i in range(cfg.n_facets):
+                cfg.facet_pos[i][(i + 1) % 3] += 0.05 * (i + 1)
+        elif kind == 1:                             # tilted normals
+            for i in range(cfg.n_facets):
+                v = np.array([cfg.facet_normal[i][k] for k in range(3)]) + 0.3 * rng.normal(size=3)
+                v /= np.linalg.norm(v)
+                for k in range(3):
+                    cfg.facet_normal[i][k] = v[k]
+        else:
+            cfg.n_facets = int(rng.integers(1, 8))
+    if level == 0 and rng.random() < 0.3:
+        flags |= FLAG_LDS_SCRATCH
+    cfg.flags |= flags
+    cfg.dt = float(rng.choice([0.05, 0.1, 0.25]))
+    cfg.fsw_every = int(rng.choice([2, 10, 13]))
+    cfg.max_length = int(rng.integers(1, 4))        # episodes end by length inside the run
+    if level == 0:
+        monkeypatch.setenv("BSKGPU_BLOCK", str(rng.choice([64, 128, 256])))
+    ic = sample_ic_batch(n, n_rw, seed=seed + 7)
+    t = 12 + n_rw
+    if n_rw:                                        # some wheels right at their limit
+        hot = rng.random(n) < 0.2
+        ic[12:12 + n_rw, hot] *= cfg.wheel_limit / np.maximum(np.abs(ic[12:12 + n_rw, hot]).max(axis=0), 1.0) * rng.uniform(0.98, 1.02)
+    if level >= 1:                                  # some batteries a few ticks from empty
+        low = rng.random(n) < 0.2
+        ic[t + 7, low] = rng.uniform(0.0, 3.0, int(low.sum()))
+    prop = BatchedPropagator(cfg, n)
+    prop.reset(ic)
+    st = ic.copy()
+    steps, ticks = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    tag = (seed, n, n_rw, grav, level, hex(flags), cfg.dt, int(cfg.fsw_every))
+    ncalls = int(rng.integers(3, 6))
+    for call in range(ncalls):
+        k = int(rng.integers(1, 60))
+        act = rng.integers(0, 3, n).astype(np.int32)
+        o = oracle.step(cfg, st, steps, ticks, act, k)
+        prop.step(act, k)
+        obs, rew, done, why = prop.get_obs()
+        errs = max_group_err(prop.get_state(), st, n_rw)
+        assert max(errs.values()) < 1e-11, (tag, call, errs)
+        assert np.abs(obs - o[0]).max() < 1e-10, (tag, call)
+        assert np.abs(rew - o[1]).max() < 1e-12 and np.array_equal(why, o[3]) and np.array_equal(done.astype(bool), o[3] != 0), (tag, call)
+        if level >= 1:
+            assert np.abs(prop.get_state()[t + 7] - st[t + 7]).max() < 1e-7, (tag, call)
+        if call == 1:                               # checkpoint, scribble, restore: nothing but slab + counters is state
+            snap, cs, ct = prop.get_state(), *prop.get_counters()
+            prop.step(act, 3)
+            prop.set_state(snap)
+            prop.set_counters(cs, ct)
+    prop.close()
