@@ -1,0 +1,47 @@
+"""GPU: the batched gym surface with device-side auto-reset, randomized — LeoPowerAttVecEnv on the HIP propagator
+against the same class on the oracle-backed stand-in: observations, rewards, done flags, terminal observations,
+episode statistics and the replayable initial conditions of the restarted episodes."""
+import os
+
+import numpy as np
+import pytest
+
+from _oracle_backend import OraclePropagator
+from basilisk_env_amd._lib import GRAV_PM, GRAV_PM_J2
+from basilisk_env_amd.envs import LeoPowerAttVecEnv
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BSK_FUZZ_SEEDS", "6"))))
+def test_vec_env_with_device_reset_matches_oracle_backend(seed):
+    rng = np.random.default_rng(90000 + seed)
+    n = int(rng.choice([1, 64, 130, 500, 1000]))
+    kw = dict(n_rw=int(rng.choice([3, 4])), gravity_model=int(rng.choice([GRAV_PM, GRAV_PM_J2])),
+              step_duration=float(rng.choice([1.0, 2.5, 5.0])), seed=int(rng.integers(0, 1000)),
+              power=bool(rng.random() < 0.7), sun_third_body=bool(rng.random() < 0.5), drag=bool(rng.random() < 0.5),
+              desat=bool(rng.random() < 0.5), device_reset_pool=int(rng.choice([0, 7, 64, 300])))
+    if not kw["power"]:
+        kw["sun_third_body"] = kw["drag"] = kw["desat"] = False
+    probe = LeoPowerAttVecEnv(n, propagator_factory=OraclePropagator, **kw)
+    cfg = probe.cfg
+    cfg.max_length = int(rng.integers(1, 4))
+    probe.close()
+    kw2 = dict(step_duration=kw["step_duration"], seed=kw["seed"], device_reset_pool=kw["device_reset_pool"])
+    g = LeoPowerAttVecEnv(n, cfg=cfg, **kw2)
+    c = LeoPowerAttVecEnv(n, cfg=cfg, propagator_factory=OraclePropagator, **kw2)
+    assert np.array_equal(g.reset(), c.reset())
+    tag = (seed, n, kw)
+    for step in range(int(rng.integers(4, 9))):
+        a = rng.integers(0, 3, n)
+        og, rg, dg, ig = g.step(a)
+        oc, rc, dc, ic = c.step(a)
+        assert np.abs(og - oc).max() < 1e-9, (tag, step)
+        assert np.abs(rg - rc).max() < 1e-12 and np.array_equal(dg, dc), (tag, step)
+        for i in np.flatnonzero(dc):
+            assert ig[i]["done_reason"] == ic[i]["done_reason"] and ig[i]["episode"]["l"] == ic[i]["episode"]["l"], (tag, step, i)
+            assert abs(ig[i]["episode"]["r"] - ic[i]["episode"]["r"]) < 1e-11, (tag, step, i)
+            assert np.abs(ig[i]["terminal_observation"] - ic[i]["terminal_observation"]).max() < 1e-9, (tag, step, i)
+        assert all(ig[i] == {} for i in np.flatnonzero(~dc.astype(bool))[:5])
+    g.close()
+    c.close()
