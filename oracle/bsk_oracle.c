@@ -480,24 +480,32 @@ static void ctx_free(orc_ctx* ctx) { free(ctx->abar); free(ctx->n1); free(ctx->n
 static double safe_asin(double x) { return x >= 1.0 ? M_PI / 2 : (x <= -1.0 ? -M_PI / 2 : asin(x)); }
 
 /* fraction of the solar disc left visible, from the apparent radii a (Sun), b (planet) and the
-   apparent separation c of their centres as seen from the spacecraft.  The formula is the published one; it is
-   evaluated in extended precision (x87 long double) because in fp64 the lens area `a^2 acos(x/a) + b^2 acos((c-x)/b)
-   - c y` cancels catastrophically near first and last contact - up to 6e-8 of the factor (seed 7777 of
-   tests/test_gpu_fuzz.py; 50-digit value on the kernel's side), 1e-9 typically.  Basilisk's own fp64 evaluation
-   carries that noise too: it is not something to reproduce. */
+   apparent separation c of their centres as seen from the spacecraft: the published two-disc lens area
+       x = (c^2 + a^2 - b^2)/(2c),  y = sqrt(a^2 - x^2),  area = a^2 acos(x/a) + b^2 acos((c - x)/b) - c y.
+   With the planet's disc a thousand times the Sun's, (c - x)/b sits within 1e-8 of 1 and acos() amplifies its
+   rounding by 1e8: evaluated as written the factor is off by 1e-9 typically and 6e-8 near first contact in fp64
+   (seed 7777 of tests/test_gpu_fuzz.py), and still by 1e-10 in x87 extended precision (seed 96 of
+   tests/test_gpu_fuzz_wide.py) - in both cases the 50-digit value sided with the kernel.  So the two angles are
+   taken from the chord's half-height y instead - acos(x/a) = atan2(y, x), acos((c - x)/b) = atan2(y, c - x): the
+   same lens, without the amplification - and in long double.  Basilisk's own fp64 evaluation of the written form
+   carries the noise; that is not something to reproduce. */
 static double percent_shadow(double req, const double r_HB[3], const double s_BP[3]) {
     const long double REQ_SUN = 695000.0e3L, PI_L = 3.14159265358979323846264338327950288L;
     long double nh = sqrtl((long double)r_HB[0] * r_HB[0] + (long double)r_HB[1] * r_HB[1] + (long double)r_HB[2] * r_HB[2]);
     long double ns = sqrtl((long double)s_BP[0] * s_BP[0] + (long double)s_BP[1] * s_BP[1] + (long double)s_BP[2] * s_BP[2]);
     long double sa = REQ_SUN / nh, sb = (long double)req / ns;
     long double a = sa >= 1.0L ? PI_L / 2 : asinl(sa), b = sb >= 1.0L ? PI_L / 2 : asinl(sb);
-    long double cc = -((long double)s_BP[0] * r_HB[0] + (long double)s_BP[1] * r_HB[1] + (long double)s_BP[2] * r_HB[2]) / (ns * nh);
-    long double c = cc >= 1.0L ? 0.0L : (cc <= -1.0L ? PI_L : acosl(cc));
+    /* separation of the two directions through the cross product: acos() of their cosine loses digits when the
+       spacecraft looks almost along the Sun line */
+    long double u[3] = {-(long double)s_BP[0], -(long double)s_BP[1], -(long double)s_BP[2]};
+    long double w[3] = {r_HB[0], r_HB[1], r_HB[2]};
+    long double cx = u[1] * w[2] - u[2] * w[1], cy = u[2] * w[0] - u[0] * w[2], cz = u[0] * w[1] - u[1] * w[0];
+    long double c = atan2l(sqrtl(cx * cx + cy * cy + cz * cz), u[0] * w[0] + u[1] * w[1] + u[2] * w[2]);
     if (c < b - a) return 0.0;                                   /* total */
     if (c < a - b) return (double)(1.0L - (b * b) / (a * a));    /* annular */
     if (c < a + b) {                                             /* partial: lens area of two discs */
-        long double x = (c * c + a * a - b * b) / (2.0L * c), y = sqrtl(a * a - x * x);
-        long double area = a * a * acosl(x / a) + b * b * acosl((c - x) / b) - c * y;
+        long double x = (c * c + a * a - b * b) / (2.0L * c), y2 = a * a - x * x, y = y2 > 0.0L ? sqrtl(y2) : 0.0L;
+        long double area = a * a * atan2l(y, x) + b * b * atan2l(y, c - x) - c * y;
         return (double)(1.0L - area / (PI_L * a * a));
     }
     return 1.0;

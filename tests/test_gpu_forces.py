@@ -36,7 +36,7 @@ def test_full_scenario_matches_oracle(n_rw, grav, flags, scale):
         obs, rew, done, why = prop.get_obs()
         errs = max_group_err(prop.get_state(), st, n_rw)
         assert max(errs.values()) < 1e-11, errs
-        assert np.abs(obs[:4] - o[0][:4]).max() < 1e-11 and np.abs(obs[4] - o[0][4]).max() < 1e-10
+        assert np.abs(obs[:4] - o[0][:4]).max() < 1e-11 and np.abs(obs[4] - o[0][4]).max() < 1e-11
         assert (why == o[3]).all()
     if flags & FLAG_DRAG and scale < 1:
         cfg2_params = (cfg.base_density, cfg.scale_height)
@@ -141,7 +141,7 @@ def test_full_scenario_full_size_65536():
     o = oracle.step(cfg, st, np.zeros(idx.size, np.int32), np.zeros(idx.size, np.int32), act[idx], k)
     errs = max_group_err(s[:, idx], st, n_rw)
     assert max(errs.values()) < 1e-11, errs
-    assert np.abs(obs[:4, idx] - o[0][:4]).max() < 1e-11 and np.abs(obs[4, idx] - o[0][4]).max() < 1e-10
+    assert np.abs(obs[:4, idx] - o[0][:4]).max() < 1e-11 and np.abs(obs[4, idx] - o[0][4]).max() < 1e-11
     t = 12 + n_rw
     assert np.isfinite(s).all()
     assert (s[t + 7] >= 0).all() and (s[t + 7] <= cfg.storage_capacity).all()

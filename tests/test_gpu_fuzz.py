@@ -77,7 +77,7 @@ def test_random_configuration_matches_oracle(seed, monkeypatch):
         if flags & FLAG_POWER:     # battery charge [W s]
             t_charge = 12 + n_rw + 7
             assert np.abs(prop.get_state()[t_charge] - st[t_charge]).max() < 1e-7, tag
-        assert np.abs(obs[:4] - o[0][:4]).max() < 1e-11 and np.abs(obs[4] - o[0][4]).max() < 1e-10, tag
+        assert np.abs(obs[:4] - o[0][:4]).max() < 1e-11 and np.abs(obs[4] - o[0][4]).max() < 1e-11, tag
         assert np.abs(rew - o[1]).max() < 1e-12 and (why == o[3]).all(), tag
         gs, gt = prop.get_counters()
         assert np.array_equal(gs, steps) and np.array_equal(gt, ticks), tag

@@ -1,5 +1,5 @@
 """GPU: a second randomized sweep over what tests/test_gpu_fuzz.py leaves fixed — facet geometries (all three
-evaluation paths), workgroup sizes, the LDS-scratch variant, the integrator step, termination pressure (short
+evaluation paths), workgroup sizes, the LDS-scratch variant, the integrator step, the Sun's epoch, termination pressure (short
 episodes, batteries near empty, wheels near their limit: done reasons must match bit for bit), and a checkpoint /
 restore round trip in the middle of a run — again through the C-ABI against the CPU oracle."""
 import os
@@ -61,6 +61,9 @@ def test_random_variant_matches_oracle(seed, monkeypatch):
         ic[t + 7, low] = rng.uniform(0.0, 3.0, int(low.sum()))
     prop = BatchedPropagator(cfg, n)
     prop.reset(ic)
+    t0 = float(rng.choice([0.0, 0.0, 86400.0 * rng.uniform(1, 360)]))     # Sun ephemeris epoch offset (bsk_set_sim_time)
+    if t0:
+        prop.set_sim_time(t0)
     st = ic.copy()
     steps, ticks = np.zeros(n, np.int32), np.zeros(n, np.int32)
     tag = (seed, n, n_rw, grav, level, hex(flags), cfg.dt, int(cfg.fsw_every))
@@ -68,12 +71,12 @@ def test_random_variant_matches_oracle(seed, monkeypatch):
     for call in range(ncalls):
         k = int(rng.integers(1, 60))
         act = rng.integers(0, 3, n).astype(np.int32)
-        o = oracle.step(cfg, st, steps, ticks, act, k)
+        o = oracle.step(cfg, st, steps, ticks, act, k, sim_time0=t0)
         prop.step(act, k)
         obs, rew, done, why = prop.get_obs()
         errs = max_group_err(prop.get_state(), st, n_rw)
         assert max(errs.values()) < 1e-11, (tag, call, errs)
-        assert np.abs(obs - o[0]).max() < 1e-10, (tag, call)
+        assert np.abs(obs - o[0]).max() < 1e-11, (tag, call)
         assert np.abs(rew - o[1]).max() < 1e-12 and np.array_equal(why, o[3]) and np.array_equal(done.astype(bool), o[3] != 0), (tag, call)
         if level >= 1:
             assert np.abs(prop.get_state()[t + 7] - st[t + 7]).max() < 1e-7, (tag, call)

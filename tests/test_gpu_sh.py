@@ -150,7 +150,7 @@ def test_sh_full_scenario_matches_oracle(form, monkeypatch):
         obs, rew, done, why = prop.get_obs()
         errs = max_group_err(prop.get_state(), st, n_rw)
         assert max(errs.values()) < 1e-11, (k, errs)
-        assert np.abs(obs[:4] - o[0][:4]).max() < 1e-11 and np.abs(obs[4] - o[0][4]).max() < 1e-10
+        assert np.abs(obs[:4] - o[0][:4]).max() < 1e-11 and np.abs(obs[4] - o[0][4]).max() < 1e-11
         assert (why == o[3]).all()
     prop.close()
 

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Diagnostics for one seed of tests/test_gpu_fuzz_wide.py: python tools/fuzz_wide_seed.py SEED (GPU box)."""
+import os, sys, numpy as np
+R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+from basilisk_env_amd._lib import (FLAG_DESAT, FLAG_DRAG, FLAG_LDS_SCRATCH, FLAG_POWER, FLAG_SUN_THIRD_BODY, GRAV_PM, GRAV_PM_J2)
+from basilisk_env_amd.simulators.dynamics import BatchedPropagator, default_config
+from basilisk_env_amd.simulators.initial_conditions.batch import sample_ic_batch
+from helpers import max_group_err
+from oracle import oracle
+seed = int(sys.argv[1])
+rng = np.random.default_rng(50000 + seed)
+n = int(rng.choice([1, 64, 65, 200, 257, 1000, 1025])); n_rw = int(rng.choice([0, 3, 4])); grav = int(rng.choice([GRAV_PM, GRAV_PM_J2]))
+cfg = default_config(n_rw, grav); level = int(rng.choice([0, 1, 2, 3])); flags = 0
+if level >= 1: flags |= FLAG_POWER
+if level >= 2:
+    flags |= FLAG_SUN_THIRD_BODY | FLAG_DRAG | (FLAG_DESAT if n_rw else 0); cfg.base_density, cfg.scale_height = 1e-9, 100e3
+if level == 3:
+    kind = int(rng.choice([0, 1, 2]))
+    if kind == 0:
+        for i in range(cfg.n_facets): cfg.facet_pos[i][(i + 1) % 3] += 0.05 * (i + 1)
+    elif kind == 1:
+        for i in range(cfg.n_facets):
+            v = np.array([cfg.facet_normal[i][k] for k in range(3)]) + 0.3 * rng.normal(size=3); v /= np.linalg.norm(v)
+            for k in range(3): cfg.facet_normal[i][k] = v[k]
+    else: cfg.n_facets = int(rng.integers(1, 8))
+if level == 0 and rng.random() < 0.3: flags |= FLAG_LDS_SCRATCH
+cfg.flags |= flags; cfg.dt = float(rng.choice([0.05, 0.1, 0.25])); cfg.fsw_every = int(rng.choice([2, 10, 13])); cfg.max_length = int(rng.integers(1, 4))
+if level == 0: os.environ["BSKGPU_BLOCK"] = str(rng.choice([64, 128, 256]))
+ic = sample_ic_batch(n, n_rw, seed=seed + 7); t = 12 + n_rw
+if n_rw:
+    hot = rng.random(n) < 0.2
+    ic[12:12 + n_rw, hot] *= cfg.wheel_limit / np.maximum(np.abs(ic[12:12 + n_rw, hot]).max(axis=0), 1.0) * rng.uniform(0.98, 1.02)
+if level >= 1:
+    low = rng.random(n) < 0.2; ic[t + 7, low] = rng.uniform(0.0, 3.0, int(low.sum()))
+prop = BatchedPropagator(cfg, n); prop.reset(ic)
+t0 = float(rng.choice([0.0, 0.0, 86400.0 * rng.uniform(1, 360)]))
+if t0: prop.set_sim_time(t0)
+print("n", n, "n_rw", n_rw, "grav", grav, "level", level, "flags", hex(flags), "dt", cfg.dt, "F", cfg.fsw_every, "t0", t0)
+st = ic.copy(); steps, ticks = np.zeros(n, np.int32), np.zeros(n, np.int32)
+for call in range(int(rng.integers(3, 6))):
+    k = int(rng.integers(1, 60)); act = rng.integers(0, 3, n).astype(np.int32)
+    tk0 = ticks.copy()
+    o = oracle.step(cfg, st, steps, ticks, act, k, sim_time0=t0); prop.step(act, k)
+    obs, rew, done, why = prop.get_obs(); d = np.abs(obs - o[0])
+    print("call", call, "k", k, "state", max(max_group_err(prop.get_state(), st, n_rw).values()), "obs rows", d.max(axis=1))
+    if d[4].max() > 1e-11:
+        j = int(np.argmax(d[4])); gs = prop.get_state()
+        print("  env", j, "shadow gpu %.16f oracle %.16f" % (obs[4, j], o[0][4, j]), "tick0", tk0[j], "ticks", ticks[j])
+        print("  r =", repr(gs[0:3, j].tolist()), "sim_time0 =", repr(t0), "dt =", cfg.dt)
+    if call == 1:
+        snap, cs, ct = prop.get_state(), *prop.get_counters(); prop.step(act, 3); prop.set_state(snap); prop.set_counters(cs, ct)
