@@ -565,8 +565,23 @@ __device__ __forceinline__ void power_tick(const PowerCfg& pc, const SunGeom& g,
 __device__ __forceinline__ void power_flush(const PowerCfg& pc, LdsP L, int m, int lane, double h, double& charge,
                                             double& shadow) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // The queue counter and the whole record are read in ONE batch (2 x PEN_SLOTS + 1 LDS reads in flight): the wave
+    // is alone on its SIMD and waits every round trip out.  Only when the queue holds something (rare) the record's
+    // shadow factors are read again after the drain has filled them in.
+#ifndef BSK_FLUSH_ONE_TRIP
+#define BSK_FLUSH_ONE_TRIP 1
+#endif
+    const double draw = pc.draw, cap = pc.cap;
+    double sk[PEN_SLOTS], dq[PEN_SLOTS];
     const int qc = L->qcount;
-    if (qc > 0) {                                         // wave-uniform
+#if BSK_FLUSH_ONE_TRIP
+#pragma unroll
+    for (int k = 0; k < PEN_SLOTS; ++k) {
+        sk[k] = L->s[k][lane];
+        dq[k] = L->g[k][lane];
+    }
+#endif
+    if (BSK_UNLIKELY(qc > 0)) {                           // wave-uniform
         for (int e = lane; e < qc; e += 64) {
             const int own = L->qown[e], ol = own & 63, k = own >> 8;
             const V3 r = mk(L->qr[0][e], L->qr[1][e], L->qr[2][e]);
@@ -576,18 +591,21 @@ __device__ __forceinline__ void power_flush(const PowerCfg& pc, LdsP L, int m, i
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (lane == 0) L->qcount = 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#if BSK_FLUSH_ONE_TRIP
+#pragma unroll
+        for (int k = 0; k < PEN_SLOTS; ++k) sk[k] = L->s[k][lane];
+#endif
     }
-    // Replay: all the record's loads first (2 x PEN_SLOTS LDS reads in flight at once), the energy increments
-    // p_k h in parallel, then only the clamped sums are a dependent chain (three operations per tick; one wave per
-    // SIMD pays every dependent instruction's full latency).  charge + (p h) with p h rounded first is what the
-    // non-fused reference arithmetic does.
-    const double draw = pc.draw, cap = pc.cap;
-    double sk[PEN_SLOTS], dq[PEN_SLOTS];
+    // Replay: the energy increments p_k h in parallel, then only the clamped sums are a dependent chain (three
+    // operations per tick; one wave per SIMD pays every dependent instruction's full latency).  charge + (p h) with
+    // p h rounded first is what the non-fused reference arithmetic does.
+#if !BSK_FLUSH_ONE_TRIP
 #pragma unroll
     for (int k = 0; k < PEN_SLOTS; ++k) {
         sk[k] = L->s[k][lane];
         dq[k] = L->g[k][lane];
     }
+#endif
 #pragma unroll
     for (int k = 0; k < PEN_SLOTS; ++k) dq[k] = fma(dq[k], sk[k], draw) * h;
 #pragma unroll
