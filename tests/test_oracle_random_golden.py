@@ -1,0 +1,64 @@
+"""CPU: the oracle against the 50-digit generator (tests/golden/make_golden.py) on RANDOM short cases — wheel set,
+gravity model, feature flags, task-order switches, call lengths, actions — so that the oracle is pinned on more
+than the eight committed trajectories.  Twelve seeds by default (a fraction of a second each);
+BSK_GOLDEN_SEEDS=N for a longer hunt."""
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+
+from basilisk_env_amd._lib import FLAG_DESAT, FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY, GRAV_PM, GRAV_PM_J2
+from helpers import max_group_err
+from oracle import oracle
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BSK_GOLDEN_SEEDS", "12"))))
+def test_oracle_matches_the_50_digit_model_on_random_cases(seed):
+    import make_golden as G
+    rng = np.random.default_rng(31000 + seed)
+    n_rw = int(rng.choice([0, 3, 4]))
+    grav = int(rng.choice([GRAV_PM, GRAV_PM_J2]))
+    flags = 0
+    if rng.random() < 0.7:
+        flags |= FLAG_POWER
+        if rng.random() < 0.6:
+            flags |= FLAG_SUN_THIRD_BODY
+        if rng.random() < 0.6:
+            flags |= FLAG_DRAG
+        if n_rw and rng.random() < 0.6:
+            flags |= FLAG_DESAT
+    fsw_every = int(rng.choice([2, 5, 10]))
+    fsw_lag, nav_lag = int(rng.random() < 0.7), int(rng.random() < 0.7)
+    dense = bool(rng.random() < 0.5)
+
+    def edit(cfg):
+        cfg.flags |= flags
+        cfg.fsw_every, cfg.fsw_lag, cfg.nav_lag = fsw_every, fsw_lag, nav_lag
+        if dense:
+            cfg.base_density, cfg.scale_height = 1e-9, 100e3
+
+    n = 2
+    schedule = [(rng.integers(0, 3, n), int(rng.integers(1, 14))) for _ in range(int(rng.integers(2, 4)))]
+    with contextlib.redirect_stdout(io.StringIO()):
+        case = G.run_case("random", n_rw, grav, n, 500 + seed, schedule, cfg_edit=edit)
+    from basilisk_env_amd.simulators.dynamics import default_config
+    cfg = default_config(n_rw, grav)
+    edit(cfg)
+    st = np.array(case["ic"])
+    steps, ticks = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    tag = (seed, n_rw, grav, hex(flags), fsw_every, fsw_lag, nav_lag, dense)
+    for call in case["calls"]:
+        o = oracle.step(cfg, st, steps, ticks, np.array(call["actions"], np.int32), call["substeps"])
+        errs = max_group_err(st, np.array(call["state"]), n_rw)
+        assert max(errs.values()) < 1e-12, (tag, errs)
+        assert np.abs(o[0] - np.array(call["obs"])).max() < 1e-11, tag
+        assert np.abs(o[1] - np.array(call["reward"])).max() < 1e-13 and (o[3] == np.array(call["reason"])).all(), tag
+        t = 12 + n_rw
+        assert np.abs(st[t + 7] - np.array(call["state"])[t + 7]).max() < 1e-8, tag          # battery charge [W s]
+        if flags & FLAG_DESAT:
+            assert np.array_equal(st[t + 16:t + 26], np.array(call["state"])[t + 16:t + 26]), tag   # burst bookkeeping
