@@ -97,3 +97,39 @@ def test_sim_time_offset_moves_the_sun():
         outs.append(og[4].copy())
         g.close()
     assert (outs[0] != outs[1]).sum() > n // 4         # a different set of spacecraft is in shadow
+
+
+@pytest.mark.parametrize("level", ["power", "full"])
+def test_random_penumbra_geometries_match_oracle(level):
+    """20 000 spacecraft spread over the penumbra / antumbra bands at random distances behind the planet, for random
+    Sun epochs: the device's eclipse fraction (cooperative drain at both levels that carry the power system) against
+    the oracle, whose lens area is good to 5e-13 of the 50-digit formula (tests/test_oracle_random_golden.py)."""
+    from basilisk_env_amd._lib import FLAG_DRAG, FLAG_SUN_THIRD_BODY
+    from basilisk_env_amd.simulators.dynamics.propagator import pack_ic
+    n = 20000
+    rng = np.random.default_rng(99)
+    for epoch in (0.0, float(rng.uniform(1, 360)) * 86400.0, float(rng.uniform(1, 360)) * 86400.0):
+        cfg = default_config(0, GRAV_PM)
+        cfg.flags |= FLAG_POWER | ((FLAG_SUN_THIRD_BODY | FLAG_DRAG) if level == "full" else 0)
+        cfg.dt = 1e-6
+        sun = np.array([cfg.sun_r0[k] + cfg.sun_v[k] * epoch for k in range(3)])
+        shat = sun / np.linalg.norm(sun)
+        perp = np.cross(shat, rng.normal(size=(n, 3)))
+        perp /= np.linalg.norm(perp, axis=1)[:, None]
+        x = rng.uniform(6600e3, 9000e3, n)
+        y = cfg.req + rng.uniform(-120e3, 120e3, n) * rng.choice([1.0, 0.1, 0.01], n)
+        r = -x[:, None] * shat[None, :] + y[:, None] * perp
+        v = 7500.0 * np.cross(shat[None, :], perp)
+        ic = pack_ic(0, r, v, np.zeros((n, 3)), np.zeros((n, 3)), charge=np.full(n, 36000.0))
+        prop = BatchedPropagator(cfg, n)
+        prop.reset(ic)
+        if epoch:
+            prop.set_sim_time(epoch)
+        act = np.ones(n, np.int32)
+        prop.step(act, 3)
+        obs = prop.get_obs()[0]
+        st = ic.copy()
+        o = oracle.step(cfg, st, np.zeros(n, np.int32), np.zeros(n, np.int32), act, 3, sim_time0=epoch)
+        assert ((obs[4] > 0.0) & (obs[4] < 1.0)).sum() > 2000
+        assert np.abs(obs[4] - o[0][4]).max() < 1e-12, (level, epoch, np.abs(obs[4] - o[0][4]).max())
+        prop.close()
