@@ -399,6 +399,7 @@ struct bsk_handle {
     hipEvent_t ev_warm[2] = {nullptr, nullptr};
     bool prof = false;
     double sim_time = 0.0;
+    unsigned env_base = 0;   // global index of env 0 (bsk_set_env_base)
 };
 
 namespace {
@@ -480,6 +481,7 @@ int do_step(bsk_handle* h, const int* d_actions, int substeps) {
     b.episodes = h->d_episodes;
     b.n_pool = h->n_pool;
     b.n_fields = h->nf;
+    b.env_base = h->env_base;
     // Dispatch-timestamp sampling.  stride == 1: every launch is stamped.  stride > 1: launches
     // seq % stride == 0 and 1 are stamped as a pair and only the second is counted — the first one
     // absorbs the transition from un-stamped back-to-back launches (a lone stamped launch reads ~25 %
@@ -804,6 +806,26 @@ int bsk_get_obs_device(bsk_handle* h, double** d_obs, double** d_reward, uint64_
     return BSK_OK;
 }
 
+int bsk_get_stream(bsk_handle* h, void** stream) {
+    if (!h || !stream) return fail(BSK_EINVAL, "handle/stream is NULL");
+    *stream = (void*)h->stream;
+    return BSK_OK;
+}
+
+int bsk_get_terminal_obs_device(bsk_handle* h, double** d_term_obs, int32_t** d_episodes) {
+    if (!h) return fail(BSK_EINVAL, "handle is NULL");
+    if (d_term_obs) *d_term_obs = h->d_term_obs;
+    if (d_episodes) *d_episodes = h->d_episodes;
+    return BSK_OK;
+}
+
+int bsk_get_state_device(bsk_handle* h, double** d_state, int64_t* stride) {
+    if (!h) return fail(BSK_EINVAL, "handle is NULL");
+    if (d_state) *d_state = h->d_state;
+    if (stride) *stride = h->stride;
+    return BSK_OK;
+}
+
 int bsk_get_batch_stats(bsk_handle* h, double* reward_sum, int64_t* n_done) {
     if (!h) return fail(BSK_EINVAL, "handle is NULL");
     DeviceGuard guard(h->device);
@@ -917,7 +939,7 @@ int bsk_reset_from_pool(bsk_handle* h, const uint8_t* mask) {
         HIP_TRY(hipMemcpyAsync(d_mask, mask, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
     }
     HIP_TRY(bsk::launch_reset_from_pool(h->d_state, h->stride, h->nf, h->d_pool, h->n_pool, d_mask, h->n, h->d_cnt,
-                                        h->d_episodes, h->stream));
+                                        h->d_episodes, h->env_base, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return BSK_OK;
 }
@@ -947,6 +969,13 @@ int bsk_set_sim_time(bsk_handle* h, double t) {
     if (!h) return fail(BSK_EINVAL, "handle is NULL");
     h->sim_time = t;
     for (int i = 0; i < 3; ++i) h->sp.pc.sun_r0[i] = h->cfg.sun_r0[i] + h->cfg.sun_v[i] * t;
+    return BSK_OK;
+}
+
+int bsk_set_env_base(bsk_handle* h, int64_t env_base) {
+    if (!h) return fail(BSK_EINVAL, "handle is NULL");
+    if (env_base < 0 || env_base > 0xFFFFFFFFll) return fail(BSK_EINVAL, "env_base must be in 0..2^32-1");
+    h->env_base = (unsigned)env_base;
     return BSK_OK;
 }
 

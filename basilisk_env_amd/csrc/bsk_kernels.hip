@@ -18,6 +18,7 @@
 #include "bsk_device.hpp"
 #include "bsk_launch.hpp"
 
+#include <atomic>
 #include <cstddef>
 #define __COMMA__ ,
 
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
         stf(tob + 4 * S2, bo, o4);
         const int ep = ta.episodes[i];
         ta.episodes[i] = ep + 1;
-        const unsigned slot = ((unsigned)i * 2654435761u + (unsigned)ep * 40503u + 12345u) % (unsigned)n_pool;
+        const unsigned slot = (((unsigned)i + ta.env_base) * 2654435761u + (unsigned)ep * 40503u + 12345u) % (unsigned)n_pool;
         const double* __restrict__ pool = ta.pool;
         const int nf = ta.n_fields;
         for (int f = 0; f < nf; ++f) stf(FLD(f), bo, pool[(int64_t)f * n_pool + slot]);
@@ -599,12 +600,12 @@ __global__ void sample_pool_kernel(double* __restrict__ pool, int n_pool, int n_
 // (re)start envs from the pool with the slot rule of the step kernel's auto-reset
 __global__ void reset_from_pool_kernel(double* __restrict__ st, int64_t stride, int nf, const double* __restrict__ pool,
                                        int n_pool, const unsigned char* __restrict__ mask, int n, int2* __restrict__ cnt,
-                                       int* __restrict__ episodes) {
+                                       int* __restrict__ episodes, unsigned env_base) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || (mask && !mask[i])) return;
     const int ep = episodes[i];
     episodes[i] = ep + 1;
-    const unsigned slot = ((unsigned)i * 2654435761u + (unsigned)ep * 40503u + 12345u) % (unsigned)n_pool;
+    const unsigned slot = (((unsigned)i + env_base) * 2654435761u + (unsigned)ep * 40503u + 12345u) % (unsigned)n_pool;
     for (int f = 0; f < nf; ++f) st[f * stride + i] = pool[(int64_t)f * n_pool + slot];
     cnt[i] = make_int2(0, 0);
 }
@@ -616,9 +617,9 @@ hipError_t launch_sample_pool(double* pool, int n_pool, int n_rw, unsigned long 
 }
 
 hipError_t launch_reset_from_pool(double* st, int64_t stride, int nf, const double* pool, int n_pool, const unsigned char* mask,
-                                  int n, int2* cnt, int* episodes, hipStream_t s) {
+                                  int n, int2* cnt, int* episodes, unsigned env_base, hipStream_t s) {
     hipLaunchKernelGGL(reset_from_pool_kernel, dim3((n + 255) / 256), dim3(256), 0, s, st, stride, nf, pool, n_pool, mask, n, cnt,
-                       episodes);
+                       episodes, env_base);
     return hipGetLastError();
 }
 
@@ -665,6 +666,7 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     a.tail.pool = b.pool; a.tail.term_obs = b.term_obs; a.tail.episodes = b.episodes;
     a.tail.n_pool = b.n_pool; a.tail.n_fields = b.n_fields;
     a.tail.fsw_lag = p.fsw_lag; a.tail.nav_lag = p.nav_lag;
+    a.tail.env_base = b.env_base; a.tail.pad_ = 0;
     if (SPLIT == 5) block = 256;
     const int grid = SPLIT == 5 ? (b.n + 127) / 128 : (b.n + block - 1) / block;
     // the power system keeps a per-wave tick record and penumbra queue in dynamic LDS (bsk_device.hpp: PowerLds)
@@ -673,12 +675,19 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     // hipExtLaunchKernelGGL stamps ev0/ev1 from the dispatch packet itself (no marker packets), so
     // their difference is the kernel's own duration, as rocprofv3 --kernel-trace reports it.
     if (lds > 48 * 1024) {   // the two-wave harmonics form with the power system: 4 waves x 29 KB of dynamic LDS
-        static bool raised = false;
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)&step_kernel<GRAV, NRW, DIAG, FEAT, SPLIT>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        // the attribute belongs to (kernel, DEVICE): one bit per device and instantiation, set once the call has
+        // succeeded there (handles on different devices are stepped from different threads: atomic, and a lost race
+        // only repeats an idempotent call)
+        static std::atomic<unsigned long long> raised{0ull};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(raised.load(std::memory_order_acquire) & bit)) {
+            e = hipFuncSetAttribute((const void*)&step_kernel<GRAV, NRW, DIAG, FEAT, SPLIT>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
-            raised = true;
+            raised.fetch_or(bit, std::memory_order_release);
         }
     }
     hipExtLaunchKernelGGL((step_kernel<GRAV, NRW, DIAG, FEAT, SPLIT>), dim3(grid), dim3(block), lds, s, ev0, ev1, 0, a);

@@ -30,6 +30,8 @@ struct TailArgs {
     int n_pool;
     int n_fields;
     int fsw_lag, nav_lag;
+    unsigned env_base;             // global index of this handle's env 0 (sharded batches hash the GLOBAL index)
+    int pad_;
 };
 
 // Passed by value to step_kernel (kernarg segment -> SGPRs).
@@ -88,6 +90,7 @@ struct StepBuffers {
     int* episodes;
     int n_pool;
     int n_fields;
+    unsigned env_base;
 };
 
 hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams& p, const StepBuffers& b, int block,
@@ -95,7 +98,7 @@ hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams&
 const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat, int sh_form);
 hipError_t launch_sample_pool(double* pool, int n_pool, int n_rw, unsigned long long seed, double mu, hipStream_t s);
 hipError_t launch_reset_from_pool(double* st, int64_t stride, int nf, const double* pool, int n_pool, const unsigned char* mask,
-                                  int n, int2* cnt, int* episodes, hipStream_t s);
+                                  int n, int2* cnt, int* episodes, unsigned env_base, hipStream_t s);
 hipError_t launch_stats(const double* wave_reward, const unsigned long long* done_mask, int n_waves, double* out_sum,
                         long long* out_done, hipStream_t s);
 hipError_t launch_scatter_reset(double* st, int64_t stride, int nf, const double* ic, const int* idx, int m, int2* cnt,

@@ -18,10 +18,17 @@ from ..simulators.initial_conditions.batch import sample_ic_batch
 
 
 def _vec_env_base():
-    """stable-baselines' abstract ``VecEnv`` when one is installed (so that ``isinstance`` checks in its
-    wrappers hold), else ``object``: the class below implements the whole protocol itself either way."""
+    """stable-baselines' abstract ``VecEnv`` (so that ``isinstance`` checks in its wrappers hold) when the caller's
+    process already uses it — the module is imported — or asks for it with ``BSKGPU_SB_VECENV=1``; else ``object``.
+    Importing this package never pulls in stable-baselines (and with it torch / tensorflow) on its own; the class
+    below implements the whole protocol itself either way."""
     import importlib
+    import os
+    import sys
+    want = os.environ.get("BSKGPU_SB_VECENV") == "1"
     for mod in ("stable_baselines.common.vec_env", "stable_baselines3.common.vec_env"):
+        if not want and mod not in sys.modules:
+            continue
         try:
             return importlib.import_module(mod).VecEnv
         except Exception:
@@ -30,6 +37,10 @@ def _vec_env_base():
 
 
 _Base = _vec_env_base()
+
+# batches up to this size get a plain list of dicts as ``infos`` (every consumer sees exactly the old contract);
+# above it the dicts of envs with nothing to report are made on first access (InfoList)
+INFO_LAZY_ABOVE = 4096
 
 
 class InfoList(list):
@@ -105,11 +116,13 @@ def pool_slot(env, episode, n_pool):
 class LeoPowerAttVecEnv(_Base):
     def __init__(self, num_envs, n_rw=4, gravity_model=GRAV_PM_J2, step_duration=180., dynRate=0.1, fswRate=1.0,
                  seed=0, device=0, cfg=None, auto_reset=True, propagator_factory=None, power=True, sun_third_body=True, drag=True, desat=True,
-                 device_reset_pool=0, device_sampler=False):
+                 device_reset_pool=0, device_sampler=False, stream=None):
         """``device_reset_pool`` > 0 stages that many random initial conditions on the device and lets
         the step kernel reset finished envs itself (no host round trip at episode boundaries); 0 keeps
         the host-side masked reset with freshly sampled ICs.  With ``device_sampler`` the pool itself is
-        drawn on the GPU (Philox4x32-10 keyed by ``seed``) and ``reset()`` restarts from it on the device."""
+        drawn on the GPU (Philox4x32-10 keyed by ``seed``) and ``reset()`` restarts from it on the device.
+        ``stream``: a hipStream_t (integer) the propagator launches on instead of a stream of its own — e.g.
+        ``torch.cuda.current_stream().cuda_stream`` — so that ``step_tensors`` needs no cross-stream ordering."""
         if _Base is not object:
             _Base.__init__(self, int(num_envs), spaces.Box(-1e16, 1e16, shape=(5, 1)), spaces.Discrete(3))
         self.num_envs = int(num_envs)
@@ -140,7 +153,8 @@ class LeoPowerAttVecEnv(_Base):
         self.reward_mult = cfg.reward_mult
         self.failure_penalty = cfg.failure_penalty
         self._rng = np.random.Generator(np.random.PCG64(seed))
-        self.propagator = (propagator_factory or BatchedPropagator)(cfg, self.num_envs, device=device)
+        kw = {"stream": stream} if stream else {}
+        self.propagator = (propagator_factory or BatchedPropagator)(cfg, self.num_envs, device=device, **kw)
         self._ic = None
         self._actions = None
         self.device_reset = bool(cfg.flags & FLAG_AUTO_RESET)
@@ -208,7 +222,8 @@ class LeoPowerAttVecEnv(_Base):
         self._actions = None
         obs, rew, done, why = self.propagator.get_obs()
         self.episode_returns += rew
-        infos = InfoList(self.num_envs)     # one fresh dict per env (made on first access): wrappers write into them
+        # one fresh dict per env: a plain list for ordinary batch sizes, made on first access for very large ones
+        infos = InfoList(self.num_envs) if self.num_envs > INFO_LAZY_ABOVE else [{} for _ in range(self.num_envs)]
         obs_out = obs.T.reshape(self.num_envs, 5, 1).copy()
         idx = np.flatnonzero(done)
         if idx.size and self.device_reset:
@@ -248,6 +263,70 @@ class LeoPowerAttVecEnv(_Base):
     def step(self, actions):
         self.step_async(actions)
         return self.step_wait()
+
+    # ------------------------------------------------------------------ device-resident surface (row f4)
+    def _torch_views(self):
+        """torch tensors over the library's device buffers (zero copy, made once)."""
+        tv = getattr(self, "_tviews", None)
+        if tv is None:
+            import torch
+            dev = torch.device("cuda", self.propagator.device)
+            v = self.propagator.device_views()
+            tv = {"device": dev, "stream": self.propagator.stream_ptr()}
+            for k in ("obs", "reward", "reason", "done_mask", "state", "terminal_obs", "episodes"):
+                if k in v:
+                    tv[k] = torch.as_tensor(v[k], device=dev)
+            tv["obs_n51"] = tv["obs"].t().unsqueeze(-1)                  # (N,5,1) view of the SoA buffer
+            if "terminal_obs" in tv:
+                tv["terminal_obs_n51"] = tv["terminal_obs"].t().unsqueeze(-1)
+            tv["ext"] = None
+            self._tviews = tv
+        return tv
+
+    def reset_tensors(self):
+        """``reset()`` for the device-resident loop: restarts every env from the device pool when the pool was drawn
+        on the GPU (no host data), else uploads fresh host-sampled initial conditions; returns the (N,5,1) device
+        tensor of first observations."""
+        import torch
+        ob = self.reset()
+        tv = self._torch_views()
+        return torch.as_tensor(ob, device=tv["device"])
+
+    def step_tensors(self, actions):
+        """One env step with everything resident on the GPU: ``actions`` is an int32 device tensor (N,), the result
+        ``(obs (N,5,1), reward (N,), done (N,) bool, info)`` are device tensors — zero-copy views of the buffers the
+        step kernel writes (valid until the next step), ``done`` derived from the kernel's reason byte.  No host
+        synchronisation and no PCIe traffic: the launch is ordered after the producer of ``actions`` and before the
+        consumers of the outputs on the device (same stream when the env was created on the caller's stream, stream
+        waits otherwise).  Needs the device-side auto-reset (``device_reset_pool``) unless ``auto_reset=False``:
+        finished envs are restarted by the kernel itself; ``info`` holds device tensors ``reason`` (N,) uint8,
+        ``terminal_observation`` (N,5,1) (rows valid where ``done``) and ``episodes`` (N,) int32.
+        Host-side episode statistics (``episode_returns`` / ``episode_lengths``, ``reset_init``'s IC mirror) are not
+        updated by this path.  Replaces reference envs/leoPowerAttitudeEnvironment.py:65-145 and
+        simulators/leoPowerAttitudeSimulator.py:598-619 for an on-GPU policy."""
+        import torch
+        if self.auto_reset and not self.device_reset:
+            raise ValueError("step_tensors needs device_reset_pool > 0 (device-side auto-reset) or auto_reset=False")
+        tv = self._torch_views()
+        if not (isinstance(actions, torch.Tensor) and actions.is_cuda and actions.dtype == torch.int32
+                and actions.is_contiguous() and actions.numel() == self.num_envs and actions.device == tv["device"]):
+            raise ValueError("actions must be a contiguous int32 tensor of %d entries on %s" % (self.num_envs, tv["device"]))
+        cur = torch.cuda.current_stream(tv["device"])
+        same = cur.cuda_stream == tv["stream"]
+        if not same:
+            if tv["ext"] is None:
+                tv["ext"] = torch.cuda.ExternalStream(tv["stream"], device=tv["device"])
+            tv["ext"].wait_stream(cur)                 # the kernel reads `actions` after their producer
+            actions.record_stream(tv["ext"])
+        self._dev_actions = actions                    # alive until the next step replaces it
+        self.propagator.step_device(actions.data_ptr(), self.substeps)
+        if not same:
+            cur.wait_stream(tv["ext"])                 # consumers on the caller's stream run after the kernel
+        info = {"reason": tv["reason"]}
+        if "terminal_obs_n51" in tv:
+            info["terminal_observation"] = tv["terminal_obs_n51"]
+            info["episodes"] = tv["episodes"]
+        return tv["obs_n51"], tv["reward"], tv["reason"].ne(0), info
 
     def close(self):
         self.propagator.close()

@@ -24,16 +24,77 @@ def shard_sizes(n_total, world):
     return [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
 
 
+def _order_after_handle(prop, torch):
+    """Make torch's current stream wait for the work queued on the propagator's own stream (the step kernel) with a
+    device-side dependency — an event the GPU waits on — instead of blocking the host on the stream."""
+    if hasattr(prop, "stream_ptr"):
+        dev = torch.device("cuda", getattr(prop, "device", torch.cuda.current_device()))
+        cur = torch.cuda.current_stream(dev)
+        hs = prop.stream_ptr()
+        if hs and cur.cuda_stream != hs:
+            cur.wait_stream(torch.cuda.ExternalStream(hs, device=dev))
+    else:
+        prop.sync()
+
+
 def local_obs_tensor(prop):
     """This rank's observations as a contiguous torch tensor (5, n_local): zero-copy view of the
     library's device buffer when the propagator exposes one, else a CPU tensor from host copies."""
     import torch
 
     if hasattr(prop, "device_views"):
-        prop.sync()  # the step kernel runs on the handle's own stream
+        _order_after_handle(prop, torch)   # the step kernel runs on the handle's own stream
         v = prop.device_views()
         return torch.as_tensor(v["obs"], device="cuda").contiguous()
     return torch.from_numpy(np.ascontiguousarray(prop.get_obs()[0]))
+
+
+class ObsGatherer(object):
+    """The exchange step, set up ONCE per (propagator, group): shard sizes are static (env-index ranges), so they are
+    exchanged here and never again; ``gather`` / ``all_gather`` then run exactly one collective per call."""
+
+    def __init__(self, prop, dist, group=None):
+        self.prop, self.dist, self.group = prop, dist, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.cpu = dist.get_backend(group) == "gloo"
+        n_local = int(prop.n_envs)
+        sizes = [None] * self.world
+        dist.all_gather_object(sizes, n_local, group=group)     # pickled host collective: construction only
+        self.sizes = [int(x) for x in sizes]
+        self.equal = len(set(self.sizes)) == 1
+        self.n_local = n_local
+
+    def _local(self):
+        local = local_obs_tensor(self.prop)
+        if local.is_cuda and self.cpu:
+            local = local.cpu()   # gloo moves bytes through the host (CPU tests, single-GPU rehearsals)
+        return local
+
+    def all_gather(self):
+        import torch
+        dist, local = self.dist, self._local()
+        if self.equal:
+            # concatenation along dim 0 is the layout both RCCL and gloo accept; view as (world, 5, n)
+            out = torch.empty((self.world * local.shape[0], self.n_local), dtype=local.dtype, device=local.device)
+            dist.all_gather_into_tensor(out, local, group=self.group)
+            return out.view(self.world, local.shape[0], self.n_local)
+        n_max = max(self.sizes)
+        padded = torch.zeros((5, n_max), dtype=local.dtype, device=local.device)
+        padded[:, :self.n_local] = local
+        bufs = [torch.empty_like(padded) for _ in range(self.world)]
+        dist.all_gather(bufs, padded, group=self.group)
+        return [b[:, :s] for b, s in zip(bufs, self.sizes)]
+
+    def gather(self, dst=0):
+        import torch
+        dist, local = self.dist, self._local()
+        if self.equal:
+            bufs = [torch.empty_like(local) for _ in range(self.world)] if self.rank == dst else None
+            dist.gather(local, bufs, dst=dst, group=self.group)
+            return torch.stack(bufs) if self.rank == dst else None
+        out = self.all_gather()
+        return out if self.rank == dst else None
 
 
 def gather_observations(prop, dist, dst=None, group=None):
@@ -42,35 +103,61 @@ def gather_observations(prop, dist, dst=None, group=None):
     Equal shard sizes take the single-call ``all_gather_into_tensor`` path (one RCCL collective,
     every rank receives ``(world, 5, n_local)``); ragged shards fall back to ``all_gather`` on a
     padded buffer and are trimmed.  Returns the stacked tensor (or ``None`` on non-root ranks
-    when ``dst`` is given)."""
-    import torch
+    when ``dst`` is given).  The shard sizes are exchanged on the first call for a (propagator, group) and cached
+    on the propagator (``ObsGatherer``)."""
+    cache = prop.__dict__.setdefault("_obs_gatherers", {})
+    key = (id(dist), id(group))
+    g = cache.get(key)
+    if g is None:
+        g = cache[key] = ObsGatherer(prop, dist, group)
+    return g.all_gather() if dst is None else g.gather(dst)
 
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    local = local_obs_tensor(prop)
-    if local.is_cuda and dist.get_backend(group) == "gloo":
-        local = local.cpu()   # gloo moves bytes through the host (CPU tests, single-GPU rehearsals)
-    n_local = local.shape[1]
-    sizes = [None] * world
-    dist.all_gather_object(sizes, n_local, group=group)
-    if len(set(sizes)) == 1:
-        if dst is None:
-            # concatenation along dim 0 is the layout both RCCL and gloo accept; view as (world, 5, n)
-            out = torch.empty((world * local.shape[0], n_local), dtype=local.dtype, device=local.device)
-            dist.all_gather_into_tensor(out, local, group=group)
-            return out.view(world, local.shape[0], n_local)
-        bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
-        dist.gather(local, bufs, dst=dst, group=group)
-        return torch.stack(bufs) if rank == dst else None
-    n_max = max(sizes)
-    padded = torch.zeros((5, n_max), dtype=local.dtype, device=local.device)
-    padded[:, :n_local] = local
-    bufs = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(bufs, padded, group=group)
-    out = [b[:, :s] for b, s in zip(bufs, sizes)]
-    if dst is not None and rank != dst:
-        return None
-    return out
+
+class DirectRcclGather(object):
+    """One process per GPU, the direct leg: this rank's communicator comes from ``rccl.Comm.init_rank`` (unique id
+    broadcast once through ``dist``), the gather itself is grouped ncclSend / ncclRecv on the propagator handle's OWN
+    stream from the library's SoA rows into the root's ``[5][n_total]`` device buffer — no torch tensor, no staging
+    copy, no host synchronisation between the step kernel and the exchange."""
+
+    def __init__(self, prop, dist, root=0, group=None):
+        from . import _hip, rccl
+        self.prop, self.root = prop, int(root)
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        box = [rccl.unique_id() if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        sizes = [None] * self.world
+        dist.all_gather_object(sizes, int(prop.n_envs), group=group)
+        self.sizes = [int(x) for x in sizes]
+        self.n_total = sum(self.sizes)
+        self.comm = rccl.Comm.init_rank(self.world, self.rank, box[0], prop.device)
+        self.out = _hip.DeviceBuffer(5 * self.n_total * 8, prop.device) if self.rank == self.root else None
+        v = prop.device_views()
+        self.src = v["obs"].__cuda_array_interface__["data"][0]
+        self.pitch = v["stride"] * 8
+        self.stream = prop.stream_ptr()
+
+    def enqueue(self):
+        """Queue one gather behind whatever the handle's stream holds (asynchronous)."""
+        from . import rccl
+        out = self.out.ptr if self.out is not None else 0
+        rccl.group_start()
+        rccl.enqueue_gather_rows(self.comm, self.stream, self.root, self.sizes, self.src, self.pitch, 5, out)
+        rccl.group_end()
+        rccl.copy_own_rows(self.comm, self.stream, self.root, self.sizes, self.src, self.pitch, 5, out)
+
+    def result_view(self):
+        """Root only: zero-copy view (5, n_total) of the gathered batch, env-index order."""
+        from .simulators.dynamics.propagator import _DevArray
+        if self.out is None:
+            return None
+        return _DevArray(self.out.ptr, (5, self.n_total), "<f8", owner=self.prop, device=self.prop.device, stream=self.stream)
+
+    def close(self):
+        self.comm.destroy()
+        if self.out is not None:
+            self.out.free()
+            self.out = None
 
 
 def concat_shards(gathered):

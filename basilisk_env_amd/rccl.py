@@ -1,0 +1,172 @@
+"""Direct librccl.so binding for the ONE exchange step of the path: delivering the observation batch.
+
+Spacecraft never interact (one ``scObject`` per simulator, reference simulators/leoPowerAttitudeSimulator.py:213),
+so stepping has no collective.  What moves between GPUs is only the per-GPU ``f64[5][n_local]`` observation shard
+(+ reward, reason) when ONE consumer wants the whole batch on one device (BASELINE configs[3]).
+xGMI is point-to-point — every GPU has its own link to the root — so the gather is written as what the fabric is:
+a grouped set of ``ncclSend`` / ``ncclRecv`` pairs straight from the library's SoA rows into the root's
+``[5][n_total]`` buffer at the shard's column offset (7 inbound links busy at once, no ring, no staging copy, no
+concatenation afterwards), enqueued on the propagator handles' OWN streams, so the exchange is ordered after the
+step kernel without any host synchronisation.
+
+Two ways to get communicators: ``init_all(devices)`` — one process driving several GPUs (ShardedPropagator) — and
+``init_rank(world, rank, uid)`` — one process per GPU, the unique id distributed by whatever the caller has
+(bench.py: one ``torch.distributed`` object broadcast).  No torch in here.
+"""
+import ctypes as C
+import os
+
+from . import _hip, _lib
+
+ncclUint8, ncclInt32, ncclFloat64 = 1, 2, 8
+_RCCL = None
+
+
+class RcclError(RuntimeError):
+    pass
+
+
+class _UniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+def _candidates():
+    out = []
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is not None and spec.submodule_search_locations:
+            # the copy torch.distributed's "nccl" backend uses: one RCCL per process, like the HIP runtime
+            out.append(os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so"))
+    except Exception:
+        pass
+    out += ["librccl.so", "/opt/rocm/lib/librccl.so", "librccl.so.1"]
+    return out
+
+
+def load():
+    global _RCCL
+    if _RCCL is not None:
+        return _RCCL
+    _lib.load()          # pins the process's HIP runtime first
+    err = None
+    for cand in _candidates():
+        if os.path.isabs(cand) and not os.path.exists(cand):
+            continue
+        try:
+            lib = C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            break
+        except OSError as e:
+            err = e
+    else:
+        raise RcclError("librccl.so not loadable: %s" % err)
+    vp, sz = C.c_void_p, C.c_size_t
+    lib.ncclGetErrorString.restype = C.c_char_p
+    lib.ncclGetErrorString.argtypes = [C.c_int]
+    lib.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
+    lib.ncclCommInitRank.argtypes = [C.POINTER(vp), C.c_int, _UniqueId, C.c_int]
+    lib.ncclCommInitAll.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int)]
+    lib.ncclCommDestroy.argtypes = [vp]
+    lib.ncclGroupStart.argtypes = []
+    lib.ncclGroupEnd.argtypes = []
+    lib.ncclSend.argtypes = [vp, sz, C.c_int, C.c_int, vp, vp]
+    lib.ncclRecv.argtypes = [vp, sz, C.c_int, C.c_int, vp, vp]
+    lib.ncclAllGather.argtypes = [vp, vp, sz, C.c_int, vp, vp]
+    _RCCL = lib
+    return lib
+
+
+def _ck(rc, what):
+    if rc != 0:
+        msg = load().ncclGetErrorString(rc)
+        raise RcclError("%s: %s (%d)" % (what, msg.decode() if msg else "?", rc))
+
+
+def unique_id():
+    """128 opaque bytes; rank 0 makes them, every rank of the communicator needs the same ones."""
+    uid = _UniqueId()
+    _ck(load().ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+    return C.string_at(C.addressof(uid), 128)
+
+
+class Comm(object):
+    """One rank of a communicator (ncclComm_t) bound to ``device``."""
+
+    def __init__(self, handle, rank, world, device):
+        self.handle, self.rank, self.world, self.device = handle, int(rank), int(world), int(device)
+
+    @classmethod
+    def init_rank(cls, world, rank, uid_bytes, device):
+        lib = load()
+        if len(uid_bytes) != 128:
+            raise ValueError("unique id must be 128 bytes")
+        uid = _UniqueId()
+        C.memmove(C.addressof(uid), uid_bytes, 128)
+        _hip.set_device(device)
+        h = C.c_void_p()
+        _ck(lib.ncclCommInitRank(C.byref(h), int(world), uid, int(rank)), "ncclCommInitRank")
+        return cls(h.value, rank, world, device)
+
+    @classmethod
+    def init_all(cls, devices):
+        """Communicator over ``devices`` (distinct GPUs) driven by THIS process: one Comm per device, rank = position."""
+        lib = load()
+        devices = [int(d) for d in devices]
+        if len(set(devices)) != len(devices):
+            raise ValueError("RCCL needs distinct devices in one communicator, got %r" % (devices,))
+        n = len(devices)
+        hs = (C.c_void_p * n)()
+        _ck(lib.ncclCommInitAll(hs, n, (C.c_int * n)(*devices)), "ncclCommInitAll")
+        return [cls(hs[r], r, n, devices[r]) for r in range(n)]
+
+    def destroy(self):
+        if self.handle:
+            load().ncclCommDestroy(C.c_void_p(self.handle))
+            self.handle = None
+
+
+def group_start():
+    _ck(load().ncclGroupStart(), "ncclGroupStart")
+
+
+def group_end():
+    _ck(load().ncclGroupEnd(), "ncclGroupEnd")
+
+
+def column_offsets(sizes):
+    offs, acc = [], 0
+    for s in sizes:
+        offs.append(acc)
+        acc += int(s)
+    return offs, acc
+
+
+def enqueue_gather_rows(comm, stream, root, sizes, src_ptr, src_pitch_bytes, rows, out_ptr, itemsize=8, dtype=ncclFloat64):
+    """This rank's part of the direct gather of a ``[rows][n_r]`` shard per rank into the root's ``[rows][n_total]``
+    buffer (column offset of rank r = sum of the sizes before it).  MUST be called between group_start() and
+    group_end(), on every rank of the communicator (one process per rank: once; one process for all: once per Comm).
+    Non-root ranks send ``rows`` messages of ``sizes[rank]`` items, the root posts the matching receives and copies
+    its own shard device-to-device on the same stream after the group.  ``out_ptr`` is only read on the root."""
+    lib = load()
+    offs, n_total = column_offsets(sizes)
+    vp = C.c_void_p
+    if comm.rank == root:
+        for r in range(comm.world):
+            if r == root or sizes[r] == 0:
+                continue
+            for f in range(rows):
+                _ck(lib.ncclRecv(vp(out_ptr + (f * n_total + offs[r]) * itemsize), int(sizes[r]), dtype, r, vp(comm.handle), vp(stream)),
+                    "ncclRecv")
+    elif sizes[comm.rank]:
+        for f in range(rows):
+            _ck(lib.ncclSend(vp(src_ptr + f * src_pitch_bytes), int(sizes[comm.rank]), dtype, root, vp(comm.handle), vp(stream)), "ncclSend")
+
+
+def copy_own_rows(comm, stream, root, sizes, src_ptr, src_pitch_bytes, rows, out_ptr, itemsize=8):
+    """The root's own shard: one strided device-to-device copy on its stream (call after group_end())."""
+    if comm.rank != root or not sizes[root]:
+        return
+    offs, n_total = column_offsets(sizes)
+    _hip.set_device(comm.device)
+    _hip.memcpy2d_async(out_ptr + offs[root] * itemsize, n_total * itemsize, src_ptr, src_pitch_bytes, int(sizes[root]) * itemsize, rows,
+                        _hip.hipMemcpyDeviceToDevice, stream)

@@ -40,14 +40,34 @@ def pack_ic(n_rw, rN, vN, sigma, omega, wheelSpeeds=None, lext=None, charge=None
 
 
 class _DevArray(object):
-    """Minimal ``__cuda_array_interface__`` view of a library-owned device buffer (zero-copy
-    hand-off to torch for the RCCL gather)."""
+    """Zero-copy view of a library-owned device buffer: ``__cuda_array_interface__`` (torch.as_tensor, cupy, numba)
+    and DLPack (``torch.from_dlpack(view)``; device type kDLROCM).  The buffer belongs to the propagator, which the
+    view keeps alive; its contents are valid once the work queued on the handle's stream has been ordered before
+    the consumer's (same stream, a stream wait, or ``propagator.sync()``)."""
 
-    def __init__(self, ptr, shape, typestr, strides=None, owner=None):
+    def __init__(self, ptr, shape, typestr, strides=None, owner=None, device=0, stream=None):
         self._owner = owner
+        self._device = int(device)
+        self._stream = stream
         self.__cuda_array_interface__ = {
             "shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2, "strides": strides,
         }
+
+    def __dlpack_device__(self):
+        from ..._dlpack import kDLROCM
+        return (kDLROCM, self._device)
+
+    def __dlpack__(self, stream=None, max_version=None, dl_device=None):
+        """``stream``: the consumer's stream as the DLPack protocol passes it.  When it is the handle's own stream
+        (a propagator created on the consumer's stream) nothing needs ordering; otherwise the handle's stream is
+        drained first, so that the consumer never reads a buffer a queued step kernel is still writing."""
+        from ..._dlpack import make_capsule
+        if self._owner is not None and hasattr(self._owner, "sync"):
+            same = stream is not None and self._stream is not None and int(stream) not in (0, 1, 2, -1) and int(stream) == int(self._stream)
+            if not same:
+                self._owner.sync()
+        a = self.__cuda_array_interface__
+        return make_capsule(a["data"][0], a["shape"], a["typestr"], a["strides"], device_id=self._device, owner=self)
 
 
 class BatchedPropagator(object):
@@ -155,19 +175,37 @@ class BatchedPropagator(object):
         check(self._lib.bsk_get_batch_stats(self._handle(), C.byref(s), C.byref(d)))
         return s.value, d.value
 
+    def stream_ptr(self):
+        """The hipStream_t (as an integer) the handle launches on."""
+        st = C.c_void_p()
+        check(self._lib.bsk_get_stream(self._handle(), C.byref(st)))
+        return st.value or 0
+
     def device_views(self):
-        """Zero-copy ``__cuda_array_interface__`` views: obs (5, N) with the padded env stride,
-        reward (N,), done_mask (ceil(N/64),) uint64, reason (N,) uint8."""
+        """Zero-copy device views (``__cuda_array_interface__`` + DLPack): obs (5, N) with the padded env stride,
+        reward (N,), done_mask (ceil(N/64),) uint64, reason (N,) uint8, state (n_fields, N) strided; with a staged
+        IC pool also terminal_obs (5, N) strided and episodes (N,) int32 of the device-side auto-reset."""
         po, pr, pm, pw, st = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64()
         check(self._lib.bsk_get_obs_device(self._handle(), C.byref(po), C.byref(pr), C.byref(pm), C.byref(pw), C.byref(st)))
         n = self.n_envs
-        return {
-            "obs": _DevArray(po.value, (5, n), "<f8", strides=(st.value * 8, 8), owner=self),
-            "reward": _DevArray(pr.value, (n,), "<f8", owner=self),
-            "done_mask": _DevArray(pm.value, ((n + 63) // 64,), "<u8", owner=self),
-            "reason": _DevArray(pw.value, (n,), "|u1", owner=self),
+        stream = self.stream_ptr()
+        kw = {"owner": self, "device": self.device, "stream": stream}
+        out = {
+            "obs": _DevArray(po.value, (5, n), "<f8", strides=(st.value * 8, 8), **kw),
+            "reward": _DevArray(pr.value, (n,), "<f8", **kw),
+            "done_mask": _DevArray(pm.value, ((n + 63) // 64,), "<u8", **kw),
+            "reason": _DevArray(pw.value, (n,), "|u1", **kw),
             "stride": st.value,
         }
+        ps = C.c_void_p()
+        check(self._lib.bsk_get_state_device(self._handle(), C.byref(ps), None))
+        out["state"] = _DevArray(ps.value, (self.n_fields, n), "<f8", strides=(st.value * 8, 8), **kw)
+        pt, pe = C.c_void_p(), C.c_void_p()
+        check(self._lib.bsk_get_terminal_obs_device(self._handle(), C.byref(pt), C.byref(pe)))
+        if pt.value:
+            out["terminal_obs"] = _DevArray(pt.value, (5, n), "<f8", strides=(st.value * 8, 8), **kw)
+            out["episodes"] = _DevArray(pe.value, (n,), "<i4", **kw)
+        return out
 
     def get_ic_pool(self):
         """Host copy [n_fields, n_pool] of the staged pool (as set or as sampled on the device)."""
@@ -211,6 +249,11 @@ class BatchedPropagator(object):
 
     def set_sim_time(self, t):
         check(self._lib.bsk_set_sim_time(self._handle(), float(t)))
+
+    def set_env_base(self, base):
+        """Global index of this handle's env 0 (sharded batches; the device-side reset hashes the global index)."""
+        check(self._lib.bsk_set_env_base(self._handle(), int(base)))
+        self.env_base = int(base)
 
     # ------------------------------------------------------------------ measurement
     def profile_begin(self, capacity, stride=1):

@@ -50,7 +50,13 @@ def acquire_propagator(cfg, n_envs, device, factory):
     key = _prop_key(cfg, n_envs, device, factory)
     idle = _IDLE_PROPAGATORS.get(key)
     if idle:
-        return idle.pop(), key
+        prop = idle.pop()
+        # handle-level state that reset(ic) does not touch goes back to its create-time value: the Sun epoch offset
+        # and an armed profile (handles carrying harmonics tables or a device IC pool are never parked, see release)
+        prop.set_sim_time(0.0)
+        if hasattr(prop, "profile_end"):
+            prop.profile_end()
+        return prop, key
     return factory(cfg, n_envs, device=device), key
 
 
@@ -58,7 +64,10 @@ def release_propagator(prop, key):
     """Park a propagator for re-use, or close it when enough are parked already."""
     if prop is None:
         return
-    if sum(len(v) for v in _IDLE_PROPAGATORS.values()) >= _IDLE_MAX:
+    from .._lib import FLAG_AUTO_RESET, GRAV_SH
+    cfg = getattr(prop, "cfg", None)
+    stateful = cfg is not None and (cfg.gravity_model == GRAV_SH or (cfg.flags & FLAG_AUTO_RESET))
+    if stateful or sum(len(v) for v in _IDLE_PROPAGATORS.values()) >= _IDLE_MAX:
         prop.close()
         return
     _IDLE_PROPAGATORS.setdefault(key, []).append(prop)

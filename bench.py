@@ -155,24 +155,10 @@ def kernel_time(prop, d_act_ptr, substeps, launches, stride=None):
     return mean_ms, n, {}
 
 
-def bound_by_wall(kernel_ms, kstats, elapsed_s, steps):
-    """Launches of one stream run one after the other, so the wall time per launch of the un-stamped loop is an upper
-    bound of the kernel's average duration.  A stamped pass that reads above it caught more than a tenth of slow
-    stamped launches (the trimmed mean sets aside a tenth on each side): the bound is reported then, the stamped
-    figures stay beside it."""
-    wall_ms = elapsed_s / steps * 1e3
-    kstats = dict(kstats)
-    if kernel_ms > wall_ms:
-        kstats["stamped_trimmed_mean_us"] = kernel_ms * 1e3
-        kstats["kernel_us_source"] = "wall time per launch of the un-stamped timed loop (upper bound of the average duration)"
-        return wall_ms, kstats
-    kstats["kernel_us_source"] = "stamped pass"
-    return kernel_ms, kstats
-
-
-def cpu_baseline(cfg, n_rw, substeps, budget_s=12.0, n=8192):
+def cpu_baseline(cfg, n_rw, substeps, budget_s=12.0, n=8192, sh=None):
     """The CPU oracle (plain-C restatement, oracle/bsk_oracle.c) on the host cores of this box:
-    OpenMP over spacecraft, bounded to ~budget_s.  A reported baseline, not the target."""
+    OpenMP over spacecraft, bounded to ~budget_s.  A reported baseline, not the target.  ``sh``: harmonics degree
+    (synthetic Kaula field) when the configuration's gravity model is GRAV_SH."""
     import numpy as np
 
     from basilisk_env_amd.simulators.initial_conditions.batch import sample_ic_batch
@@ -182,12 +168,16 @@ def cpu_baseline(cfg, n_rw, substeps, budget_s=12.0, n=8192):
     st = sample_ic_batch(n, n_rw, seed=0)
     steps_c, ticks_c = np.zeros(n, np.int32), np.zeros(n, np.int32)
     act = np.zeros(n, np.int32)
-    if substeps == 1:
-        oracle.step(cfg, st, steps_c, ticks_c, act, substeps, omp=True)  # warm
+    kw = {}
+    if sh:
+        from basilisk_env_amd.simulators.dynamics.gravity_sh import synthetic_sh_coefficients
+        kw["cbar"], kw["sbar"] = synthetic_sh_coefficients(sh)
+    if substeps == 1 and not sh:
+        oracle.step(cfg, st, steps_c, ticks_c, act, substeps, omp=True, **kw)  # warm
     t0 = time.perf_counter()
     done_steps = 0
     while True:
-        oracle.step(cfg, st, steps_c, ticks_c, act, substeps, omp=True)
+        oracle.step(cfg, st, steps_c, ticks_c, act, substeps, omp=True, **kw)
         done_steps += 1
         el = time.perf_counter() - t0
         if el > budget_s or done_steps >= 100000:
@@ -195,6 +185,21 @@ def cpu_baseline(cfg, n_rw, substeps, budget_s=12.0, n=8192):
     return {"value": n * done_steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": "%d envs x %d env-steps of %d RK4 sub-step(s), same physics/config, OpenMP over envs, %.1f s"
                       % (n, done_steps, substeps, el)}
+
+
+KERNEL_SOURCES = ("basilisk_env_amd/csrc/bsk_kernels.hip", "basilisk_env_amd/csrc/bsk_device.hpp",
+                  "basilisk_env_amd/csrc/bsk_launch.hpp")
+
+
+def kernel_fingerprint():
+    """sha256[:16] over the step kernel's sources: committed profile summaries carry the fingerprint of the tree they
+    were measured on, so a bench line never silently mixes this tree's timings with another kernel's profile."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def _latest_profile(name):
@@ -205,6 +210,58 @@ def _latest_profile(name):
         if os.path.exists(f):
             best = f
     return best
+
+
+def rocprof_kernel(key):
+    """Steady-state duration of the step kernel as rocprofv3 --kernel-trace saw it for the bench command of ``key``
+    (tools/prof_summary.py -> profiles/*/kernel_trace.json).  -> dict or None."""
+    best = _latest_profile("kernel_trace.json")
+    if not best:
+        return None
+    try:
+        d = json.load(open(best))
+        rec = d.get("runs", {}).get(key)
+        if not rec:
+            return None
+        rec = dict(rec)
+        rec["source"] = os.path.relpath(best, ROOT)
+        rec["fingerprint"] = d.get("fingerprint")
+        return rec
+    except Exception:
+        return None
+
+
+def settle_roofline(roof, key, stamped_us, wall_us, work, peak, fp=None):
+    """Put every duration estimate into the roofline object and price it on the MORE CONSERVATIVE of the two kernel
+    timings: the dispatch-stamped pass of this run and the committed rocprofv3 kernel trace of the same command
+    (steady state; used only when it was taken on this very kernel source).  ``work`` = algorithmic bytes or flops per
+    launch; ``peak`` in the roofline's unit (GB/s or TFLOP/s).  The wall time per launch of the un-stamped loop is
+    reported beside them (an upper bound of the average duration of back-to-back launches)."""
+    fp = fp or kernel_fingerprint()
+    roof["kernel_us_stamped"] = stamped_us
+    roof["wall_us_per_launch"] = wall_us
+    rp = rocprof_kernel(key)
+    used = stamped_us
+    if rp:
+        fresh = rp.get("fingerprint") == fp
+        roof["kernel_us_rocprof"] = rp.get("trimmed_mean_us")
+        roof["kernel_us_rocprof_median"] = rp.get("median_us")
+        roof["kernel_us_rocprof_source"] = "%s [%s]" % (rp["source"], rp.get("csv", key))
+        roof["kernel_us_rocprof_fresh"] = bool(fresh)
+        if fresh and rp.get("trimmed_mean_us"):
+            used = max(used, float(rp["trimmed_mean_us"]))
+        elif not fresh:
+            roof["kernel_us_rocprof_note"] = "taken on other kernel sources (fingerprint %s, this tree %s): not used for frac" % (rp.get("fingerprint"), fp)
+    else:
+        roof["kernel_us_rocprof"] = None
+    roof["kernel_us"] = used
+    roof["kernel_us_rule"] = "max(stamped pass of this run, committed rocprofv3 steady-state trimmed mean of the same command)"
+    unit = 1e3 if roof.get("unit") == "GB/s" else 1e6        # bytes/us -> GB/s ; flop/us -> TFLOP/s
+    if work is not None and used > 0:
+        roof["achieved"] = work / used / unit
+        roof["frac"] = roof["achieved"] / peak
+        roof["frac_stamped"] = work / stamped_us / unit / peak if stamped_us > 0 else None
+    return roof
 
 
 def pmc_traffic(n_envs, substeps):
@@ -226,25 +283,27 @@ def pmc_traffic(n_envs, substeps):
 def isa_mix(key):
     """fp64 instructions the step kernel EXECUTES per RK4 sub-step and wave, by class, from the committed
     SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 counter passes (tools/isa_mix.sh -> profiles/*/isa_mix.json).
-    key: 'bare' | 'power' | 'full' | 'sh'.  -> (dict, source) or (None, None)."""
+    key: 'bare' | 'power' | 'full' | 'sh'.  -> (dict, source, fingerprint of the tree it was counted on)."""
     best = _latest_profile("isa_mix.json")
     if not best:
-        return None, None
+        return None, None, None
     try:
-        m = json.load(open(best)).get(key)
-        return (m, os.path.relpath(best, ROOT)) if m else (None, None)
+        d = json.load(open(best))
+        m = d.get(key)
+        return (m, os.path.relpath(best, ROOT), d.get("_meta", {}).get("fingerprint")) if m else (None, None, None)
     except Exception:
-        return None, None
+        return None, None, None
 
 
 def fp64_roofline(key, rk4_steps_per_gpu, kernel_s, info):
     """Roofline object for the fp64-issue-bound regimes: executed flop = 64 lanes x (2 FMA + MUL + ADD + TRANS)
-    per wave-instruction (counter passes), against the 78.6 TFLOP/s fp64 vector peak."""
-    mix, src = isa_mix(key)
+    per wave-instruction (counter passes), against the 78.6 TFLOP/s fp64 vector peak.  ``flop_per_launch`` is what
+    settle_roofline() prices."""
+    mix, src, mix_fp = isa_mix(key)
     out = {"bound": "fp64", "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None, "kernel": info["name"],
            "kernel_us": kernel_s * 1e6, "vgprs": info["vgprs"], "block": info["block"], "grid": info["grid"]}
     if not mix or kernel_s <= 0:
-        out.update({"achieved": None, "frac": None, "note": "no isa_mix.json entry '%s' under profiles/" % key})
+        out.update({"achieved": None, "frac": None, "flop_per_launch": None, "note": "no isa_mix.json entry '%s' under profiles/" % key})
         return out
     # counts are per wave-instruction and RK4 step; `lanes_per_env` > 1 where several waves carry one spacecraft
     # (the two-wave harmonics form runs the cheap RK4 part redundantly in both waves)
@@ -252,8 +311,13 @@ def fp64_roofline(key, rk4_steps_per_gpu, kernel_s, info):
     achieved = flop_per_lane_step * rk4_steps_per_gpu / kernel_s / 1e12
     # the same instructions as issue slots: one fp64 wave-instruction occupies its SIMD for 4 cycles
     out.update({"achieved": achieved, "frac": achieved / FP64_PEAK_TFLOPS, "flop_per_rk4_step_executed": flop_per_lane_step,
+                "flop_per_launch": flop_per_lane_step * rk4_steps_per_gpu,
                 "fp64_instr_per_rk4_step": mix["fma"] + mix["mul"] + mix["add"] + mix.get("trans", 0.0),
-                "valu_instr_per_rk4_step": mix.get("valu"), "isa_mix_source": src})
+                "valu_instr_per_rk4_step": mix.get("valu"), "isa_mix_source": src,
+                "isa_mix_fresh": mix_fp == kernel_fingerprint()})
+    if not out["isa_mix_fresh"]:
+        out["isa_mix_note"] = ("instruction mix counted on other kernel sources (fingerprint %s): executed-flop figures are "
+                               "indicative until tools/isa_mix.sh has been re-run on this tree" % mix_fp)
     return out
 
 
@@ -302,6 +366,90 @@ def gather_legs(prop, dist, torch, world, n):
     full = gather_observations(prop, dist)
     assert tuple(full.shape) == (world, 5, n)
     return out
+
+
+def profile_key(a, sh):
+    """Name of this configuration's run in profiles/*/kernel_trace.json (tools/round.sh produces them)."""
+    if sh:
+        return "sh70" if (a.substeps == 1 and a.envs == 65536) else None
+    if a.features is not None or a.lds_scratch or a.fsw_timing != "reference":
+        return None
+    if a.envs == 65536:
+        if a.scenario == "bare" and a.substeps == 1:
+            return "65k_k1"
+        return "%s_k%d" % (a.scenario, a.substeps)
+    if a.envs == (1 << 22) and a.scenario == "bare" and a.substeps == 1:
+        return "4m_k1"
+    return None
+
+
+SH_FLOP_PER_RK4 = 4 * 2592 * 16 + 2 * 450   # config 5, algorithmic (SURVEY.md §8(d) / DESIGN.md §4)
+
+
+def scenario_flags(scenario):
+    from basilisk_env_amd._lib import FLAG_DESAT, FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY
+    if scenario == "bare":
+        return 0
+    return FLAG_POWER | ((FLAG_SUN_THIRD_BODY | FLAG_DRAG | FLAG_DESAT) if scenario == "full" else 0)
+
+
+def fp64_point(key, mix_key, prop, d_ptr, n, substeps, steps, warmup, stamped, barrier, sync, fp):
+    """One fp64-issue-bound measurement point: wall-timed un-stamped launches, then the stamped pass; roofline priced on the
+    conservative duration (settle_roofline)."""
+    el = timed_run(prop, d_ptr, substeps, steps, warmup, barrier, sync)
+    km, _, kst = kernel_time(prop, d_ptr, substeps, stamped)
+    info = prop.kernel_info()
+    roof = fp64_roofline(mix_key, float(n) * substeps, km * 1e-3, info)
+    roof.update(kst)
+    flop = roof.get("flop_per_launch")
+    if mix_key == "sh":
+        roof["executed_flop_per_launch"] = flop
+        flop = float(n) * SH_FLOP_PER_RK4 * substeps
+        roof["algorithmic_flop_per_env_step"] = SH_FLOP_PER_RK4 * substeps
+        roof["flop_per_launch"] = flop
+    settle_roofline(roof, key, km * 1e3, el / steps * 1e6, flop, FP64_PEAK_TFLOPS, fp)
+    if mix_key == "sh" and roof.get("executed_flop_per_launch") and roof["kernel_us"] > 0:
+        roof["executed_tflops"] = roof["executed_flop_per_launch"] / roof["kernel_us"] / 1e6
+        roof["executed_frac"] = roof["executed_tflops"] / FP64_PEAK_TFLOPS
+    return {"env_steps_per_s": n * steps / el, "rk4_substeps_per_s": n * steps * substeps / el, "ms_per_step": el / steps * 1e3,
+            "kernel_ms": roof["kernel_us"] * 1e-3, "roofline": roof}
+
+
+def rl_loop(torch, n, substeps, steps, warmup=10):
+    """The whole on-device RL step as a training loop sees it: an on-GPU policy (linear -> argmax) reads the (N,5,1)
+    observation tensor, the env steps on device int32 actions (LeoPowerAttVecEnv.step_tensors: the full reference
+    scenario, device-side auto-reset), rewards accumulate on the device; nothing crosses PCIe and the host never waits
+    inside the loop.  -> end-to-end env-steps/s beside the step kernel's own rate."""
+    from basilisk_env_amd.envs import LeoPowerAttVecEnv
+    env = LeoPowerAttVecEnv(n, n_rw=4, step_duration=0.1 * substeps, seed=0, device_reset_pool=4096, device_sampler=True,
+                            stream=torch.cuda.current_stream().cuda_stream)
+    ob = env.reset_tensors()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    w = torch.randn(5, 3, dtype=torch.float64, device="cuda", generator=g)
+    ret = torch.zeros(n, dtype=torch.float64, device="cuda")
+
+    def one(ob):
+        act = (ob.reshape(n, 5) @ w).argmax(dim=1).to(torch.int32)
+        ob2, rew, done, _ = env.step_tensors(act)
+        ret.add_(rew)
+        return ob2
+
+    for _ in range(warmup):
+        ob = one(ob)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ob = one(ob)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    d_act = torch.zeros(n, dtype=torch.int32, device="cuda")
+    km, _, _ = kernel_time(env.propagator, d_act.data_ptr(), substeps, 16 if substeps > 1 else 64)
+    assert bool(torch.isfinite(ret).all())
+    env.close()
+    return {"env_steps_per_s": n * steps / el, "ms_per_step": el / steps * 1e3, "kernel_ms": km,
+            "kernel_env_steps_per_s": n / (km * 1e-3), "loop_over_kernel_rate": (n * steps / el) / (n / (km * 1e-3)),
+            "steps": steps, "policy": "obs(N,5) @ W(5,3) -> argmax -> int32, torch on the env's stream",
+            "env": "LeoPowerAttVecEnv.step_tensors, full reference scenario, J2 + 4 wheels, device IC pool 4096 (Philox), device-side auto-reset"}
 
 
 def main():
@@ -355,10 +503,9 @@ def main():
 
     n_rw = 4
     sh = a.gravity == "sh"
+    fp = kernel_fingerprint()
     cfg = default_config(n_rw=n_rw, gravity_model=GRAV_SH if sh else GRAV_PM_J2)
-    if a.scenario != "bare":
-        from basilisk_env_amd._lib import FLAG_DESAT, FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY
-        cfg.flags |= FLAG_POWER | ((FLAG_SUN_THIRD_BODY | FLAG_DRAG | FLAG_DESAT) if a.scenario == "full" else 0)
+    cfg.flags |= scenario_flags(a.scenario)
     if a.features is not None:
         from basilisk_env_amd._lib import FLAG_DESAT, FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY
         names = {"power": FLAG_POWER, "sun": FLAG_SUN_THIRD_BODY, "drag": FLAG_DRAG, "desat": FLAG_DESAT}
@@ -383,22 +530,39 @@ def main():
     el_local = timed_run(prop, d_act.data_ptr(), a.substeps, a.steps, a.warmup, barrier, sync)
     el = max_over_ranks(el_local)
     kernel_ms, n_launch, kstats = kernel_time(prop, d_act.data_ptr(), a.substeps, min(STAMPED_LAUNCHES, max(a.steps, 4)))
-    kernel_ms, kstats = bound_by_wall(kernel_ms, kstats, el_local, a.steps)
     obs, rew, done, why = prop.get_obs()
     assert np.isfinite(obs).all() and np.isfinite(rew).all()
     info = prop.kernel_info()
+    key = profile_key(a, sh)
+    wall_us = el_local / a.steps * 1e6
 
     value = n * world * a.steps / el
     kernel_s = kernel_ms * 1e-3
     traffic_bytes, traffic_src = pmc_traffic(n, a.substeps) if (not sh and a.scenario == "bare") else (None, None)
     hbm = hbm_roofline(n, kernel_s, info, traffic_bytes, traffic_src, n_launch)
     hbm.update(kstats)
+    settle_roofline(hbm, key, kernel_ms * 1e3, wall_us, BYTES_PER_ENV_STEP * n, HBM_PEAK_GBS, fp)
+    hbm["frac_of_copy_ceiling"] = hbm["achieved"] / HBM_COPY_CEILING_GBS
     # which roofline bounds this configuration: K = 1 of the bare / power / full propagator streams its state once
     # per launch (HBM); many sub-steps per launch and the harmonics are fp64-issue bound
     mix_key = "sh" if sh else a.scenario
     fp64_bound = sh or a.substeps >= 10
     fp64 = fp64_roofline(mix_key, float(n) * a.substeps, kernel_s, info)
     fp64.update(kstats)
+    flop = fp64.get("flop_per_launch")
+    if sh:
+        # config 5, algorithmic flops as SURVEY.md §8(d) / DESIGN.md §4 count them: 9 fp64 instructions (7 FMA + 2 MUL
+        # = 16 flop) per (l, m) entry of the padded Pines stream (2 592 entries at degree 70), four field evaluations
+        # per RK4 step, + ~450 fp64 instructions for the rest of the step.  `roofline.achieved` is this figure; the
+        # counter-derived one (every executed fp64 instruction, column ends and the redundant RK4 of the second wave
+        # included) is kept beside it.
+        fp64["executed_flop_per_launch"] = flop
+        flop = float(n) * SH_FLOP_PER_RK4 * a.substeps
+        fp64["algorithmic_flop_per_env_step"] = SH_FLOP_PER_RK4 * a.substeps
+    settle_roofline(fp64, key, kernel_ms * 1e3, wall_us, flop, FP64_PEAK_TFLOPS, fp)
+    if sh and fp64.get("executed_flop_per_launch"):
+        fp64["executed_tflops"] = fp64["executed_flop_per_launch"] / fp64["kernel_us"] / 1e6
+        fp64["executed_frac"] = fp64["executed_tflops"] / FP64_PEAK_TFLOPS
     out = {
         "metric": "env steps/sec at 65k parallel spacecraft, 1/2/4/8 MI355X; HBM GB/s vs roofline",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -410,23 +574,13 @@ def main():
                                % ("4" if sh else "2", n, "degree-70 spherical-harmonic (synthetic Kaula field)" if sh else "J2",
                                   a.substeps),
                    "envs_per_gpu": n, "substeps": a.substeps, "scenario": a.scenario, "lds_scratch": bool(a.lds_scratch), "fsw_timing": a.fsw_timing, "features": a.features,
-                   "sharding": "env ranges, no step-path collective"},
+                   "sharding": "env ranges, no step-path collective", "kernel_fingerprint": fp},
         "roofline": fp64 if fp64_bound else hbm,
         "rk4_substeps_per_s": value * a.substeps,
     }
     if fp64_bound:
         out["roofline_hbm"] = hbm
     if sh:
-        # config 5, algorithmic flops as SURVEY.md §8(d) / DESIGN.md §4 count them: 9 fp64 instructions (7 FMA + 2 MUL
-        # = 16 flop) per (l, m) entry of the padded Pines stream (2 592 entries at degree 70), four field evaluations
-        # per RK4 step, + ~450 fp64 instructions for the rest of the step.  `roofline.achieved` is this figure; the
-        # counter-derived one (every executed fp64 instruction, column ends and the redundant RK4 of the second wave
-        # included) is kept beside it.
-        flop = (4 * 2592 * 16 + 2 * 450) * a.substeps
-        tf = n * flop / kernel_s / 1e12 if kernel_s > 0 else 0.0
-        fp64["executed_tflops"], fp64["executed_frac"] = fp64.get("achieved"), fp64.get("frac")
-        fp64["achieved"], fp64["frac"] = tf, tf / FP64_PEAK_TFLOPS
-        fp64["algorithmic_flop_per_env_step"] = flop
         out["sh"] = {"degree": 70, "field_evals_per_s": n * world * a.steps * a.substeps * 4 / el}
 
     if dist is not None:
@@ -434,27 +588,53 @@ def main():
         out["gather_ms"] = out["gather"]["all_gather_ms"]
 
     extra = {}
-    if world == 1 and not a.no_extra and not sh and a.scenario == "bare" and not a.lds_scratch:
+    default_line = not a.no_extra and not sh and a.scenario == "bare" and not a.lds_scratch and a.features is None
+    if world == 1 and default_line:
+        dp = d_act.data_ptr()
         # reference-faithful env step: 180 s of sim time = 1 800 RK4 sub-steps, 180 FSW updates
         # (the first few 2 ms launches after the K = 1 burst run while the clocks settle: five warm-up steps)
-        ksteps = 10
-        el2 = timed_run(prop, d_act.data_ptr(), 1800, ksteps, 5, barrier, sync)
-        km2, _, _ = kernel_time(prop, d_act.data_ptr(), 1800, 5)
-        extra["k1800"] = {"env_steps_per_s": n * ksteps / el2, "rk4_substeps_per_s": n * ksteps * 1800 / el2,
-                          "kernel_ms": km2, "ms_per_step": el2 / ksteps * 1e3,
-                          "roofline": fp64_roofline("bare", float(n) * 1800, km2 * 1e-3, info)}
+        extra["k1800"] = fp64_point("bare_k1800", "bare", prop, dp, n, 1800, 10, 5, 5, barrier, sync, fp)
+        # the kernels behind the drop-in env (leoPowerAttEnv / LeoPowerAttVecEnv): config-3 physics + the reference
+        # scenario of leoPowerAttitudeSimulator.py:213-366 (power system; + Sun third body, drag, desaturation),
+        # replacing the ExecuteSimulation call at :594-595, at the reference's 1 800 sub-steps per env step
+        for sc in ("power", "full"):
+            c2 = cfg.copy()
+            c2.flags |= scenario_flags(sc)
+            p2 = BatchedPropagator(c2, n, device=local)
+            p2.reset(ic)
+            extra["%s_k1800" % sc] = fp64_point("%s_k1800" % sc, sc, p2, dp, n, 1800, 10, 5, 5, barrier, sync, fp)
+            extra["%s_k1800" % sc]["scenario"] = sc
+            p2.close()
+        # BASELINE configs[4]: degree-70 harmonics, K = 1 (a 250 us kernel needs ~300 launches before the clocks settle)
+        c5 = default_config(n_rw=n_rw, gravity_model=GRAV_SH)
+        c5.sh_degree = 70
+        p5 = BatchedPropagator(c5, n, device=local)
+        p5.set_gravity_sh(70, *synthetic_sh_coefficients(70))
+        p5.reset(ic)
+        extra["sh70"] = fp64_point("sh70", "sh", p5, dp, n, 1, 1000, 300, 32, barrier, sync, fp)
+        extra["sh70"]["workload"] = "BASELINE configs[4]: 65 536 envs, degree-70 harmonics (synthetic Kaula field), 4 wheels, K = 1"
+        p5.close()
         # large-batch point where the HBM roofline is the binding limit (4 Mi envs = 1.4 GB/launch)
         nl = 1 << 22
         big = BatchedPropagator(cfg, nl, device=local)
         big.reset(sample_ic_batch(nl, n_rw, seed=1))
         d_act_big = torch.zeros(nl, dtype=torch.int32, device="cuda")
         el3 = timed_run(big, d_act_big.data_ptr(), 1, 50, 5, barrier, sync)
-        km3, nl3, _ = kernel_time(big, d_act_big.data_ptr(), 1, 20)
+        km3, nl3, kst3 = kernel_time(big, d_act_big.data_ptr(), 1, 20)
         tb, ts = pmc_traffic(nl, 1)
-        extra["large_n"] = {"envs": nl, "env_steps_per_s": nl * 50 / el3,
-                            "roofline": hbm_roofline(nl, km3 * 1e-3, big.kernel_info(), tb, ts, nl3)}
+        roof3 = hbm_roofline(nl, km3 * 1e-3, big.kernel_info(), tb, ts, nl3)
+        roof3.update(kst3)
+        settle_roofline(roof3, "4m_k1", km3 * 1e3, el3 / 50 * 1e6, BYTES_PER_ENV_STEP * nl, HBM_PEAK_GBS, fp)
+        roof3["frac_of_copy_ceiling"] = roof3["achieved"] / HBM_COPY_CEILING_GBS
+        extra["large_n"] = {"envs": nl, "env_steps_per_s": nl * 50 / el3, "roofline": roof3}
         big.close()
-    if dist is not None and not a.no_extra and not sh and a.scenario == "bare" and not a.lds_scratch:
+        del d_act_big
+        # the device-resident RL loop (row f4): on-GPU policy -> step_tensors, at K = 1 and at the reference's K = 1 800
+        try:
+            extra["rl_loop"] = {"k1": rl_loop(torch, n, 1, 200), "k1800": rl_loop(torch, n, 1800, 200 if a.steps >= 1000 else 40)}
+        except Exception as e:   # never lose the line to an auxiliary leg
+            extra["rl_loop"] = {"error": repr(e)}
+    if dist is not None and default_line:
         # BASELINE configs[3]: 131 072 envs per GPU (1 048 576 on 8), config-3 physics, + the observation exchange
         n3 = 131072
         p3 = BatchedPropagator(cfg, n3, device=local)
@@ -479,11 +659,23 @@ def main():
         ps.close()
     if extra and rank == 0:
         out["extra"] = extra
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and not sh:
-        out["cpu_baseline"] = cpu_baseline(cfg, n_rw, a.substeps)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        # the CPU oracle on this box's host cores, like for like beside every GPU point of the line (bounded samples)
+        if sh:
+            out["cpu_baseline"] = cpu_baseline(cfg, n_rw, a.substeps, budget_s=10.0, n=256, sh=70)
+        else:
+            out["cpu_baseline"] = cpu_baseline(cfg, n_rw, a.substeps, budget_s=10.0 if default_line else 12.0)
         if "k1800" in extra:
-            # like for like beside extra.k1800: a bounded sample of the reference-faithful env step on the host cores
-            extra["k1800"]["cpu_baseline"] = cpu_baseline(cfg, n_rw, 1800, budget_s=8.0, n=512)
+            extra["k1800"]["cpu_baseline"] = cpu_baseline(cfg, n_rw, 1800, budget_s=6.0, n=512)
+        for sc in ("power", "full"):
+            if "%s_k1800" % sc in extra:
+                c2 = cfg.copy()
+                c2.flags |= scenario_flags(sc)
+                extra["%s_k1800" % sc]["cpu_baseline"] = cpu_baseline(c2, n_rw, 1800, budget_s=5.0, n=256)
+        if "sh70" in extra:
+            c5 = default_config(n_rw=n_rw, gravity_model=GRAV_SH)
+            c5.sh_degree = 70
+            extra["sh70"]["cpu_baseline"] = cpu_baseline(c5, n_rw, 1, budget_s=5.0, n=256, sh=70)
     prop.close()
     if rank == 0:
         print(json.dumps(out), flush=True)

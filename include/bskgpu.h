@@ -210,6 +210,17 @@ int bsk_get_obs(bsk_handle* h, double* obs, double* reward, uint8_t* done, uint8
 int bsk_get_obs_device(bsk_handle* h, double** d_obs, double** d_reward, uint64_t** d_done_mask,
                        uint8_t** d_done_reason, int64_t* stride);
 
+/* Device-resident stepping ("so training loops stay on-GPU"; replaces the host read-back of
+ * …Simulator.py:598-619 for a policy that lives on the same GPU).
+ * bsk_get_stream: the hipStream_t the handle launches on, so that a caller can order its own work against the step
+ * kernel with events / stream waits instead of a host synchronisation (or hand its own stream to bsk_create).
+ * bsk_get_terminal_obs_device: device pointers of the terminal observations f64[5][stride] and the per-env
+ * finished-episode counts int32[stride] of the device-side auto-reset (NULL until a pool is staged).
+ * bsk_get_state_device: the state slab f64[n_fields][stride] itself (read-only for the caller between steps). */
+int bsk_get_stream(bsk_handle* h, void** stream);
+int bsk_get_terminal_obs_device(bsk_handle* h, double** d_term_obs, int32_t** d_episodes);
+int bsk_get_state_device(bsk_handle* h, double** d_state, int64_t* stride);
+
 /* Batch scalars produced with wavefront reductions: sum of rewards and number of done envs
  * of the last step (synchronises). */
 int bsk_get_batch_stats(bsk_handle* h, double* reward_sum, int64_t* n_done);
@@ -227,8 +238,8 @@ int bsk_set_counters(bsk_handle* h, const int32_t* steps, const int32_t* ticks);
 /* Device-side auto-reset (BSK_FLAG_AUTO_RESET; reference reset semantics,
  * envs/leoPowerAttitudeEnvironment.py:172-191, without the host round trip).  Stage a pool of
  * initial conditions, host SoA [n_fields][n_pool].  When an env finishes, the step kernel itself
- * reloads it from pool slot  (env * 2654435761 + episode * 40503 + 12345) mod 2^32 mod n_pool
- * (episode = that env's count of finished episodes), zeroes its counters, writes the NEW episode's
+ * reloads it from pool slot  ((env_base + env) * 2654435761 + episode * 40503 + 12345) mod 2^32 mod n_pool
+ * (episode = that env's count of finished episodes; env_base: bsk_set_env_base, 0 unless the batch is sharded), zeroes its counters, writes the NEW episode's
  * initial observation [|sigma_BN|, |omega|, |Omega|/limit, charge/3600/power_max, 1] to obs and keeps
  * the finished episode's last observation in the terminal-observation buffer. */
 int bsk_set_ic_pool(bsk_handle* h, int n_pool, const double* ic_pool);
@@ -247,6 +258,11 @@ int bsk_get_ic_pool(bsk_handle* h, double* ic_pool);
 /* terminal observations f64[5][n_envs] (valid for envs whose done flag is set) and per-env
  * finished-episode counts int32[n_envs]; either pointer may be NULL.  Synchronises. */
 int bsk_get_terminal_obs(bsk_handle* h, double* term_obs, int32_t* episodes);
+
+/* Sharded batches (one handle per GPU): the GLOBAL index of this handle's env 0.  The device-side
+ * reset's slot rule hashes env_base + local index, so a batch split over several handles restarts its envs from
+ * exactly the pool slots the unsplit batch would use.  Default 0. */
+int bsk_set_env_base(bsk_handle* h, int64_t env_base);
 
 /* Epoch offset [s] added to every spacecraft's own clock (ticks * dt) when the Sun position
  * sun_r0 + sun_v * t is evaluated at the start of an env step (default 0). */

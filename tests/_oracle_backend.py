@@ -25,6 +25,8 @@ class OraclePropagator(object):
         self._t0 = 0.0
         self.episodes = np.zeros(self.n_envs, np.int32)
         self._term_obs = np.zeros((5, self.n_envs))
+        self.env_base = 0
+        self.device = int(device)
 
     def set_gravity_sh(self, degree, cbar, sbar):
         assert degree == self.cfg.sh_degree
@@ -80,7 +82,7 @@ class OraclePropagator(object):
         for i in range(self.n_envs):
             if mask is not None and not mask[i]:
                 continue
-            slot = ((i * 2654435761 + int(self.episodes[i]) * 40503 + 12345) & 0xFFFFFFFF) % n_pool
+            slot = (((i + self.env_base) * 2654435761 + int(self.episodes[i]) * 40503 + 12345) & 0xFFFFFFFF) % n_pool
             self.episodes[i] += 1
             self.state[:, i] = self._pool[:, slot]
             self.steps[i] = 0
@@ -97,7 +99,7 @@ class OraclePropagator(object):
         t = 12 + self.n_rw
         for i in np.flatnonzero(done):
             self._term_obs[:, i] = obs[:, i]
-            slot = ((i * 2654435761 + int(self.episodes[i]) * 40503 + 12345) & 0xFFFFFFFF) % n_pool
+            slot = (((i + self.env_base) * 2654435761 + int(self.episodes[i]) * 40503 + 12345) & 0xFFFFFFFF) % n_pool
             self.episodes[i] += 1
             ic = self._pool[:, slot]
             self.state[:, i] = ic
@@ -118,3 +120,6 @@ class OraclePropagator(object):
 
     def set_sim_time(self, t):
         self._t0 = float(t)
+
+    def set_env_base(self, base):
+        self.env_base = int(base)

@@ -157,12 +157,14 @@ def test_rooflines():
     h = b.hbm_roofline(65536, 7e-6, info, 25.9e6, "profiles/x", 64)
     assert h["bound"] == "hbm" and abs(h["achieved"] - 340 * 65536 / 7e-6 / 1e9) < 1e-6
     assert abs(h["frac"] - h["achieved"] / 8000.0) < 1e-12 and abs(h["frac_of_copy_ceiling"] - h["achieved"] / 6290.0) < 1e-12
-    mix, src = b.isa_mix("bare")
+    mix, src, mix_fp = b.isa_mix("bare")
     f = b.fp64_roofline("bare", 65536.0 * 1800, 1.9e-3, info)
     assert f["bound"] == "fp64" and f["peak"] == 78.6 and f["unit"] == "TFLOP/s"
     if mix:      # executed flops from the committed counter pass: can never exceed the peak
         assert src.startswith("profiles/") and 0.0 < f["frac"] < 1.0
         assert abs(f["achieved"] - (2 * mix["fma"] + mix["mul"] + mix["add"] + mix.get("trans", 0)) * 65536 * 1800 / 1.9e-3 / 1e12) < 1e-9
+        assert f["isa_mix_fresh"] == (mix_fp == b.kernel_fingerprint())     # a stale instruction mix is flagged, never silent
+        assert f["isa_mix_fresh"] or "isa_mix_note" in f
     else:
         assert f["achieved"] is None
     assert b.fp64_roofline("nope", 1.0, 1.0, info)["achieved"] is None
@@ -185,12 +187,42 @@ def test_committed_bench_line_has_the_contract_keys():
         assert d["metric"] == json.load(f)["metric"]
 
 
-def test_kernel_time_is_bounded_by_the_wall_time_per_launch():
-    """bench.bound_by_wall: serialized launches of one stream cannot average longer than the loop's wall time per
-    launch; a stamped pass that reads above it is replaced by the bound and kept beside it."""
-    import bench
-    k, st = bench.bound_by_wall(7.8e-3, {"median_us": 7.1}, 7.36e-6 * 10000, 10000)
-    assert abs(k - 7.36e-3) < 1e-9 and abs(st["stamped_trimmed_mean_us"] - 7.8) < 1e-9 and "wall" in st["kernel_us_source"]
-    assert st["median_us"] == 7.1
-    k, st = bench.bound_by_wall(7.2e-3, {}, 8.2e-6 * 20, 20)             # cold 20-step loop: the stamped pass stands
-    assert k == 7.2e-3 and st["kernel_us_source"] == "stamped pass"
+def test_roofline_is_priced_on_the_more_conservative_duration(monkeypatch):
+    """bench.settle_roofline: frac uses max(stamped pass, committed rocprofv3 steady-state mean of the same command),
+    and the committed figure only when it was measured on this very kernel source; every estimate stays in the object."""
+    b = _load_bench()
+    info = {"name": "k", "vgprs": 200, "lds_bytes": 0, "block": 64, "grid": 1024}
+    fp = b.kernel_fingerprint()
+    assert len(fp) == 16 and fp == b.kernel_fingerprint()
+    work = 340.0 * 65536
+
+    def roof():
+        return b.hbm_roofline(65536, 6.6e-6, info, None, None, 64)
+
+    monkeypatch.setattr(b, "rocprof_kernel", lambda key: {"trimmed_mean_us": 7.5, "median_us": 7.4, "source": "profiles/rXX/kernel_trace.json",
+                                                          "csv": "kt_65k", "fingerprint": fp})
+    r = b.settle_roofline(roof(), "65k_k1", 6.6, 7.7, work, 8000.0, fp)
+    assert r["kernel_us"] == 7.5 and r["kernel_us_stamped"] == 6.6 and r["wall_us_per_launch"] == 7.7 and r["kernel_us_rocprof_fresh"]
+    assert abs(r["frac"] - work / 7.5 / 1e3 / 8000.0) < 1e-12 and abs(r["frac_stamped"] - work / 6.6 / 1e3 / 8000.0) < 1e-12
+    assert r["frac"] < r["frac_stamped"]
+    monkeypatch.setattr(b, "rocprof_kernel", lambda key: {"trimmed_mean_us": 9.9, "median_us": 9.9, "source": "profiles/rXX/kernel_trace.json",
+                                                          "csv": "kt_65k", "fingerprint": "0" * 16})
+    r = b.settle_roofline(roof(), "65k_k1", 6.6, 7.7, work, 8000.0, fp)        # profile of another kernel: shown, not used
+    assert r["kernel_us"] == 6.6 and r["kernel_us_rocprof"] == 9.9 and not r["kernel_us_rocprof_fresh"] and "kernel_us_rocprof_note" in r
+    monkeypatch.setattr(b, "rocprof_kernel", lambda key: None)
+    r = b.settle_roofline(roof(), None, 6.6, 7.7, work, 8000.0, fp)
+    assert r["kernel_us"] == 6.6 and r["kernel_us_rocprof"] is None
+    f = {"bound": "fp64", "unit": "TFLOP/s", "peak": 78.6}
+    r = b.settle_roofline(f, None, 3700.0, 3710.0, 1.5e11, 78.6, fp)
+    assert abs(r["achieved"] - 1.5e11 / 3700.0 / 1e6) < 1e-9 and abs(r["frac"] - r["achieved"] / 78.6) < 1e-12
+
+
+def test_profile_keys():
+    b = _load_bench()
+    assert b.profile_key(b.parse([]), False) == "65k_k1"
+    assert b.profile_key(b.parse(["--scenario", "full", "--substeps", "1800"]), False) == "full_k1800"
+    assert b.profile_key(b.parse(["--substeps", "1800"]), False) == "bare_k1800"
+    assert b.profile_key(b.parse(["--gravity", "sh"]), True) == "sh70"
+    assert b.profile_key(b.parse(["--envs", "4194304"]), False) == "4m_k1"
+    assert b.profile_key(b.parse(["--envs", "1000"]), False) is None
+    assert b.profile_key(b.parse(["--features", "power"]), False) is None

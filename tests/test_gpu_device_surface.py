@@ -1,0 +1,166 @@
+"""GPU: the device-resident env surface (row f4's purpose: the training loop stays on the GPU) and the one-process
+multi-handle batch — both must give EXACTLY what the host path / the unsharded batch give.
+
+* ``LeoPowerAttVecEnv.step_tensors``: device int32 actions in, device obs / reward / done out, no host sync;
+  compared bit for bit with ``step()`` of a twin env through episode ends and device-side resets, on the handle's
+  own stream (cross-stream waits) and on torch's stream (no ordering needed).
+* DLPack / ``__cuda_array_interface__`` views alias the library's buffers.
+* ``ShardedVecEnv(devices=[0, 0])``: two handles and streams on the one card == the unsharded env, bit for bit;
+  pinned per-device D2H; the direct gather's own-shard path.
+"""
+import numpy as np
+import pytest
+
+from basilisk_env_amd._lib import FLAG_AUTO_RESET, GRAV_PM, GRAV_PM_J2
+from basilisk_env_amd.envs import LeoPowerAttVecEnv
+from basilisk_env_amd.sharded import ShardedPropagator, ShardedVecEnv
+from basilisk_env_amd.simulators.dynamics import BatchedPropagator, default_config
+from basilisk_env_amd.simulators.initial_conditions.batch import sample_ic_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _twin_envs(n, own_stream, **extra):
+    import torch
+    kw = dict(n_rw=3, gravity_model=GRAV_PM_J2, step_duration=2.0, seed=7, device_reset_pool=32)
+    kw.update(extra)
+    probe = LeoPowerAttVecEnv(n, **kw)
+    cfg = probe.cfg
+    probe.close()
+    cfg.max_length = 3
+    host = LeoPowerAttVecEnv(n, cfg=cfg, step_duration=2.0, seed=7, device_reset_pool=32)
+    stream = None if own_stream else torch.cuda.current_stream().cuda_stream
+    dev = LeoPowerAttVecEnv(n, cfg=cfg, step_duration=2.0, seed=7, device_reset_pool=32, stream=stream)
+    return host, dev
+
+
+@pytest.mark.parametrize("own_stream", [True, False])
+@pytest.mark.parametrize("n", [64, 333])
+def test_step_tensors_is_bit_identical_to_host_path(n, own_stream):
+    import torch
+    host, dev = _twin_envs(n, own_stream)
+    ob_h = host.reset()
+    ob_d = dev.reset_tensors()
+    assert ob_d.is_cuda and tuple(ob_d.shape) == (n, 5, 1) and np.array_equal(ob_d.cpu().numpy(), ob_h)
+    rng = np.random.default_rng(3)
+    n_done = 0
+    for step in range(8):
+        a = rng.integers(0, 3, n).astype(np.int32)
+        oh, rh, dh, ih = host.step(a)
+        at = torch.as_tensor(a, device="cuda")
+        od, rd, dd, info = dev.step_tensors(at)
+        assert od.is_cuda and rd.is_cuda and dd.is_cuda and dd.dtype == torch.bool and tuple(od.shape) == (n, 5, 1)
+        # consumers on torch's current stream are ordered after the kernel: no explicit synchronisation here
+        assert np.array_equal(od.cpu().numpy(), oh)
+        assert np.array_equal(rd.cpu().numpy(), rh)
+        assert np.array_equal(dd.cpu().numpy(), dh)
+        if dh.any():
+            term = info["terminal_observation"].cpu().numpy()
+            for i in np.flatnonzero(dh):
+                assert np.array_equal(term[i], ih[i]["terminal_observation"])
+            n_done += int(dh.sum())
+        assert np.array_equal(info["episodes"].cpu().numpy(), host.propagator.get_terminal_obs()[1])
+    assert n_done >= n                                   # every env went through a device-side reset
+    assert np.array_equal(dev.get_state(), host.get_state())
+    host.close()
+    dev.close()
+
+
+def test_step_tensors_argument_checks():
+    import torch
+    env = LeoPowerAttVecEnv(64, n_rw=3, gravity_model=GRAV_PM, step_duration=1.0, power=False)
+    env.reset()
+    with pytest.raises(ValueError):                       # host-side auto-reset cannot serve the tensor path
+        env.step_tensors(torch.zeros(64, dtype=torch.int32, device="cuda"))
+    env.close()
+    env = LeoPowerAttVecEnv(64, n_rw=3, gravity_model=GRAV_PM, step_duration=1.0, power=False, auto_reset=False)
+    env.reset()
+    for bad in (torch.zeros(64, dtype=torch.int64, device="cuda"), torch.zeros(63, dtype=torch.int32, device="cuda"),
+                torch.zeros(64, dtype=torch.int32), np.zeros(64, np.int32)):
+        with pytest.raises(ValueError):
+            env.step_tensors(bad)
+    ob, rew, done, info = env.step_tensors(torch.ones(64, dtype=torch.int32, device="cuda"))
+    assert "terminal_observation" not in info and not bool(done.any())
+    env.close()
+
+
+def test_on_device_policy_loop_runs_without_host_sync():
+    """A linear -> argmax policy on the GPU drives the env for 50 steps; the only host read is at the end."""
+    import torch
+    n = 4096
+    env = LeoPowerAttVecEnv(n, n_rw=4, step_duration=1.0, seed=1, device_reset_pool=256, device_sampler=True,
+                            stream=torch.cuda.current_stream().cuda_stream)
+    ob = env.reset_tensors()
+    w = torch.randn(5, 3, dtype=torch.float64, device="cuda")
+    ret = torch.zeros(n, dtype=torch.float64, device="cuda")
+    for _ in range(50):
+        act = (ob.reshape(n, 5) @ w).argmax(dim=1).to(torch.int32)
+        ob, rew, done, info = env.step_tensors(act)
+        ret += rew
+    assert bool(torch.isfinite(ret).all()) and bool(torch.isfinite(ob).all())
+    env.close()
+
+
+def test_device_views_dlpack_and_cuda_array_interface_alias_the_buffers():
+    import torch
+    n = 200
+    cfg = default_config(4, GRAV_PM_J2)
+    cfg.flags |= FLAG_AUTO_RESET
+    p = BatchedPropagator(cfg, n)
+    p.set_ic_pool(sample_ic_batch(8, 4, seed=0))
+    p.reset(sample_ic_batch(n, 4, seed=1))
+    p.step(np.zeros(n, np.int32), 3)
+    obs, rew, done, why = p.get_obs()
+    v = p.device_views()
+    assert set(v) >= {"obs", "reward", "reason", "done_mask", "state", "terminal_obs", "episodes", "stride"}
+    for name, want in (("obs", obs), ("reward", rew), ("reason", why), ("state", p.get_state())):
+        a = torch.from_dlpack(v[name])
+        b = torch.as_tensor(v[name], device="cuda")
+        assert a.is_cuda and a.data_ptr() == b.data_ptr() and a.stride() == b.stride()
+        assert np.array_equal(a.cpu().numpy(), want)
+    assert v["obs"].__dlpack_device__() == (10, 0)
+    assert torch.from_dlpack(v["episodes"]).dtype == torch.int32
+    assert p.stream_ptr() != 0
+    p.close()
+
+
+@pytest.mark.parametrize("n", [130, 1000])
+def test_sharded_vec_env_two_handles_one_card_equals_unsharded(n):
+    kw = dict(n_rw=3, gravity_model=GRAV_PM_J2, step_duration=2.0, seed=11, device_reset_pool=32)
+    probe = LeoPowerAttVecEnv(n, **kw)
+    cfg = probe.cfg
+    probe.close()
+    cfg.max_length = 3
+    one = LeoPowerAttVecEnv(n, cfg=cfg, step_duration=2.0, seed=11, device_reset_pool=32)
+    two = ShardedVecEnv(n, devices=[0, 0], cfg=cfg, step_duration=2.0, seed=11, device_reset_pool=32)
+    assert len(two.propagator.shards) == 2 and two.propagator.shards[0].stream_ptr() != two.propagator.shards[1].stream_ptr()
+    assert np.array_equal(one.reset(), two.reset())
+    rng = np.random.default_rng(5)
+    for _ in range(7):
+        a = rng.integers(0, 3, n)
+        r1, r2 = one.step(a), two.step(a)
+        for x, y in zip(r1[:3], r2[:3]):
+            assert np.array_equal(x, y)
+        for i in np.flatnonzero(r1[2]):
+            assert np.array_equal(r1[3][i]["terminal_observation"], r2[3][i]["terminal_observation"])
+            assert r1[3][i]["episode"] == r2[3][i]["episode"]
+    assert np.array_equal(one.get_state(), two.get_state())
+    assert one.batch_stats()[1] == two.batch_stats()[1]
+    one.close()
+    two.close()
+
+
+def test_sharded_gather_obs_device_single_shard_path():
+    """world = 1: the direct gather degenerates to the root's own strided device-to-device copy (the RCCL legs need
+    distinct GPUs; their address arithmetic is covered on CPU, tests/test_sharded_host.py)."""
+    import torch
+    n = 300
+    cfg = default_config(4, GRAV_PM_J2)
+    sp = ShardedPropagator(cfg, n, devices=[0])
+    sp.reset(sample_ic_batch(n, 4, seed=2))
+    sp.step(np.zeros(n, np.int32), 5)
+    view = sp.gather_obs_device(root=0)
+    t = torch.from_dlpack(view)              # drains the handle's stream, then aliases the gather buffer
+    obs = sp.get_obs()[0]
+    assert tuple(t.shape) == (5, n) and t.is_contiguous() and np.array_equal(t.cpu().numpy(), obs)
+    sp.close()

@@ -1,0 +1,175 @@
+"""CPU: one batch over several "devices" in one process (basilisk_env_amd/sharded.py) with the oracle-backed engine
+on two / three fake devices — the sharded batch must reproduce the unsharded one EXACTLY (env-index ranges, global
+index in the device-side reset's slot rule, no step-path exchange), through the propagator interface and through
+the whole VecEnv.  Plus the DLPack export and the direct-RCCL gather's address arithmetic (no GPU, no librccl call).
+"""
+import numpy as np
+import pytest
+
+from _oracle_backend import OraclePropagator
+from basilisk_env_amd._lib import FLAG_AUTO_RESET, GRAV_PM_J2
+from basilisk_env_amd.envs import LeoPowerAttVecEnv
+from basilisk_env_amd.sharded import ShardedPropagator, ShardedVecEnv
+from basilisk_env_amd.simulators.dynamics.config import default_config
+from basilisk_env_amd.simulators.initial_conditions.batch import sample_ic_batch
+
+
+@pytest.mark.parametrize("n,devices", [(64, [0, 1]), (37, [0, 1, 2]), (5, [0, 0])])
+def test_sharded_propagator_equals_unsharded(n, devices):
+    cfg = default_config(4, GRAV_PM_J2)
+    cfg.flags |= FLAG_AUTO_RESET
+    cfg.max_length = 2
+    ic = sample_ic_batch(n, 4, seed=1)
+    pool = sample_ic_batch(11, 4, seed=2)
+    one = OraclePropagator(cfg, n)
+    many = ShardedPropagator(cfg, n, devices=devices, propagator_factory=OraclePropagator)
+    assert [p.env_base for p in many.shards] == [lo for lo, _ in many.ranges] and sum(many.sizes) == n
+    for p in (one, many):
+        p.set_ic_pool(pool)
+        p.reset(ic)
+    rng = np.random.default_rng(0)
+    for _ in range(4):                       # episodes end after 2 steps: the pool reset fires on both sides
+        a = rng.integers(0, 3, n).astype(np.int32)
+        one.step(a, 7)
+        many.step(a, 7)
+        for x, y in zip(one.get_obs(), many.get_obs()):
+            assert np.array_equal(x, y)
+        assert np.array_equal(one.get_state(), many.get_state())
+        for x, y in zip(one.get_terminal_obs(), many.get_terminal_obs()):
+            assert np.array_equal(x, y)
+        for x, y in zip(one.get_counters(), many.get_counters()):
+            assert np.array_equal(x, y)
+        assert abs(one.batch_stats()[0] - many.batch_stats()[0]) < 1e-12 and one.batch_stats()[1] == many.batch_stats()[1]
+    # masked reset and checkpoint restore go to the right shards
+    mask = (np.arange(n) % 3 == 0).astype(np.uint8)
+    ic2 = sample_ic_batch(n, 4, seed=3)
+    one.reset(ic2, mask)
+    many.reset(ic2, mask)
+    assert np.array_equal(one.get_state(), many.get_state())
+    st = many.get_state()
+    many.set_state(st[:, ::-1].copy())
+    assert np.array_equal(many.get_state(), st[:, ::-1])
+    many.close()
+
+
+def _same(x, y):
+    if isinstance(x, dict):
+        return isinstance(y, dict) and set(x) == set(y) and all(_same(x[k], y[k]) for k in x)
+    if isinstance(x, np.ndarray):
+        return np.array_equal(x, y)
+    return x == y
+
+
+def test_sharded_vec_env_equals_single_vec_env():
+    kw = dict(n_rw=3, seed=5, device_reset_pool=16, power=False)
+    a = LeoPowerAttVecEnv(12, propagator_factory=OraclePropagator, **kw)
+    b = ShardedVecEnv(12, devices=[0, 1, 2], propagator_factory=OraclePropagator, **kw)
+    assert isinstance(b, LeoPowerAttVecEnv) and isinstance(b.propagator, ShardedPropagator)
+    for e in (a, b):
+        e.max_length = 2
+        e.cfg.max_length = 2
+    a.propagator.cfg.max_length = 2
+    for p in b.propagator.shards:
+        p.cfg.max_length = 2
+    oa, ob = a.reset(), b.reset()
+    assert np.array_equal(oa, ob)
+    rng = np.random.default_rng(1)
+    for _ in range(5):
+        act = rng.integers(0, 3, 12)
+        ra, rb = a.step(act), b.step(act)
+        assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2])
+        for x, y in zip(ra[3], rb[3]):
+            assert _same(x, y)
+    assert np.array_equal(a.reset_init(), b.reset_init())
+    a.close()
+    b.close()
+
+
+def test_too_few_envs_or_no_devices():
+    cfg = default_config(0, GRAV_PM_J2)
+    with pytest.raises(ValueError):
+        ShardedPropagator(cfg, 1, devices=[0, 1], propagator_factory=OraclePropagator)
+    with pytest.raises(ValueError):
+        ShardedPropagator(cfg, 4, devices=[], propagator_factory=OraclePropagator)
+
+
+def test_direct_gather_address_arithmetic(monkeypatch):
+    """rccl.enqueue_gather_rows / copy_own_rows post exactly the messages that land shard r's row f at
+    out[f][offset_r : offset_r + n_r]: played back against numpy buffers with a fake librccl."""
+    from basilisk_env_amd import _hip, rccl
+
+    sizes, rows = [3, 4, 2], 5
+    n_total = sum(sizes)
+    shards = [np.arange(rows * 8, dtype=np.float64).reshape(rows, 8) + 100 * r for r in range(3)]   # pitch 8 > n_r
+    out = np.zeros((rows, n_total))
+    sends, recvs = {}, []
+
+    class FakeLib(object):
+        def ncclSend(self, ptr, count, dtype, peer, comm, stream):
+            sends.setdefault((comm.value, peer), []).append((ptr.value, count))
+            return 0
+
+        def ncclRecv(self, ptr, count, dtype, peer, comm, stream):
+            recvs.append((ptr.value, count, peer))
+            return 0
+
+    monkeypatch.setattr(rccl, "load", lambda: FakeLib())
+    copies = []
+    monkeypatch.setattr(_hip, "set_device", lambda d: None)
+    monkeypatch.setattr(_hip, "memcpy2d_async", lambda *a: copies.append(a))
+    root = 1
+    for r in range(3):
+        comm = rccl.Comm(1000 + r, r, 3, r)
+        rccl.enqueue_gather_rows(comm, 7, root, sizes, shards[r].ctypes.data, 8 * 8, rows, out.ctypes.data)
+        rccl.copy_own_rows(comm, 7, root, sizes, shards[r].ctypes.data, 8 * 8, rows, out.ctypes.data)
+    # play the messages: the k-th recv from peer p pairs with the k-th send of p to the root
+    import ctypes
+    taken = {}
+    for ptr, count, peer in recvs:
+        k = taken.get(peer, 0)
+        sptr, scount = sends[(1000 + peer, root)][k]
+        taken[peer] = k + 1
+        assert scount == count == sizes[peer]
+        ctypes.memmove(ptr, sptr, count * 8)
+    assert len(copies) == 1
+    dst, dpitch, src, spitch, width, height, kind, stream = copies[0]
+    for f in range(height):
+        ctypes.memmove(dst + f * dpitch, src + f * spitch, width)
+    want = np.concatenate([s[:, :n] for s, n in zip(shards, sizes)], axis=1)
+    assert np.array_equal(out, want) and kind == _hip.hipMemcpyDeviceToDevice
+
+
+def test_dlpack_capsule_roundtrip_on_host_memory():
+    """_dlpack.make_capsule: a strided (5, N) view over foreign memory reaches torch without a copy and releases
+    its bookkeeping when the consumer lets go (device type forced to CPU here; kDLROCM on the product path)."""
+    import gc
+
+    import torch
+
+    from basilisk_env_amd import _dlpack
+
+    buf = np.arange(5 * 16, dtype=np.float64).reshape(5, 16)     # stride 16, 10 valid envs per row
+
+    class View(object):
+        def __dlpack_device__(self):
+            return (1, 0)
+
+        def __dlpack__(self, stream=None, **_):
+            return _dlpack.make_capsule(buf.ctypes.data, (5, 10), "<f8", (16 * 8, 8), owner=self, device_type=1)
+
+    before = _dlpack.live_exports()
+    t = torch.from_dlpack(View())
+    assert tuple(t.shape) == (5, 10) and t.stride() == (16, 1) and t.dtype == torch.float64
+    assert np.array_equal(t.numpy(), buf[:, :10])
+    buf[2, 3] = -1.0
+    assert float(t[2, 3]) == -1.0                                # zero copy
+    assert _dlpack.live_exports() == before + 1
+    del t
+    gc.collect()
+    assert _dlpack.live_exports() == before
+    cap = View().__dlpack__()                                    # never consumed: the capsule cleans up itself
+    assert _dlpack.live_exports() == before + 1
+    del cap
+    gc.collect()
+    assert _dlpack.live_exports() == before
+    assert _dlpack.typestr_to_dl("|u1").bits == 8 and _dlpack.typestr_to_dl("<i4").code == 0

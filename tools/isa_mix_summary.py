@@ -33,4 +33,10 @@ for key, sub in SUB.items():
                   "wait_any_over_wave_cycles": rec["SQ_WAIT_ANY"] / rec["SQ_WAVE_CYCLES"],
                   "grbm_gui_active": rec.get("GRBM_GUI_ACTIVE")})
     out[key] = m
+# fingerprint of the kernel sources the counts were taken on (bench.py flags a mix counted on another tree)
+import importlib.util
+_spec = importlib.util.spec_from_file_location("bench_module", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+_b = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_b)
+out["_meta"] = {"fingerprint": _b.kernel_fingerprint()}
 print(json.dumps(out, indent=1))

@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Steady-state summary of rocprofv3 --kernel-trace runs of bench.py (tools/round.sh) -> kernel_trace.json.
+
+usage: tools/kernel_trace_summary.py GPURUN_OUT_DIR [PROFILES_DIR]
+
+For every kt_<name>/ run directory: the per-dispatch CSV of the step kernel, in dispatch order; the dispatches that
+start within RAMP_MS of the kernel's first dispatch are set aside (clock ramp: the first ~25 ms of a run read up to
+20 % long), at most half of them; over the rest median, p10 / p90, mean and the mean of the middle 80 %.  The result
+carries the fingerprint of the kernel sources it was measured on (bench.kernel_fingerprint), and bench.py prices its
+rooflines on max(its own stamped pass, this trimmed mean) only while the fingerprints agree.  With PROFILES_DIR the
+per-dispatch durations are written next to the summary as kt_<name>_dispatches.csv (dispatch index, start offset
+[us], duration [ns]) so that every figure can be recomputed from the committed files.
+"""
+import csv
+import glob
+import importlib.util
+import json
+import os
+import sys
+
+RAMP_MS = 25.0
+KEYS = {"kt_65k": "65k_k1", "kt_4m": "4m_k1", "kt_k1800": "bare_k1800", "kt_power_k1800": "power_k1800",
+        "kt_full_k1800": "full_k1800", "kt_sh": "sh70"}
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def fingerprint():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.kernel_fingerprint()
+
+
+def pct(srt, q):
+    return srt[min(len(srt) - 1, max(0, int(round(q * (len(srt) - 1)))))]
+
+
+def summarise(path):
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if "step_kernel" not in r.get("Kernel_Name", ""):
+                continue
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("VGPR_Count"),
+                         r.get("Accum_VGPR_Count"), r.get("Grid_Size_X") or r.get("Grid_Size"), r.get("Workgroup_Size_X") or r.get("Workgroup_Size")))
+    if not rows:
+        return None, []
+    rows.sort()
+    # one run may hold launches of different shapes (the stamped pass and warm-up are the same launch): keep the most
+    # frequent (kernel, grid) pair
+    shapes = {}
+    for r in rows:
+        shapes[(r[2], r[5])] = shapes.get((r[2], r[5]), 0) + 1
+    top = max(shapes, key=shapes.get)
+    rows = [r for r in rows if (r[2], r[5]) == top]
+    t0 = rows[0][0]
+    dur = [(r[0] - t0, r[1] - r[0]) for r in rows]
+    n_ramp = sum(1 for s, _ in dur if s < RAMP_MS * 1e6)
+    n_ramp = min(n_ramp, len(dur) // 2)
+    steady = sorted(d for _, d in dur[n_ramp:])
+    cut = len(steady) // 10
+    core = steady[cut:len(steady) - cut] if len(steady) >= 10 else steady
+    rec = {"kernel": rows[0][2], "grid": rows[0][5], "workgroup": rows[0][6], "vgprs": rows[0][3], "agprs": rows[0][4],
+           "dispatches": len(dur), "ramp_dispatches_dropped": n_ramp, "ramp_ms": RAMP_MS, "steady_dispatches": len(steady),
+           "mean_all_us": sum(d for _, d in dur) / len(dur) / 1e3,
+           "mean_ramp_us": (sum(d for _, d in dur[:n_ramp]) / n_ramp / 1e3) if n_ramp else None,
+           "mean_us": sum(steady) / len(steady) / 1e3, "median_us": pct(steady, 0.5) / 1e3, "p10_us": pct(steady, 0.1) / 1e3,
+           "p90_us": pct(steady, 0.9) / 1e3, "min_us": steady[0] / 1e3, "max_us": steady[-1] / 1e3,
+           "trimmed_mean_us": sum(core) / len(core) / 1e3, "averaging": "mean of the middle 80 % of the steady-state dispatches"}
+    return rec, dur
+
+
+def main():
+    d = sys.argv[1]
+    outdir = sys.argv[2] if len(sys.argv) > 2 else None
+    out = {"fingerprint": fingerprint(), "runs": {}}
+    for sub in sorted(os.listdir(d)):
+        p = os.path.join(d, sub)
+        if not os.path.isdir(p) or not sub.startswith("kt_"):
+            continue
+        fs = [f for f in glob.glob(os.path.join(p, "*", "*_kernel_trace.csv")) if os.path.getsize(f) > 0]
+        if not fs:
+            continue
+        rec, dur = summarise(fs[0])
+        if rec is None:
+            continue
+        key = KEYS.get(sub, sub[3:])
+        rec["csv"] = "%s_dispatches.csv" % sub
+        rec["stats_csv"] = "%s_kernel_stats.csv" % sub
+        out["runs"][key] = rec
+        if outdir:
+            with open(os.path.join(outdir, rec["csv"]), "w") as f:
+                f.write("dispatch,start_offset_us,duration_ns\n")
+                for i, (s, dd) in enumerate(dur):
+                    f.write("%d,%.1f,%d\n" % (i, s / 1e3, dd))
+            st = glob.glob(os.path.join(p, "*", "*_kernel_stats.csv"))
+            if st:
+                with open(st[0]) as src, open(os.path.join(outdir, rec["stats_csv"]), "w") as dst:
+                    dst.write(src.read())
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
