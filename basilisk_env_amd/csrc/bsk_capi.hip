@@ -335,6 +335,8 @@ int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool&
         for (int j = 0; j < 3; ++j) k.kt[bsk::KA_G + 3 * i + j] = c.gs[i][j];
         k.kt[bsk::KA_JS + i] = c.js[i];
         k.kt[16 + bsk::KB_IJS + i] = 1.0 / c.js[i];
+        for (int j = 0; j < 3; ++j) k.kt[48 + bsk::KD_JG + 3 * i + j] = c.js[i] * c.gs[i][j];
+        k.kt[48 + bsk::KD_HIJS + i] = c.dt / c.js[i];
     }
     for (int sgn = 0; sgn < 2; ++sgn)
         for (int axis = 0; axis < 3; ++axis) {

@@ -185,7 +185,7 @@ struct ColdCfg {
     int32_t nav_lag, pad3_;   // bsk_config.nav_lag: FSW ticks run before the dynamics task of their time
     // wave-uniform constants of the full-scenario kernels: three rows of 16 doubles, fetched lane-wise into three
     // VGPR pairs (lane l holds entry l & 15 of each row) and fed to the FMAs through the DPP row broadcast (KTab)
-    double kt[48];
+    double kt[64];
     // force / torque sums of every subset of the thrusters at full thrust, body frame: row m = sum over the bits
     // of m of (thr_f[i], thr_l[i]) added in ascending i (the oracle's order), so an 8-term conditional sum with
     // 48 table loads per integrator stage becomes one 6-double row picked by the activity mask
@@ -195,6 +195,7 @@ struct ColdCfg {
 enum { KA_G = 0, KA_JS = 12 };                                 // wheel spin axes g[i][k] at 3 i + k, Js_i
 enum { KB_IJS = 0, KB_FAC = 4, KB_FAD = 10 };                  // 1/Js_i, facet half sums / differences (6 + 6)
 enum { KC_IMASS = 0, KC_NB = 1, KC_KFLUX = 4, KC_RHO0 = 5, KC_NIH = 6, KC_REQIH = 7, KC_RSKIP = 8 };   // 1/m, panel normal, ...
+enum { KD_JG = 0, KD_HIJS = 12 };                              // row D: Js_i g[i][k] at 3 i + k, dt / Js_i
 
 // Guidance / observation / reward constants: by value in the kernarg (used once per launch, outside
 // the RK4 loop, so they may be parked in VGPR lanes across it at no cost to the loop).
@@ -236,6 +237,11 @@ struct WheelV {
             p = axpy(js_[i] * Om[i], g, p);
             tqj[i] = tq[i] * ijs_[i];
         }
+    }
+    // wheel speeds at the end of the step without the hub's reaction: Om_i + h tq_i / Js_i
+    __device__ __forceinline__ void bases(double h, const double* tq, const double* tqj, const double* Om, double* base) const {
+#pragma unroll
+        for (int i = 0; i < NRW; ++i) base[i] = fma(h, tqj[i], Om[i]);
     }
     // tail: Om_i = base_i - g_i . dw   (accumulated z, y, x: the order of the fma chain below)
     __device__ __forceinline__ void tail(V3 dw, const double* base, double* Om) const {
@@ -417,9 +423,20 @@ __device__ __forceinline__ double shadow_factor(const PowerCfg& pc, const SunGeo
 // evaluated by lane e mod 64, whoever owns it, so ten penumbra ticks of one spacecraft cost one pass of
 // percent_shadow instead of ten — and every lane replays its battery updates in tick order (three operations per
 // tick).  Same arithmetic on the same inputs as the tick-by-tick form, hence the same results bit for bit.
-constexpr int PEN_SLOTS = 10;                 // ticks between two flushes (the inner loop is chunked to this)
-constexpr int PEN_QCAP = 64 * PEN_SLOTS;      // every lane partially eclipsed at every tick still fits
-struct PowerLds {                             // one per wavefront, in dynamic LDS (29 KB)
+// Round 3: the record is three FSW periods long.  Measured (profiles/r03/rejected/power_system_forms.txt): the per-tick
+// arithmetic is nearly free, what costs is the drain - percent_shadow is ~250 dependent fp64 instructions, ~2 us for a wave
+// alone on its SIMD - and with 64 spacecraft per wave some lane is in the penumbra during most 10-tick windows, so
+// practically every flush paid it (0.4 ms of the power level's 2.3 ms at K = 1800).  One pass serves up to 64 queue entries
+// for the same latency, so the record now spans PEN_SLOTS = 30 ticks (a third of the passes); the queue holds PEN_QCAP
+// entries and a tick that finds it full evaluates its factor on the spot (never in LEO: 192 entries are three spacecraft in
+// the penumbra for the whole record), so the worst case costs time, not correctness.
+constexpr int PEN_CHUNK = 10;                 // RK4 ticks per trip of the inner loop at most (third-body anchor)
+#ifndef PEN_SLOTS_OVERRIDE
+#define PEN_SLOTS_OVERRIDE 30
+#endif
+constexpr int PEN_SLOTS = PEN_SLOTS_OVERRIDE; // ticks recorded between two flushes
+constexpr int PEN_QCAP = 192;                 // penumbra queue entries per record
+struct PowerLds {                             // one per wavefront, in dynamic LDS (38.5 KB: four waves per CU fit the 160 KB)
     double g[PEN_SLOTS][64];
     double s[PEN_SLOTS][64];
     double sun[3][64];                        // each lane's Sun position of this launch
@@ -473,7 +490,40 @@ __device__ __forceinline__ double get_k(double tab) {                           
 // its operands (the compiler pads that distance with s_nop, and every s_nop costs a one-wave SIMD an issue slot)
 template <int NRW>
 struct WheelDpp {
-    double ta, tb;
+    double ta, tb, td;
+#ifndef BSK_FOLD_JS
+#define BSK_FOLD_JS 1
+#endif
+#if BSK_FOLD_JS
+    // The wheel inertia folded into the table (row D: Js_i g_i and dt / Js_i): the momentum sum reads the wheel speeds
+    // directly and the end-of-step base is one DPP FMA per wheel - no Js Om_i / tq_i / Js_i intermediates, each of
+    // which cost a zero-initialising move and a one-term chain (16 issue slots per step less)
+    __device__ __forceinline__ void head(const double* tq, const double* Om, V3& T, V3& p, double* tqj) const {
+        T = mk(0, 0, 0);
+        p = mk(0, 0, 0);
+        auto wheel = [&](auto IC) {
+            constexpr int i = decltype(IC)::value;
+            T.x = fmac_k<KA_G + 3 * i>(T.x, ta, tq[i]); T.y = fmac_k<KA_G + 3 * i + 1>(T.y, ta, tq[i]); T.z = fmac_k<KA_G + 3 * i + 2>(T.z, ta, tq[i]);
+            p.x = fmac_k<KD_JG + 3 * i>(p.x, td, Om[i]); p.y = fmac_k<KD_JG + 3 * i + 1>(p.y, td, Om[i]); p.z = fmac_k<KD_JG + 3 * i + 2>(p.z, td, Om[i]);
+        };
+        if constexpr (NRW > 0) wheel(std::integral_constant<int, 0>{});
+        if constexpr (NRW > 1) wheel(std::integral_constant<int, 1>{});
+        if constexpr (NRW > 2) wheel(std::integral_constant<int, 2>{});
+        if constexpr (NRW > 3) wheel(std::integral_constant<int, 3>{});
+    }
+    __device__ __forceinline__ void bases(double h, const double* tq, const double* tqj, const double* Om, double* base) const {
+#pragma unroll
+        for (int i = 0; i < NRW; ++i) base[i] = Om[i];
+        if constexpr (NRW > 0) base[0] = fmac_k<KD_HIJS + 0>(base[0], td, tq[0]);
+        if constexpr (NRW > 1) base[1] = fmac_k<KD_HIJS + 1>(base[1], td, tq[1]);
+        if constexpr (NRW > 2) base[2] = fmac_k<KD_HIJS + 2>(base[2], td, tq[2]);
+        if constexpr (NRW > 3) base[3] = fmac_k<KD_HIJS + 3>(base[3], td, tq[3]);
+    }
+#else
+    __device__ __forceinline__ void bases(double h, const double* tq, const double* tqj, const double* Om, double* base) const {
+#pragma unroll
+        for (int i = 0; i < NRW; ++i) base[i] = fma(h, tqj[i], Om[i]);
+    }
     __device__ __forceinline__ void head(const double* tq, const double* Om, V3& T, V3& p, double* tqj) const {
         double jo[NRW > 0 ? NRW : 1];
         T = mk(0, 0, 0);
@@ -498,6 +548,7 @@ struct WheelDpp {
         if constexpr (NRW > 2) wheel(std::integral_constant<int, 2>{});
         if constexpr (NRW > 3) wheel(std::integral_constant<int, 3>{});
     }
+#endif
     __device__ __forceinline__ void tail(V3 dw, const double* base, double* Om) const {
 #pragma unroll
         for (int i = 0; i < NRW; ++i) Om[i] = base[i];
@@ -546,15 +597,33 @@ __device__ __forceinline__ void power_tick(const PowerCfg& pc, const SunGeom& g,
     const V3 sB = sN + (8.0 * iop2) * t2 - (4.0 * (1.0 - q2) * iop2) * t1;
     if constexpr (LDSK) {     // panel normal and flux constant from the broadcast table (row C)
         const double proj = fmax(fmac_k<KC_NB>(fmac_k<KC_NB + 1>(mul_k<KC_NB + 2>(tc, sB.z), tc, sB.y), tc, sB.x), 0.0);
-        L->g[t][lane] = mul_k<KC_KFLUX>(tc, id * id) * proj;
+        const double gain = mul_k<KC_KFLUX>(tc, id * id) * proj;
+#if defined(BSK_ABLATE) && BSK_ABLATE == 7
+        asm volatile("" ::"v"(gain));
+#else
+        L->g[t][lane] = gain;
+#endif
     } else {
         const double proj = fmax(fma(pc.nB[0], sB.x, fma(pc.nB[1], sB.y, pc.nB[2] * sB.z)), 0.0);
-        L->g[t][lane] = pc.kflux * (id * id) * proj;
+        const double gain = pc.kflux * (id * id) * proj;
+#if defined(BSK_ABLATE) && BSK_ABLATE == 7
+        asm volatile("" ::"v"(gain));
+#else
+        L->g[t][lane] = gain;
+#endif
     }
+#if defined(BSK_ABLATE) && BSK_ABLATE == 7   // timing only: the tick's arithmetic without its LDS record
+    asm volatile("" ::"v"(sh), "v"(band ? 1 : 0));
+    return;
+#endif
     if (BSK_UNLIKELY(band)) {
         const int e = __hip_atomic_fetch_add(&L->qcount, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        L->qr[0][e] = r.x; L->qr[1][e] = r.y; L->qr[2][e] = r.z;
-        L->qown[e] = lane | (t << 8);
+        if (BSK_LIKELY(e < PEN_QCAP)) {
+            L->qr[0][e] = r.x; L->qr[1][e] = r.y; L->qr[2][e] = r.z;
+            L->qown[e] = lane | (t << 8);
+        } else {
+            L->s[t][lane] = percent_shadow(pc, g.sun - r, r, dot(r, r));   // queue full: this lane evaluates its own tick now
+        }
     } else {
         L->s[t][lane] = sh;
     }
@@ -573,7 +642,7 @@ __device__ __forceinline__ void power_flush(const PowerCfg& pc, LdsP L, int m, i
 #endif
     const double draw = pc.draw, cap = pc.cap;
     double sk[PEN_SLOTS], dq[PEN_SLOTS];
-    const int qc = L->qcount;
+    const int qc = min(L->qcount, PEN_QCAP);               // (pushes beyond the capacity were evaluated in place)
 #if BSK_FLUSH_ONE_TRIP
 #pragma unroll
     for (int k = 0; k < PEN_SLOTS; ++k) {
@@ -581,7 +650,11 @@ __device__ __forceinline__ void power_flush(const PowerCfg& pc, LdsP L, int m, i
         dq[k] = L->g[k][lane];
     }
 #endif
+#if defined(BSK_ABLATE) && BSK_ABLATE == 8   // timing only: record read back and replayed, queue never drained
+    if (false) {
+#else
     if (BSK_UNLIKELY(qc > 0)) {                           // wave-uniform
+#endif
         for (int e = lane; e < qc; e += 64) {
             const int own = L->qown[e], ol = own & 63, k = own >> 8;
             const V3 r = mk(L->qr[0][e], L->qr[1][e], L->qr[2][e]);
@@ -1063,14 +1136,17 @@ struct Core {
 
 // THR: the step runs inside a thruster burst of some lane of the wave (the tick loop picks the instantiation, so the
 // steps outside bursts - nearly all - carry no thruster code and no branch around it)
-template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT, bool THR>
+// DRAGM: 0 = the drag switch is tested where it is used (one wave-uniform branch per stage), 1 / 2 = the tick loop has
+// picked the instantiation with / without drag, so that a stage is one branch-free scheduling region
+template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT, bool THR, int DRAGM = 0>
 __device__ __forceinline__ void eom(const HotCfg<NRW, DIAG>& c, const Core& x, V3 rhs0, V3 T, double tsim, const Env& ev,
                                     int de2, Core& d) {
     d.r = x.v;
     if constexpr (is_full<FEAT>()) {
         // Sun third body, unconditionally: with the flag off k and A0 are zero and both FMAs return their addend
         d.v = tidal(ev.s3, x.r, gravity<GRAV, SPLIT>(c, x.r, tsim, ev.s3.A0));
-        if (BSK_LIKELY(ev.drag_on)) facet_drag<FEAT == FEAT_FULLG>(ev, x.s, x.v, d.v, rhs0);
+        if constexpr (DRAGM == 1) facet_drag<FEAT == FEAT_FULLG>(ev, x.s, x.v, d.v, rhs0);
+        else if constexpr (DRAGM == 0) { if (BSK_LIKELY(ev.drag_on)) facet_drag<FEAT == FEAT_FULLG>(ev, x.s, x.v, d.v, rhs0); }
         if constexpr (THR) {
             V3 aN, LB;
             thrusters(ev, de2, x.s, aN, LB);
@@ -1138,7 +1214,18 @@ __device__ __forceinline__ void acc_load(AccP A, int lane, Core& a) {
 // shadow-set switch once per completed step.  Motor torque and Coulomb friction are evaluated
 // from the wheel speeds at the start of the step and held through its four stages (the RW
 // effector updates both once per dyn tick, outside the equations of motion).
-template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT, bool THR = false, class WV>
+// keeps the RK4 accumulator's update where it is written (between the volatile DPP chains of two stages) instead of
+// letting the scheduler sink it to the end of the step, which keeps k1..k3 alive (45 doubles) until then
+__device__ __forceinline__ void anchor(V3& a) { asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z)); }
+template <int NRW>
+__device__ __forceinline__ void anchor_core(Core& a) {
+#ifdef BSK_ANCHOR_ACC
+    anchor(a.r); anchor(a.v); anchor(a.s); anchor(a.w);
+    if constexpr (NRW > 0) anchor(a.p);
+#endif
+}
+
+template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT, bool THR = false, int DRAGM = 0, class WV>
 __device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, const WV& wv, State<NRW>& x,
                                          const double* u, V3 lext, double t0, const Env& ev, AccP acc_lds = nullptr) {
     Core y, k, yt, acc;
@@ -1169,27 +1256,32 @@ __device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, const WV& w
     AccP A = nullptr;
     int lane = 0;
     if constexpr (LDSACC) { A = acc_lds; lane = (int)(threadIdx.x & 63u); }
-    eom<GRAV, NRW, DIAG, FEAT, SPLIT, THR>(c, y, rhs0, T, t0, ev, 0, k);
+    eom<GRAV, NRW, DIAG, FEAT, SPLIT, THR, DRAGM>(c, y, rhs0, T, t0, ev, 0, k);
     core_axpy<NRW>(c.h6, k, y, acc);
+    if constexpr (is_full<FEAT>()) anchor_core<NRW>(acc);
     if constexpr (LDSACC) acc_store<NRW>(A, lane, acc);
     core_axpy<NRW>(c.h2, k, y, yt);
-    eom<GRAV, NRW, DIAG, FEAT, SPLIT, THR>(c, yt, rhs0, T, t0 + c.h2, ev, 1, k);
+    eom<GRAV, NRW, DIAG, FEAT, SPLIT, THR, DRAGM>(c, yt, rhs0, T, t0 + c.h2, ev, 1, k);
     if constexpr (LDSACC) acc_load<NRW>(A, lane, acc);
     core_axpy<NRW>(c.h3, k, acc, acc);
+    if constexpr (is_full<FEAT>()) anchor_core<NRW>(acc);
     if constexpr (LDSACC) acc_store<NRW>(A, lane, acc);
     core_axpy<NRW>(c.h2, k, y, yt);
-    eom<GRAV, NRW, DIAG, FEAT, SPLIT, THR>(c, yt, rhs0, T, t0 + c.h2, ev, 1, k);
+    eom<GRAV, NRW, DIAG, FEAT, SPLIT, THR, DRAGM>(c, yt, rhs0, T, t0 + c.h2, ev, 1, k);
     if constexpr (LDSACC) acc_load<NRW>(A, lane, acc);
     core_axpy<NRW>(c.h3, k, acc, acc);
+    if constexpr (is_full<FEAT>()) anchor_core<NRW>(acc);
     if constexpr (LDSACC) acc_store<NRW>(A, lane, acc);
     core_axpy<NRW>(c.h, k, y, yt);
-    eom<GRAV, NRW, DIAG, FEAT, SPLIT, THR>(c, yt, rhs0, T, t0 + c.h, ev, 2, k);
+    eom<GRAV, NRW, DIAG, FEAT, SPLIT, THR, DRAGM>(c, yt, rhs0, T, t0 + c.h, ev, 2, k);
     if constexpr (LDSACC) acc_load<NRW>(A, lane, acc);
     core_axpy<NRW>(c.h6, k, acc, yt);
     const V3 dw = yt.w - y.w;
-#pragma unroll
-    for (int i = 0; i < NRW; ++i) tqj[i] = fma(c.h, tqj[i], x.Om[i]);
-    if constexpr (NRW > 0) wv.tail(dw, tqj, x.Om);
+    double base[NRW > 0 ? NRW : 1];
+    if constexpr (NRW > 0) {
+        wv.bases(c.h, tq, tqj, x.Om, base);
+        wv.tail(dw, base, x.Om);
+    }
     x.r = yt.r; x.v = yt.v; x.s = yt.s; x.w = yt.w;
     double s2 = dot(x.s, x.s);
     if (BSK_UNLIKELY(s2 > 1.0)) x.s = (-rcp_nr(s2)) * x.s;

@@ -146,10 +146,10 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
         // lane l of every 16-lane row fetches entry l & 15 of the three table rows (three coalesced loads)
         const int l16 = lane & 15;
         kt.a = cold->kt[l16]; kt.b = cold->kt[16 + l16]; kt.c = cold->kt[32 + l16];
-        wv.ta = kt.a; wv.tb = kt.b;
+        wv.ta = kt.a; wv.tb = kt.b; wv.td = cold->kt[48 + l16];
     } else if constexpr (WDPP) {
         const int l16 = lane & 15;
-        wv.ta = cold->kt[l16]; wv.tb = cold->kt[16 + l16];
+        wv.ta = cold->kt[l16]; wv.tb = cold->kt[16 + l16]; wv.td = cold->kt[48 + l16];
     } else {
         wv.load(c);
     }
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
             const int trig = navlag ? fsw_every - 1 : 0;
             int dist = trig - phase;                   // ticks to the next FSW tick of this lane
             if (dist <= 0) dist += fsw_every;
-#if !(defined(BSK_ABLATE) && BSK_ABLATE == 3)   // 3: timing only, no FSW chain
+#if !(defined(BSK_ABLATE) && (BSK_ABLATE == 3 || BSK_ABLATE == 6))   // 3: timing only, no FSW chain; 6: dynamics path only
             const bool anyz = navlag && __builtin_amdgcn_ballot_w64(z0) != 0;
             if (z0 || (!anyz && phase == trig)) {
                 State<NRW> nav = x;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
             z0 = false;
 #endif
             m = min(m, dist);
-            if constexpr (POWER) m = min(m, PEN_SLOTS);   // the power system's per-wave tick record holds PEN_SLOTS ticks
+            if constexpr (POWER) m = min(m, PEN_CHUNK);
             // The DPP-broadcast harmonics need every lane active inside the RK4 loop, so the trip count is
             // made wave-uniform: envs of one wave that sit at different FSW phases (after a masked reset)
             // advance together to the nearest FSW tick of any of them.
@@ -306,10 +306,10 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
             if (phase >= fsw_every) phase -= fsw_every;
         }
         if constexpr (POWER && NRW == 0) {
-            m = min(m, PEN_SLOTS);
+            m = min(m, PEN_CHUNK);
             if constexpr (FULL) m = wave_min_uniform(m);
         }
-#if !(defined(BSK_ABLATE) && BSK_ABLATE == 4)   // 4: timing only, no drain / battery replay
+#if !(defined(BSK_ABLATE) && (BSK_ABLATE == 4 || BSK_ABLATE == 6))   // 4: timing only, no drain / battery replay
         if constexpr (POWER) {
             // the tick record is flushed (queue drained cooperatively, battery replayed) when some lane's would overflow
             if (__builtin_amdgcn_ballot_w64(np + m > PEN_SLOTS) != 0) {
@@ -348,12 +348,30 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
                 }
             }
             if constexpr (FULL) {
+#ifndef BSK_DRAG_TEMPLATE
+#define BSK_DRAG_TEMPLATE 1
+#endif
+#if BSK_DRAG_TEMPLATE
+                // the drag switch picks the instantiation too: each integrator stage is then one branch-free region
+                if (BSK_LIKELY(!ev.thr_on)) {
+                    if (BSK_LIKELY(ev.drag_on)) rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT, false, 1>(c, wv, x, u, lext, (double)tick * c.h, ev, accp);
+                    else rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT, false, 2>(c, wv, x, u, lext, (double)tick * c.h, ev, accp);
+                } else rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT, true, 0>(c, wv, x, u, lext, (double)tick * c.h, ev, accp);
+#else
                 if (BSK_LIKELY(!ev.thr_on)) rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT, false>(c, wv, x, u, lext, (double)tick * c.h, ev, accp);
                 else rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT, true>(c, wv, x, u, lext, (double)tick * c.h, ev, accp);
+#endif
             } else {
                 rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT, false>(c, wv, x, u, lext, (double)tick * c.h, ev, accp);
             }
+#if defined(BSK_ABLATE) && BSK_ABLATE == 6
+            if constexpr (POWER) {   // what the dynamics wave of a two-wave design would do instead: hand (r, sigma) over
+                L->s[t][lane] = x.r.x; L->s[(t + 1) % PEN_SLOTS][lane] = x.r.y; L->s[(t + 2) % PEN_SLOTS][lane] = x.r.z;
+                L->sun[0][lane] = x.s.x; L->sun[1][lane] = x.s.y; L->sun[2][lane] = x.s.z;
+            }
+#else
             if constexpr (POWER) power_tick<FULL>(a.power, sg, x.r, x.s, L, np + t, lane, kt.c);
+#endif
             // after a chunk's first step the new commands act; plain moves, no-ops on every later step (measured
             // against a conditional latch and against splitting the chunk: profiles/r02/fsw_timing_cost.txt)
             if constexpr (NRW > 0) latch();
@@ -370,7 +388,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
         np += m;
         if constexpr (NRW > 0) latch();        // the t = 0 chunk has no step
     }
-#if !(defined(BSK_ABLATE) && BSK_ABLATE == 4)
+#if !(defined(BSK_ABLATE) && (BSK_ABLATE == 4 || BSK_ABLATE == 6))
     if constexpr (POWER) {
         if (__builtin_amdgcn_ballot_w64(np > 0) != 0) power_flush(a.power, L, np, lane, c.h, charge, shadow);
     }

@@ -317,8 +317,11 @@ class LeoPowerAttVecEnv(_Base):
             if tv["ext"] is None:
                 tv["ext"] = torch.cuda.ExternalStream(tv["stream"], device=tv["device"])
             tv["ext"].wait_stream(cur)                 # the kernel reads `actions` after their producer
-            actions.record_stream(tv["ext"])
-        self._dev_actions = actions                    # alive until the next step replaces it
+        # `actions` stays referenced until the next step replaces it: by then the caller's stream has been ordered after
+        # the kernel that read it (wait below), so the caching allocator may hand the block out again.  (No
+        # record_stream on the handle's stream: the allocator would record an event on it when the tensor dies, possibly
+        # after close() has destroyed that stream.)
+        self._dev_actions = actions
         self.propagator.step_device(actions.data_ptr(), self.substeps)
         if not same:
             cur.wait_stream(tv["ext"])                 # consumers on the caller's stream run after the kernel
@@ -329,6 +332,8 @@ class LeoPowerAttVecEnv(_Base):
         return tv["obs_n51"], tv["reward"], tv["reason"].ne(0), info
 
     def close(self):
+        self._tviews = None            # torch views alias device buffers the propagator is about to free
+        self._dev_actions = None
         self.propagator.close()
 
     def _n_indexed(self, indices):

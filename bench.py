@@ -458,9 +458,12 @@ def main():
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(self_launch(a.gpus, argv))
 
+    import faulthandler
+
     import numpy as np
     import torch
 
+    faulthandler.enable()     # a native fault leaves a Python traceback on stderr instead of a bare signal
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
