@@ -488,13 +488,38 @@ __device__ __forceinline__ double get_k(double tab) {                           
 // wheel geometry through the broadcast table (rows A and B of KTab): the same operations in the same order per
 // accumulator as WheelV, issued wheel-interleaved so that no DPP FMA follows the instruction that produced one of
 // its operands (the compiler pads that distance with s_nop, and every s_nop costs a one-wave SIMD an issue slot)
-template <int NRW>
-struct WheelDpp {
-    double ta, tb, td;
 #ifndef BSK_FOLD_JS
 #define BSK_FOLD_JS 1
 #endif
-#if BSK_FOLD_JS
+// FOLD (the full-scenario levels): the wheel inertia folded into the table.  The LDS-scratch level keeps the unfolded
+// form, whose operations per accumulator are those of WheelV - it is held bit-identical to the register kernel.
+template <int NRW, bool FOLD>
+struct WheelDpp;
+template <int NRW>
+struct WheelDppBase {
+    double ta, tb, td;
+    __device__ __forceinline__ void tail(V3 dw, const double* base, double* Om) const {
+#pragma unroll
+        for (int i = 0; i < NRW; ++i) Om[i] = base[i];
+        if constexpr (NRW > 0) Om[0] = fmac_k_neg<KA_G + 2>(Om[0], ta, dw.z);
+        if constexpr (NRW > 1) Om[1] = fmac_k_neg<KA_G + 5>(Om[1], ta, dw.z);
+        if constexpr (NRW > 2) Om[2] = fmac_k_neg<KA_G + 8>(Om[2], ta, dw.z);
+        if constexpr (NRW > 3) Om[3] = fmac_k_neg<KA_G + 11>(Om[3], ta, dw.z);
+        if constexpr (NRW > 0) Om[0] = fmac_k_neg<KA_G + 1>(Om[0], ta, dw.y);
+        if constexpr (NRW > 1) Om[1] = fmac_k_neg<KA_G + 4>(Om[1], ta, dw.y);
+        if constexpr (NRW > 2) Om[2] = fmac_k_neg<KA_G + 7>(Om[2], ta, dw.y);
+        if constexpr (NRW > 3) Om[3] = fmac_k_neg<KA_G + 10>(Om[3], ta, dw.y);
+        if constexpr (NRW > 0) Om[0] = fmac_k_neg<KA_G + 0>(Om[0], ta, dw.x);
+        if constexpr (NRW > 1) Om[1] = fmac_k_neg<KA_G + 3>(Om[1], ta, dw.x);
+        if constexpr (NRW > 2) Om[2] = fmac_k_neg<KA_G + 6>(Om[2], ta, dw.x);
+        if constexpr (NRW > 3) Om[3] = fmac_k_neg<KA_G + 9>(Om[3], ta, dw.x);
+    }
+};
+template <int NRW>
+struct WheelDpp<NRW, true> : WheelDppBase<NRW> {
+    using WheelDppBase<NRW>::ta;
+    using WheelDppBase<NRW>::tb;
+    using WheelDppBase<NRW>::td;
     // The wheel inertia folded into the table (row D: Js_i g_i and dt / Js_i): the momentum sum reads the wheel speeds
     // directly and the end-of-step base is one DPP FMA per wheel - no Js Om_i / tq_i / Js_i intermediates, each of
     // which cost a zero-initialising move and a one-term chain (16 issue slots per step less)
@@ -519,7 +544,12 @@ struct WheelDpp {
         if constexpr (NRW > 2) base[2] = fmac_k<KD_HIJS + 2>(base[2], td, tq[2]);
         if constexpr (NRW > 3) base[3] = fmac_k<KD_HIJS + 3>(base[3], td, tq[3]);
     }
-#else
+};
+template <int NRW>
+struct WheelDpp<NRW, false> : WheelDppBase<NRW> {
+    using WheelDppBase<NRW>::ta;
+    using WheelDppBase<NRW>::tb;
+    using WheelDppBase<NRW>::td;
     __device__ __forceinline__ void bases(double h, const double* tq, const double* tqj, const double* Om, double* base) const {
 #pragma unroll
         for (int i = 0; i < NRW; ++i) base[i] = fma(h, tqj[i], Om[i]);
@@ -547,23 +577,6 @@ struct WheelDpp {
         if constexpr (NRW > 1) wheel(std::integral_constant<int, 1>{});
         if constexpr (NRW > 2) wheel(std::integral_constant<int, 2>{});
         if constexpr (NRW > 3) wheel(std::integral_constant<int, 3>{});
-    }
-#endif
-    __device__ __forceinline__ void tail(V3 dw, const double* base, double* Om) const {
-#pragma unroll
-        for (int i = 0; i < NRW; ++i) Om[i] = base[i];
-        if constexpr (NRW > 0) Om[0] = fmac_k_neg<KA_G + 2>(Om[0], ta, dw.z);
-        if constexpr (NRW > 1) Om[1] = fmac_k_neg<KA_G + 5>(Om[1], ta, dw.z);
-        if constexpr (NRW > 2) Om[2] = fmac_k_neg<KA_G + 8>(Om[2], ta, dw.z);
-        if constexpr (NRW > 3) Om[3] = fmac_k_neg<KA_G + 11>(Om[3], ta, dw.z);
-        if constexpr (NRW > 0) Om[0] = fmac_k_neg<KA_G + 1>(Om[0], ta, dw.y);
-        if constexpr (NRW > 1) Om[1] = fmac_k_neg<KA_G + 4>(Om[1], ta, dw.y);
-        if constexpr (NRW > 2) Om[2] = fmac_k_neg<KA_G + 7>(Om[2], ta, dw.y);
-        if constexpr (NRW > 3) Om[3] = fmac_k_neg<KA_G + 10>(Om[3], ta, dw.y);
-        if constexpr (NRW > 0) Om[0] = fmac_k_neg<KA_G + 0>(Om[0], ta, dw.x);
-        if constexpr (NRW > 1) Om[1] = fmac_k_neg<KA_G + 3>(Om[1], ta, dw.x);
-        if constexpr (NRW > 2) Om[2] = fmac_k_neg<KA_G + 6>(Om[2], ta, dw.x);
-        if constexpr (NRW > 3) Om[3] = fmac_k_neg<KA_G + 9>(Om[3], ta, dw.x);
     }
 };
 

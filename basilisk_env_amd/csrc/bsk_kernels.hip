@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
 #endif
     // (the LDS-scratch level is after a third wave per SIMD: it takes the 36 registers of the wheel geometry too)
     constexpr bool WDPP = FULL || (FEAT == FEAT_LDSS && NRW > 0) || (BSK_BARE_DPP && FEAT == FEAT_BARE && NRW > 0);
-    std::conditional_t<WDPP, WheelDpp<NRW>, WheelV<NRW>> wv;
+    std::conditional_t<WDPP, WheelDpp<NRW, (FULL && BSK_FOLD_JS != 0)>, WheelV<NRW>> wv;
 #if defined(BSK_ABLATE) && BSK_ABLATE == 2
     const int substeps_eff = 0;   // loads + epilogue stores, no RK4 / FSW
 #else

@@ -338,9 +338,10 @@ def _with_degree(cfg, degree):
 
 
 def gather_legs(prop, dist, torch, world, n):
-    """The one exchange step of the path, three ways: RCCL gather of the observation shards to
-    rank 0, RCCL all-gather, and every GPU copying its own shard to pinned host memory.  Max over ranks, ms."""
-    from basilisk_env_amd.parallel import gather_observations, local_obs_tensor
+    """The one exchange step of the path, through torch.distributed three ways: RCCL gather of the
+    observation shards to rank 0, RCCL all-gather, and every GPU copying its own shard to pinned host memory.  The shard
+    sizes are exchanged once, outside the clocked region (ObsGatherer).  Max over ranks, ms."""
+    from basilisk_env_amd.parallel import ObsGatherer, local_obs_tensor
 
     def clock(fn, reps=5):
         fn()
@@ -357,15 +358,54 @@ def gather_legs(prop, dist, torch, world, n):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    g = ObsGatherer(prop, dist)
     local = local_obs_tensor(prop)
     host = torch.empty(tuple(local.shape), dtype=local.dtype, pin_memory=True)
     out = {"shard_bytes": int(local.numel() * 8), "total_bytes": int(local.numel() * 8 * world),
-           "gather_to_rank0_ms": clock(lambda: gather_observations(prop, dist, dst=0)),
-           "all_gather_ms": clock(lambda: gather_observations(prop, dist)),
+           "gather_to_rank0_ms": clock(lambda: g.gather(0)),
+           "all_gather_ms": clock(g.all_gather),
            "direct_d2h_per_gpu_ms": clock(lambda: host.copy_(local_obs_tensor(prop), non_blocking=True))}
-    full = gather_observations(prop, dist)
+    full = g.all_gather()
     assert tuple(full.shape) == (world, 5, n)
+    out["_clock"] = clock
     return out
+
+
+def direct_rccl_leg(prop, dist, torch, world, clock):
+    """The same gather through librccl directly (basilisk_env_amd/rccl.py): grouped ncclSend / ncclRecv from the library's
+    SoA rows into rank 0's [5][n_total] buffer on the propagator handle's own stream - no torch tensor, no staging copy.
+    Checked against the torch leg on rank 0."""
+    from basilisk_env_amd.parallel import DirectRcclGather, ObsGatherer, concat_shards
+    d = DirectRcclGather(prop, dist, root=0)
+    try:
+        ms = clock(d.enqueue)
+        ref = ObsGatherer(prop, dist).gather(0)
+        ok = None
+        if dist.get_rank() == 0:
+            got = torch.as_tensor(d.result_view(), device="cuda")
+            ok = bool(torch.equal(got, concat_shards(ref)))
+        return {"direct_rccl_gather_to_rank0_ms": ms, "direct_rccl_matches_torch_gather": ok,
+                "direct_rccl_form": "grouped ncclSend/ncclRecv, 5 rows per rank straight into [5][n_total], handle stream"}
+    finally:
+        d.close()
+
+
+def with_deadline(seconds, on_timeout, fn):
+    """Run fn(); if it has not returned after ``seconds`` call on_timeout() from a watchdog thread (which ends the
+    process): an auxiliary collective leg must never take the whole bench line with it."""
+    import threading
+    done = threading.Event()
+
+    def watch():
+        if not done.wait(seconds):
+            on_timeout()
+
+    t = threading.Thread(target=watch, daemon=True)
+    t.start()
+    try:
+        return fn()
+    finally:
+        done.set()
 
 
 def profile_key(a, sh):
@@ -586,8 +626,10 @@ def main():
     if sh:
         out["sh"] = {"degree": 70, "field_evals_per_s": n * world * a.steps * a.substeps * 4 / el}
 
+    clock = None
     if dist is not None:
         out["gather"] = gather_legs(prop, dist, torch, world, n)
+        clock = out["gather"].pop("_clock")
         out["gather_ms"] = out["gather"]["all_gather_ms"]
 
     extra = {}
@@ -649,6 +691,7 @@ def main():
                             "env_steps_per_s": n3 * world * 500 / el4, "ms_per_step": el4 / 500 * 1e3,
                             "roofline": hbm_roofline(n3, km4 * 1e-3, p3.kernel_info(), None, None, 32),
                             "gather": gather_legs(p3, dist, torch, world, n3)}
+        extra["config3"]["gather"].pop("_clock", None)
         p3.close()
         # strong-scaling points of the literal target (65 536 spacecraft in total), K = 1 and the reference's K = 1 800
         ns = max(1, 65536 // world)
@@ -679,6 +722,18 @@ def main():
             c5 = default_config(n_rw=n_rw, gravity_model=GRAV_SH)
             c5.sh_degree = 70
             extra["sh70"]["cpu_baseline"] = cpu_baseline(c5, n_rw, 1, budget_s=5.0, n=256, sh=70)
+    if dist is not None and not rehearsal and os.environ.get("BSKGPU_DIRECT_RCCL", "1") != "0":
+        # last, and under a watchdog: if the direct-RCCL leg (a second communicator, never run on more than one rank
+        # before the driver's 8-GPU node) hangs, every rank gives up after 90 s and rank 0 still prints the line
+        def give_up():
+            out["gather"]["direct_rccl"] = "timeout after 90 s: leg abandoned"
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        try:
+            out["gather"].update(with_deadline(90.0, give_up, lambda: direct_rccl_leg(prop, dist, torch, world, clock)))
+        except Exception as e:
+            out["gather"]["direct_rccl_error"] = repr(e)
     prop.close()
     if rank == 0:
         print(json.dumps(out), flush=True)

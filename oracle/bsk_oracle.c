@@ -48,6 +48,12 @@ static void m33v3(const double m[9], const double v[3], double o[3]) {
     for (int i = 0; i < 3; ++i) t[i] = m[3 * i] * v[0] + m[3 * i + 1] * v[1] + m[3 * i + 2] * v[2];
     v3copy(t, o);
 }
+/* Engine behaviours this restatement had to DECIDE (each [BSK-recall]).  The defaults (0) are what the
+   kernels implement; the alternatives exist so that every decision's weight on a trajectory is a measured number
+   (tests/test_oracle_decisions.py) and can be flipped the day a Basilisk build settles it (orc_set_decision). */
+static int g_friction_per_stage = 0;  /* 1: Coulomb friction re-evaluated from the stage state inside the equations of motion */
+static int g_sun_per_tick = 0;        /* 1: Sun position advanced every dyn tick instead of held over the env step (SPICE task rate) */
+static int g_t0_real_messages = 0;    /* 1: the FSW tick at t = 0 (nav_lag) reads the initial state instead of unwritten (zero) messages */
 static int m33inv(const double m[9], double o[9]) {
     double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
     double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
@@ -348,11 +354,14 @@ static void rk4_step(orc_ctx* ctx, double x[NX], const double ucmd[BSK_MAX_RW], 
     eom(ctx, x, u, lext, t, sun, rho, th, k);
     for (int i = 0; i < NX; ++i) { acc[i] = x[i] + h / 6.0 * k[i]; xt[i] = x[i] + 0.5 * h * k[i]; }
     if (th) th->e2 = e2 + 1;
+    if (g_friction_per_stage) wheel_torque(ctx, xt, ucmd, u);
     eom(ctx, xt, u, lext, t + 0.5 * h, sun, rho, th, k);
     for (int i = 0; i < NX; ++i) { acc[i] += h / 3.0 * k[i]; xt[i] = x[i] + 0.5 * h * k[i]; }
+    if (g_friction_per_stage) wheel_torque(ctx, xt, ucmd, u);
     eom(ctx, xt, u, lext, t + 0.5 * h, sun, rho, th, k);
     for (int i = 0; i < NX; ++i) { acc[i] += h / 3.0 * k[i]; xt[i] = x[i] + h * k[i]; }
     if (th) th->e2 = e2 + 2;
+    if (g_friction_per_stage) wheel_torque(ctx, xt, ucmd, u);
     eom(ctx, xt, u, lext, t + h, sun, rho, th, k);
     for (int i = 0; i < NX; ++i) x[i] = acc[i] + h / 6.0 * k[i];
     double s2 = v3dot(x + 6, x + 6);
@@ -511,6 +520,34 @@ static double percent_shadow(double req, const double r_HB[3], const double s_BP
     return 1.0;
 }
 
+/* The same fraction exactly as the eclipse module writes it [BSK-recall: computePercentShadow], in plain fp64:
+   a = safeAsin(R_sun/|r_HB|), b = safeAsin(R_p/|s_BP|), c = safeAcos(-s_BP.r_HB/(|s_BP||r_HB|)),
+   area = a^2 acos(x/a) + b^2 acos((c - x)/b) - c y.  Selected with orc_set_penumbra_form(1): what the reference engine
+   itself would report on a penumbra tick, ill-conditioning included (tests/test_oracle_power.py records how far that
+   sits from the conditioned form above). */
+static double safe_acos(double x) { return x >= 1.0 ? 0.0 : (x <= -1.0 ? M_PI : acos(x)); }
+static double percent_shadow_as_written(double req, const double r_HB[3], const double s_BP[3]) {
+    const double REQ_SUN = 695000.0e3;
+    double shadowFraction = 1.0;
+    double normR_HB = v3norm(r_HB), normS_BP = v3norm(s_BP);
+    double a = safe_asin(REQ_SUN / normR_HB);
+    double b = safe_asin(req / normS_BP);
+    double c = safe_acos(-v3dot(s_BP, r_HB) / (normS_BP * normR_HB));
+    if (c < b - a) {
+        shadowFraction = 0.0;
+    } else if (c < a - b) {
+        double areaSun = M_PI * a * a, areaBody = M_PI * b * b;
+        shadowFraction = 1 - (areaSun - areaBody) / (M_PI * a * a);
+    } else if (c < a + b) {
+        double x = (c * c + a * a - b * b) / (2 * c);
+        double y = sqrt(a * a - x * x);
+        double area = a * a * safe_acos(x / a) + b * b * safe_acos((c - x) / b) - c * y;
+        shadowFraction = 1 - area / (M_PI * a * a);
+    }
+    return shadowFraction;
+}
+static int g_penumbra_form = 0;   /* 0: conditioned form (default, what the kernels are held to); 1: as written, fp64 */
+
 static double shadow_factor(const bsk_config* c, const double r[3], const double sun[3]) {
     /* Earth is the zero base (…Simulator.py:225): s_BP = r, r_HP = sun, r_HB = sun - r */
     const double REQ_SUN = 695000.0e3;
@@ -521,7 +558,8 @@ static double shadow_factor(const bsk_config* c, const double r[3], const double
     double s = v3norm(r), s0 = -v3dot(r, sun) / nhp;
     double c1 = s0 + c->req / sin(f1), c2 = s0 - c->req / sin(f2);
     double l = sqrt(s * s - s0 * s0), l1 = c1 * tan(f1), l2 = c2 * tan(f2);
-    if (fabs(l) < fabs(l2) || fabs(l) < fabs(l1)) return percent_shadow(c->req, r_HB, r);
+    if (fabs(l) < fabs(l2) || fabs(l) < fabs(l1))
+        return g_penumbra_form ? percent_shadow_as_written(c->req, r_HB, r) : percent_shadow(c->req, r_HB, r);
     return 1.0;
 }
 
@@ -639,6 +677,7 @@ int orc_step(const bsk_config* c, int n, double* state, int32_t* steps, int32_t*
         const int navlag = c->nav_lag && nrw > 0;
         if (navlag && tick == 0) {
             double nav0[NX] = {0};
+            if (g_t0_real_messages) for (int f = 0; f < NX; ++f) nav0[f] = x[f];
             FSW_TICK(nav0);
             LATCH();
         }
@@ -651,6 +690,8 @@ int orc_step(const bsk_config* c, int n, double* state, int32_t* steps, int32_t*
                 th.e2 = 2 * (tick - thr_t0);
                 for (int i = 0; i < c->n_thr; ++i) if (thr_lim[i] > 0.0 && (double)th.e2 <= thr_lim[i]) th.active = 1;
             }
+            if (g_sun_per_tick)
+                for (int k = 0; k < 3; ++k) sun[k] = (c->sun_r0[k] + c->sun_v[k] * sim_time0) + c->sun_v[k] * (tick * c->dt);
             rk4_step(&ctx, x, u, lext, t, c->dt, sun, desat ? &th : 0);
             ++tick;
             if (navlag) LATCH();
@@ -767,3 +808,13 @@ void orc_mrp2c(const double q[3], double c[9]) { mrp2c(q, c); }
 void orc_c2mrp(const double c[9], double q[3]) { c2mrp(c, q); }
 void orc_submrp(const double a[3], const double b[3], double q[3]) { submrp(a, b, q); }
 double orc_shadow(const bsk_config* c, const double r[3], const double sun[3]) { return shadow_factor(c, r, sun); }
+/* penumbra expression used by shadow_factor (and so by orc_step): 0 conditioned (default), 1 as Basilisk writes it */
+void orc_set_penumbra_form(int form) { g_penumbra_form = form ? 1 : 0; }
+int orc_get_penumbra_form(void) { return g_penumbra_form; }
+/* decision switches: 0 friction_per_stage, 1 sun_per_tick, 2 t0_real_messages; value 0 / 1 */
+int orc_set_decision(int which, int value) {
+    int* g = which == 0 ? &g_friction_per_stage : which == 1 ? &g_sun_per_tick : which == 2 ? &g_t0_real_messages : 0;
+    if (!g) return -1;
+    *g = value ? 1 : 0;
+    return 0;
+}

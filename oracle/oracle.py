@@ -141,7 +141,26 @@ def submrp(a, b):
     return q
 
 
-def shadow(cfg, r, sun):
+def shadow(cfg, r, sun, omp=False):
     r = np.ascontiguousarray(r, dtype=np.float64)
     sun = np.ascontiguousarray(sun, dtype=np.float64)
-    return load().orc_shadow(C.byref(cfg), _p(r), _p(sun))
+    return load(omp).orc_shadow(C.byref(cfg), _p(r), _p(sun))
+
+
+DECISIONS = {"friction_per_stage": 0, "sun_per_tick": 1, "t0_real_messages": 2}
+
+
+def set_decision(name, value):
+    """Flip one of the engine behaviours the restatement had to decide (all default 0 = what the
+    kernels implement): 'friction_per_stage', 'sun_per_tick', 't0_real_messages'."""
+    for omp in (False, True):
+        if load(omp).orc_set_decision(DECISIONS[name], int(value)) != 0:
+            raise ValueError(name)
+
+
+def set_penumbra_form(form):
+    """0 (default): the conditioned lens-area form the kernels are held to; 1: the expression exactly as the
+    reference engine's eclipse module writes it, in fp64.  Applies to shadow() and step() of both
+    oracle libraries."""
+    for omp in (False, True):
+        load(omp).orc_set_penumbra_form(int(form))

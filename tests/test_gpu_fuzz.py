@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 REGRESSION_SEEDS = [978]
 
 
-@pytest.mark.parametrize("seed", list(range(int(os.environ.get("BSK_FUZZ_SEEDS", "24")))) + REGRESSION_SEEDS)   # BSK_FUZZ_SEEDS=N for a longer hunt
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("BSK_FUZZ_SEEDS", "64")))) + REGRESSION_SEEDS)   # BSK_FUZZ_SEEDS=N for a longer hunt
 def test_random_configuration_matches_oracle(seed, monkeypatch):
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 200, 257, 511, 600]))

@@ -13,7 +13,7 @@ from basilisk_env_amd.envs import LeoPowerAttVecEnv
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("BSK_FUZZ_SEEDS", "6"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BSK_FUZZ_SEEDS", "16"))))
 def test_vec_env_with_device_reset_matches_oracle_backend(seed):
     rng = np.random.default_rng(90000 + seed)
     n = int(rng.choice([1, 64, 130, 500, 1000]))
@@ -47,7 +47,7 @@ def test_vec_env_with_device_reset_matches_oracle_backend(seed):
     c.close()
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("BSK_FUZZ_SEEDS", "4"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BSK_FUZZ_SEEDS", "8"))))
 def test_single_env_episodes_match_oracle_backend(seed):
     """The reference's own usage: ONE environment, 180 s steps, random actions, episodes restarted with reset() and
     replayed with reset_init() - the product env on the HIP propagator against the same class on the oracle stand-in."""

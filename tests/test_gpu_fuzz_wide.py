@@ -16,7 +16,7 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("BSK_FUZZ_SEEDS", "16"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BSK_FUZZ_SEEDS", "32"))))
 def test_random_variant_matches_oracle(seed, monkeypatch):
     rng = np.random.default_rng(50000 + seed)
     n = int(rng.choice([1, 64, 65, 200, 257, 1000, 1025]))

@@ -66,6 +66,8 @@ def test_bench_collective_legs_on_rccl_single_rank(tmp_path):
     g = d["gather"]
     assert g["gather_to_rank0_ms"] > 0 and g["all_gather_ms"] > 0 and g["direct_d2h_per_gpu_ms"] > 0
     assert g["shard_bytes"] == 5 * 65536 * 8
+    # the direct librccl leg (its own communicator from ncclCommInitRank, gather on the handle's stream) ran and agrees
+    assert g.get("direct_rccl_matches_torch_gather") is True and g["direct_rccl_gather_to_rank0_ms"] > 0, g
     x = d["extra"]
     assert "1048576" not in x["config3"]["workload"] and "131072 per GPU" in x["config3"]["workload"]
     assert x["config3"]["gather"]["shard_bytes"] == 5 * 131072 * 8
