@@ -64,7 +64,7 @@ class BskConfig(C.Structure):
 
 EXPORTS = [
     "bsk_default_config", "bsk_create", "bsk_destroy", "bsk_set_gravity_sh", "bsk_reset", "bsk_step",
-    "bsk_step_device", "bsk_get_obs", "bsk_get_obs_device", "bsk_get_stream", "bsk_get_terminal_obs_device", "bsk_get_state_device", "bsk_get_batch_stats", "bsk_n_fields",
+    "bsk_step_device", "bsk_get_obs", "bsk_get_obs_device", "bsk_get_obs_state", "bsk_get_stream", "bsk_get_terminal_obs_device", "bsk_get_state_device", "bsk_get_batch_stats", "bsk_n_fields",
     "bsk_get_state", "bsk_set_state", "bsk_get_counters", "bsk_set_counters", "bsk_set_ic_pool", "bsk_sample_ic_pool", "bsk_reset_from_pool", "bsk_get_ic_pool", "bsk_get_terminal_obs", "bsk_set_env_base", "bsk_set_sim_time", "bsk_sync",
     "bsk_profile_begin", "bsk_profile_set_stride", "bsk_profile_end", "bsk_profile_end_samples", "bsk_kernel_info", "bsk_last_error", "bsk_version",
 ]
@@ -127,6 +127,7 @@ def load():
     lib.bsk_step_device.argtypes = [vp, vp, C.c_int]
     lib.bsk_get_obs.argtypes = [vp, vp, vp, vp, vp]
     lib.bsk_get_obs_device.argtypes = [vp, P(vp), P(vp), P(vp), P(vp), P(C.c_int64)]
+    lib.bsk_get_obs_state.argtypes = [vp, vp, vp, vp, vp]
     lib.bsk_get_stream.argtypes = [vp, P(vp)]
     lib.bsk_get_terminal_obs_device.argtypes = [vp, P(vp), P(vp)]
     lib.bsk_get_state_device.argtypes = [vp, P(vp), P(C.c_int64)]

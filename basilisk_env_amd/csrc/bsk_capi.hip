@@ -797,6 +797,18 @@ int bsk_get_obs(bsk_handle* h, double* obs, double* reward, uint8_t* done, uint8
     return BSK_OK;
 }
 
+int bsk_get_obs_state(bsk_handle* h, double* obs, double* reward, uint8_t* done_reason, double* state) {
+    if (!h) return fail(BSK_EINVAL, "handle is NULL");
+    DeviceGuard guard(h->device);
+    const size_t row = (size_t)h->n * sizeof(double), pitch = (size_t)h->stride * sizeof(double);
+    if (obs) HIP_TRY(hipMemcpy2DAsync(obs, row, h->d_obs, pitch, row, 5, hipMemcpyDeviceToHost, h->stream));
+    if (reward) HIP_TRY(hipMemcpyAsync(reward, h->d_reward, row, hipMemcpyDeviceToHost, h->stream));
+    if (done_reason) HIP_TRY(hipMemcpyAsync(done_reason, h->d_reason, (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+    if (state) HIP_TRY(hipMemcpy2DAsync(state, row, h->d_state, pitch, row, h->nf, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return BSK_OK;
+}
+
 int bsk_get_obs_device(bsk_handle* h, double** d_obs, double** d_reward, uint64_t** d_done_mask, uint8_t** d_done_reason,
                        int64_t* stride) {
     if (!h) return fail(BSK_EINVAL, "handle is NULL");

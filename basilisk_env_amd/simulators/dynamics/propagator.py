@@ -170,6 +170,13 @@ class BatchedPropagator(object):
         check(self._lib.bsk_get_obs(self._handle(), obs.ctypes.data, rew.ctypes.data, done.ctypes.data, why.ctypes.data))
         return obs, rew, done.astype(bool), why
 
+    def get_obs_state(self):
+        """-> obs (5, N), state (n_fields, N) with one stream synchronisation (what the single-env mirror reads per step)."""
+        obs = np.empty((5, self.n_envs), dtype=np.float64)
+        st = np.empty((self.n_fields, self.n_envs), dtype=np.float64)
+        check(self._lib.bsk_get_obs_state(self._handle(), obs.ctypes.data, None, None, st.ctypes.data))
+        return obs, st
+
     def batch_stats(self):
         s, d = C.c_double(), C.c_int64()
         check(self._lib.bsk_get_batch_stats(self._handle(), C.byref(s), C.byref(d)))

@@ -199,8 +199,11 @@ class LEOPowerAttitudeSimulator(object):
         self.sim_over = False
         self.simTime += self.step_duration
         self.propagator.step(np.array([int(self.modeRequest)], dtype=np.int32), self.substeps)
-        dev_obs, _, _, _ = self.propagator.get_obs()
-        st = self.propagator.get_state()
+        if hasattr(self.propagator, "get_obs_state"):
+            dev_obs, st = self.propagator.get_obs_state()      # one synchronisation for both read-backs
+        else:
+            dev_obs, _, _, _ = self.propagator.get_obs()
+            st = self.propagator.get_state()
         omega = st[9:12, 0]
         wheels = st[12:12 + min(self.n_rw, 3), 0]  # the reference logs wheelSpeeds[0:3] (:606,614)
         charge = st[12 + self.n_rw + 7, 0]

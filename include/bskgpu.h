@@ -205,6 +205,10 @@ int bsk_step_device(bsk_handle* h, const int32_t* d_actions, int substeps);
 #define BSK_DONE_ORBIT 0x8
 int bsk_get_obs(bsk_handle* h, double* obs, double* reward, uint8_t* done, uint8_t* done_reason);
 
+/* bsk_get_obs + bsk_get_state behind ONE stream synchronisation (the single-env mirror reads both after every step:
+ * …Simulator.py:598-619 pulls the same quantities from the message logs).  Any pointer may be NULL. */
+int bsk_get_obs_state(bsk_handle* h, double* obs, double* reward, uint8_t* done_reason, double* state);
+
 /* Device pointers of the output buffers (for the RCCL gather / zero-copy hand-off).
  * obs stride (envs per field) is returned in *stride; done_mask is uint64[ceil(n/64)]. */
 int bsk_get_obs_device(bsk_handle* h, double** d_obs, double** d_reward, uint64_t** d_done_mask,

@@ -10,14 +10,16 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from basilisk_env_amd._lib import FLAG_DESAT, FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY, GRAV_PM  # noqa: E402
+from basilisk_env_amd._lib import FLAG_DESAT, FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY, GRAV_PM, GRAV_PM_J2  # noqa: E402
 from basilisk_env_amd.envs import leoPowerAttEnv  # noqa: E402
 from basilisk_env_amd.simulators.dynamics import BatchedPropagator, default_config  # noqa: E402
 from basilisk_env_amd.simulators.initial_conditions.batch import sample_ic_batch  # noqa: E402
 
-out = {"env_step_ms": {}}
-for n in (1, 64, 1024, 8192, 65536):
-    cfg = default_config(3, GRAV_PM)
+# LATENCY_GRAV=j2: J2 gravity (the kernels the A/B variant libraries carry); LATENCY_ONLY_STEP=1: the batch table only
+GRAV = GRAV_PM_J2 if os.environ.get("LATENCY_GRAV") == "j2" else GRAV_PM
+out = {"env_step_ms": {}, "gravity": "j2" if GRAV == GRAV_PM_J2 else "pm", "lib": os.environ.get("BSKGPU_LIB", "libbskgpu.so")}
+for n in (1, 2, 63, 64, 1024, 4096, 8192, 65536):
+    cfg = default_config(3, GRAV)
     cfg.flags |= FLAG_POWER | FLAG_SUN_THIRD_BODY | FLAG_DRAG | FLAG_DESAT
     p = BatchedPropagator(cfg, n)
     p.reset(sample_ic_batch(n, 3, seed=1))
@@ -32,6 +34,9 @@ for n in (1, 64, 1024, 8192, 65536):
         ts.append(time.perf_counter() - t0)
     out["env_step_ms"][n] = round(min(ts) * 1e3, 3)
     p.close()
+if os.environ.get("LATENCY_ONLY_STEP") == "1":
+    print(json.dumps(out))
+    sys.exit(0)
 env = leoPowerAttEnv()
 env.seed(1)
 t0 = time.perf_counter()

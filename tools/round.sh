@@ -2,7 +2,7 @@
 # One GPU-box pass of the round's evidence: GPU tests, bench lines, the 2-rank rehearsal of the self-launch path on
 # one card, kernel traces and counter passes.  Usage: tools/round.sh TAG   (outputs under gpurun_out/TAG/)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
@@ -19,7 +19,7 @@ cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-cpu-baseline --no-extra"
 prof() { tag=$1; shift; timeout -k 10 300 rocprofv3 "$@" > $O/$tag.log 2>&1 && echo $tag ok; }
 SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"
-prof kt_65k --kernel-trace --stats --output-format csv -d $O/kt_65k -- $B
+prof kt_65k --kernel-trace --stats --output-format csv -d $O/kt_65k -- $B --steps 40000 --warmup 4000
 prof fetch_65k --pmc FETCH_SIZE --output-format csv -d $O/fetch_65k -- $B --steps 50
 prof write_65k --pmc WRITE_SIZE --output-format csv -d $O/write_65k -- $B --steps 50
 prof sq_65k --pmc $SQ --output-format csv -d $O/sq_65k -- $B --steps 50
@@ -34,8 +34,16 @@ prof sq_k1800 --pmc $SQ --output-format csv -d $O/sq_k1800 -- $BK
 BF="$B --scenario full --substeps 1800 --steps 20 --warmup 10"
 prof kt_full_k1800 --kernel-trace --stats --output-format csv -d $O/kt_full_k1800 -- $BF
 prof sq_full_k1800 --pmc $SQ --output-format csv -d $O/sq_full_k1800 -- $BF
-BS="$B --gravity sh --steps 400 --warmup 100"
+BP="$B --scenario power --substeps 1800 --steps 20 --warmup 10"
+prof kt_power_k1800 --kernel-trace --stats --output-format csv -d $O/kt_power_k1800 -- $BP
+BS="$B --gravity sh --steps 1000 --warmup 300"
 prof kt_sh --kernel-trace --stats --output-format csv -d $O/kt_sh -- $BS
 prof sq_sh --pmc $SQ --output-format csv -d $O/sq_sh -- $BS
 cd $R
 python3 tools/prof_summary.py $O > $O/summary_latest.json 2>/dev/null && echo summary ok
+python3 tools/kernel_trace_summary.py $O $O > $O/kernel_trace.json && echo kernel_trace ok
+# A/B: the same commands without the profiler (their own stamped pass), beside the traces above
+for ab in "65k:--steps 40000 --warmup 4000" "full_k1800:--scenario full --substeps 1800 --steps 20 --warmup 10" "power_k1800:--scenario power --substeps 1800 --steps 20 --warmup 10" "k1800:--substeps 1800 --steps 20 --warmup 10" "sh:--gravity sh --steps 1000 --warmup 300" "4m:--envs 4194304 --steps 20 --warmup 3"; do
+  python bench.py --no-cpu-baseline --no-extra ${ab#*:} > $O/ab_${ab%%:*}_plain.json 2>> $O/bench.err
+done
+python3 tools/latency.py > $O/latency.json 2>> $O/bench.err && echo latency ok
