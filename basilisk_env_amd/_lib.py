@@ -66,7 +66,7 @@ EXPORTS = [
     "bsk_default_config", "bsk_create", "bsk_destroy", "bsk_set_gravity_sh", "bsk_reset", "bsk_step",
     "bsk_step_device", "bsk_get_obs", "bsk_get_obs_device", "bsk_get_obs_state", "bsk_get_stream", "bsk_get_terminal_obs_device", "bsk_get_state_device", "bsk_get_batch_stats", "bsk_n_fields",
     "bsk_get_state", "bsk_set_state", "bsk_get_counters", "bsk_set_counters", "bsk_set_ic_pool", "bsk_sample_ic_pool", "bsk_reset_from_pool", "bsk_get_ic_pool", "bsk_get_terminal_obs", "bsk_set_env_base", "bsk_set_sim_time", "bsk_sync",
-    "bsk_profile_begin", "bsk_profile_set_stride", "bsk_profile_end", "bsk_profile_end_samples", "bsk_kernel_info", "bsk_last_error", "bsk_version",
+    "bsk_profile_begin", "bsk_profile_set_stride", "bsk_profile_end", "bsk_profile_end_samples", "bsk_calibrate_fp64", "bsk_kernel_info", "bsk_last_error", "bsk_version",
 ]
 
 _LIB = None
@@ -149,9 +149,17 @@ def load():
     lib.bsk_profile_set_stride.argtypes = [vp, C.c_int]
     lib.bsk_profile_end.argtypes = [vp, P(C.c_double), P(C.c_int)]
     lib.bsk_profile_end_samples.argtypes = [vp, P(C.c_double), P(C.c_int), vp, C.c_int]
+    lib.bsk_calibrate_fp64.argtypes = [C.c_int, C.c_int, C.c_int, P(C.c_double), P(C.c_double)]
     lib.bsk_kernel_info.argtypes = [vp, C.c_char_p, C.c_int, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int)]
     _LIB = lib
     return lib
+
+
+def calibrate_fp64(device=0, waves_per_simd=2, repeats=5):
+    """-> (TFLOP/s, ns per FMA wave-instruction and SIMD) this device sustains on independent fp64 FMA chains."""
+    tf, ns = C.c_double(), C.c_double()
+    check(load().bsk_calibrate_fp64(int(device), int(waves_per_simd), int(repeats), C.byref(tf), C.byref(ns)))
+    return tf.value, ns.value
 
 
 def check(rc):

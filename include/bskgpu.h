@@ -288,6 +288,12 @@ int bsk_profile_end(bsk_handle* h, double* mean_kernel_ms, int* n_launches);
  * into samples_ms (so that a caller can report median / min / max beside the mean). */
 int bsk_profile_end_samples(bsk_handle* h, double* mean_kernel_ms, int* n_launches, float* samples_ms, int cap);
 
+/* Measurement aid: the fp64 FMA rate device `device_id` sustains with `waves_per_simd` waves of independent v_fma_f64 chains per
+ * SIMD (median of `repeats` timed launches of ~2-4 ms after three warm-up launches): TFLOP/s of the whole device and
+ * nanoseconds per FMA wave-instruction and SIMD.  bench.py prints it beside its fp64 rooflines, whose `peak` stays the nominal
+ * 78.6 TFLOP/s. */
+int bsk_calibrate_fp64(int device_id, int waves_per_simd, int repeats, double* tflops, double* ns_per_fma_per_simd);
+
 /* Kernel resource facts for DESIGN.md / bench: name of the kernel variant selected for this
  * handle, its VGPR count, static LDS bytes and the launch geometry. */
 int bsk_kernel_info(bsk_handle* h, char* name, int name_cap, int* vgprs, int* lds_bytes,
