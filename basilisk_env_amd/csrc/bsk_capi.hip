@@ -1044,43 +1044,6 @@ int bsk_profile_end(bsk_handle* h, double* mean_kernel_ms, int* n_launches) {
     return bsk_profile_end_samples(h, mean_kernel_ms, n_launches, nullptr, 0);
 }
 
-int bsk_calibrate_fp64(int device_id, int waves_per_simd, int repeats, double* tflops, double* ns_per_fma_per_simd) {
-    if (waves_per_simd < 1 || waves_per_simd > 8 || repeats < 1 || repeats > 64) return fail(BSK_EINVAL, "waves_per_simd in 1..8, repeats in 1..64");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return fail(BSK_ENODEV, "device_id out of range");
-    DeviceGuard guard(device_id);
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
-    const int simds = prop.multiProcessorCount * 4, grid = simds * waves_per_simd, iters = 60000;
-    double host_in[18];
-    host_in[0] = 0.999999; host_in[1] = 1e-7;
-    for (int k = 0; k < 16; ++k) host_in[2 + k] = 1.0 + 0.01 * k;
-    double *d_in = nullptr, *d_out = nullptr;
-    hipStream_t st = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    HIP_TRY(hipMalloc(&d_in, sizeof host_in));
-    HIP_TRY(hipMalloc(&d_out, (size_t)grid * 64 * sizeof(double)));
-    HIP_TRY(hipMemcpy(d_in, host_in, sizeof host_in, hipMemcpyHostToDevice));
-    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    float best = 0.f;
-    std::vector<float> ms(repeats);
-    for (int w = 0; w < 3; ++w) HIP_TRY(bsk::launch_fp64_fma(d_in, d_out, grid, iters, st, nullptr, nullptr));   // clocks settle
-    for (int r = 0; r < repeats; ++r) {
-        HIP_TRY(bsk::launch_fp64_fma(d_in, d_out, grid, iters, st, e0, e1));
-        HIP_TRY(hipStreamSynchronize(st));
-        HIP_TRY(hipEventElapsedTime(&ms[r], e0, e1));
-    }
-    std::sort(ms.begin(), ms.end());
-    best = ms[repeats / 2];                       // median
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st); (void)hipFree(d_in); (void)hipFree(d_out);
-    const double fmas_per_wave = 16.0 * iters, sec = best * 1e-3;
-    if (tflops) *tflops = fmas_per_wave * 64.0 * 2.0 * grid / sec / 1e12;
-    if (ns_per_fma_per_simd) *ns_per_fma_per_simd = sec * 1e9 / (fmas_per_wave * waves_per_simd);
-    return BSK_OK;
-}
-
 int bsk_kernel_info(bsk_handle* h, char* name, int name_cap, int* vgprs, int* lds_bytes, int* block, int* grid) {
     if (!h) return fail(BSK_EINVAL, "handle is NULL");
     DeviceGuard guard(h->device);

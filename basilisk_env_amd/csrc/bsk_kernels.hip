@@ -763,31 +763,6 @@ const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat, int sh_form)
     return nullptr;
 }
 
-// Measurement aid: the fp64 FMA rate this device SUSTAINS (its clocks under a dense fp64 load, on this box, today), so that a
-// roofline fraction against the nominal 78.6 TFLOP/s can be read beside what the silicon actually delivers.  16 independent
-// accumulators per lane (no dependent-issue stalls), `iters` x 16 v_fma_f64 per lane, operands from memory so that nothing
-// folds; one wave per workgroup, waves_per_simd x 1024 workgroups.
-__global__ __launch_bounds__(64) void fp64_fma_kernel(const double* __restrict__ in, double* __restrict__ out, int iters) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    const double a = in[0], b = in[1];
-    double acc[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) acc[k] = in[2 + k] + (double)(threadIdx.x & 3);
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc[k] = fma(acc[k], a, b);
-    }
-    double sum = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) sum += acc[k];
-    out[i] = sum;
-}
-
-hipError_t launch_fp64_fma(const double* in, double* out, int grid, int iters, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    hipExtLaunchKernelGGL(fp64_fma_kernel, dim3(grid), dim3(64), 0, s, ev0, ev1, 0, in, out, iters);
-    return hipGetLastError();
-}
-
 hipError_t launch_stats(const double* wave_reward, const unsigned long long* done_mask, int n_waves, double* out_sum,
                         long long* out_done, hipStream_t s) {
     hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(256), 0, s, wave_reward, done_mask, n_waves, out_sum, out_done);

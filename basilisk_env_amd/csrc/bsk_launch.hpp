@@ -99,7 +99,6 @@ const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat, int sh_form)
 hipError_t launch_sample_pool(double* pool, int n_pool, int n_rw, unsigned long long seed, double mu, hipStream_t s);
 hipError_t launch_reset_from_pool(double* st, int64_t stride, int nf, const double* pool, int n_pool, const unsigned char* mask,
                                   int n, int2* cnt, int* episodes, unsigned env_base, hipStream_t s);
-hipError_t launch_fp64_fma(const double* in, double* out, int grid, int iters, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 hipError_t launch_stats(const double* wave_reward, const unsigned long long* done_mask, int n_waves, double* out_sum,
                         long long* out_done, hipStream_t s);
 hipError_t launch_scatter_reset(double* st, int64_t stride, int nf, const double* ic, const int* idx, int m, int2* cnt,

@@ -164,3 +164,26 @@ def test_sharded_gather_obs_device_single_shard_path():
     obs = sp.get_obs()[0]
     assert tuple(t.shape) == (5, n) and t.is_contiguous() and np.array_equal(t.cpu().numpy(), obs)
     sp.close()
+
+
+def test_get_obs_state_is_the_two_read_backs_in_one():
+    n = 77
+    cfg = default_config(3, GRAV_PM_J2)
+    p = BatchedPropagator(cfg, n)
+    p.reset(sample_ic_batch(n, 3, seed=9))
+    p.step((np.arange(n) % 3).astype(np.int32), 25)
+    obs, st = p.get_obs_state()
+    assert np.array_equal(obs, p.get_obs()[0]) and np.array_equal(st, p.get_state())
+    p.close()
+
+
+def test_fp64_calibration_reports_a_plausible_sustained_rate():
+    """bsk_calibrate_fp64: independent v_fma_f64 chains; two waves per SIMD issue faster than one, and neither exceeds
+    the nominal 78.6 TFLOP/s of the part."""
+    from basilisk_env_amd._lib import BskError, calibrate_fp64
+    tf1, ns1 = calibrate_fp64(0, 1, 3)
+    tf2, ns2 = calibrate_fp64(0, 2, 3)
+    assert 20.0 < tf1 < 79.0 and 20.0 < tf2 < 79.0 and tf2 >= 0.95 * tf1
+    assert 1.0 < ns2 <= ns1 * 1.05 < 5.0
+    with pytest.raises(BskError):
+        calibrate_fp64(0, 0, 3)
