@@ -403,6 +403,12 @@ struct bsk_handle {
     bool prof = false;
     double sim_time = 0.0;
     unsigned env_base = 0;   // global index of env 0 (bsk_set_env_base)
+    // pair form of the step kernel (bsk_device.hpp: PairLds): used for launches of >= pair_min_substeps sub-steps of batches
+    // of <= pair_max_envs spacecraft where it is built (power / full-scenario levels, point mass or J2, diagonal hub).  Measured
+    // (profiles/r03/pair_form.txt): -13 % per env step up to one pair per CU (16 384 spacecraft), level with the single-wave
+    // form up to three pairs per CU, 1.6x slower at four (65 536).  BSKGPU_PAIR=0 / 1 forces it off / on for every launch.
+    bool pair_ok = false, last_pair = false;
+    int pair_min_substeps = 16, pair_max_envs = 16384;
 };
 
 namespace {
@@ -507,6 +513,8 @@ int do_step(bsk_handle* h, const int* d_actions, int substeps) {
             e1 = h->ev_warm[1];
         }
     }
+    h->sp.pair = (h->pair_ok && substeps >= h->pair_min_substeps && h->n <= h->pair_max_envs) ? 1 : 0;
+    h->last_pair = h->sp.pair != 0;
     HIP_TRY(bsk::launch_step(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp.feat, h->sp, b, h->block, h->stream, e0, e1));
     return BSK_OK;
 }
@@ -650,8 +658,16 @@ int bsk_create(const bsk_config* cfg, int n_envs, int device_id, void* stream, b
         const int v = std::atoi(b);
         if (v == 64 || v == 128 || v == 256) h->block = v;
     }
-    // the power-system kernels carry 29 KB of LDS per wave: one wave per workgroup at every batch size
+    // the power-system kernels carry 37.6 KB of LDS per wave: one wave per workgroup at every batch size
     if (cfg->flags & BSK_FLAG_POWER) h->block = 64;
+    h->pair_ok = bsk::pair_available(cfg->gravity_model, h->diag, h->sp.feat);
+    h->sp.pair_shift = 31;     // no swap: the hardware already places one wave 0 and one wave 1 of different workgroups on a SIMD (tools/micro/placement.hip)
+    if (const char* ps = std::getenv("BSKGPU_PAIR_SHIFT")) h->sp.pair_shift = std::max(0, std::min(31, std::atoi(ps)));
+    if (const char* pv = std::getenv("BSKGPU_PAIR")) {
+        const int v = std::atoi(pv);
+        if (v == 0) h->pair_ok = false;
+        else { h->pair_min_substeps = 1; h->pair_max_envs = 1 << 28; }   // every launch (measurement / tests)
+    }
     if (stream) { h->stream = (hipStream_t)stream; h->own_stream = false; }
     else {
         hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -1048,7 +1064,8 @@ int bsk_kernel_info(bsk_handle* h, char* name, int name_cap, int* vgprs, int* ld
     if (!h) return fail(BSK_EINVAL, "handle is NULL");
     DeviceGuard guard(h->device);
     const bool sh = h->cfg.gravity_model == BSK_GRAV_SH;
-    const void* fp = bsk::step_kernel_ptr(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp.feat, h->sp.sh_form);
+    // (the kernel of the LAST launch: the pair form is chosen per launch by its number of sub-steps)
+    const void* fp = bsk::step_kernel_ptr(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp.feat, h->sp.sh_form, h->last_pair);
     if (!fp) return fail(BSK_EINVAL, "no kernel variant for this config");
     hipFuncAttributes at;
     HIP_TRY(hipFuncGetAttributes(&at, fp));
@@ -1056,15 +1073,15 @@ int bsk_kernel_info(bsk_handle* h, char* name, int name_cap, int* vgprs, int* ld
         std::snprintf(name, name_cap, "step_kernel<%s,%d,%s>",
                       h->cfg.gravity_model == BSK_GRAV_PM ? "PM" : (h->cfg.gravity_model == BSK_GRAV_PM_J2 ? "PM_J2" : (h->sp.sh_form == 5 ? "SH/dpp2" : (h->sp.sh_form == 4 ? "SH/dpp" : "SH/scalar"))), h->cfg.n_rw,
                       h->sp.feat >= 2 ? (h->sp.feat == 3 ? (h->diag ? "diag,scenario/generic-facets" : "full,scenario/generic-facets")
-                                                         : (h->diag ? "diag,scenario" : "full,scenario"))
-                                      : (h->sp.feat == 1 ? (h->diag ? "diag,power" : "full,power")
+                                                         : (h->last_pair ? "diag,scenario,pair" : (h->diag ? "diag,scenario" : "full,scenario")))
+                                      : (h->sp.feat == 1 ? (h->last_pair ? "diag,power,pair" : (h->diag ? "diag,power" : "full,power"))
                                                          : (h->sp.feat == -1 ? (h->diag ? "diag,lds-scratch" : "full,lds-scratch") : (h->diag ? "diag" : "full"))));
     if (vgprs) *vgprs = at.numRegs;
     if (lds_bytes) *lds_bytes = (int)at.sharedSizeBytes;
     // the two-wave harmonics form launches 256-thread workgroups of 2 x 64 spacecraft x 2 halves
-    const int blk = (sh && h->sp.sh_form == 5) ? 256 : h->block;
+    const int blk = (sh && h->sp.sh_form == 5) ? 256 : (h->last_pair ? 128 : h->block);
     if (block) *block = blk;
-    if (grid) *grid = (sh && h->sp.sh_form == 5) ? (h->n + 127) / 128 : (h->n + blk - 1) / blk;
+    if (grid) *grid = (sh && h->sp.sh_form == 5) ? (h->n + 127) / 128 : (h->last_pair ? (h->n + 63) / 64 : (h->n + blk - 1) / blk);
     return BSK_OK;
 }
 

@@ -447,6 +447,32 @@ struct PowerLds {                             // one per wavefront, in dynamic L
 // LDS pointers are spelled with their address space (through a generic pointer the accesses would be flat)
 typedef PowerLds __attribute__((address_space(3))) * LdsP;
 
+// Pair form (SPLIT == 2; round 3): TWO cooperating waves per 64 spacecraft - a dynamics wave (RK4 with gravity, Sun, drag,
+// thrusters, wheels: Basilisk's DynamicsProcess) and a flight-software + environment wave (the 1 Hz FSW chain,
+// desaturation, eclipse -> panel -> battery: its FSWProcess and EnvTask) - so that 65 536 spacecraft are 2 048 waves, two
+// per SIMD, and what was a serial 24 % tail of every env step (measured: dynamics alone 2.87 of 3.53 ms) runs beside the
+// integration instead of after it.  They exchange through this block: the dynamics wave leaves (r, sigma) of every tick in a
+// ring, double-buffered by chunk of PAIR_CHUNK ticks, and the state at FSW ticks in `box`; the other wave answers in `box`
+// with the commands (wheel torques, thruster burst) and, at the end of the launch, with battery charge, shadow factor and
+// the FSW bookkeeping.  37.4 KB per pair: four pairs per CU.
+#ifndef PAIR_CHUNK_OVERRIDE
+#define PAIR_CHUNK_OVERRIDE 4
+#endif
+constexpr int PAIR_CHUNK = PAIR_CHUNK_OVERRIDE;
+struct PairLds {
+    double rr[2][3][PAIR_CHUNK][64];          // ring: position after each tick of the chunk
+    double rs[2][3][PAIR_CHUNK][64];          // ring: sigma_BN after each tick
+    double box[16][64];                       // D -> F: state at an FSW tick;  F -> D: commands, final values (aliased)
+    double sfac[PAIR_CHUNK][64];              // shadow factors the cooperative drain filled in
+    double sun[3][64];                        // each lane's Sun position of this launch
+    double lext[3][64];                       // each lane's disturbance torque (parked here: the dynamics wave's tick loop has
+                                              // 256 registers, and what does not fit goes to scratch memory, whose reloads miss the
+                                              // L1 once eight waves per CU spill - measured as a 40 % cliff at four pairs per CU)
+    int qown[PAIR_CHUNK * 64];                // penumbra queue: owner lane | slot << 8
+    int qcount, pad_[3];
+};
+typedef PairLds __attribute__((address_space(3))) * PairP;
+
 // ---------------------------------------------------------------------------------------------------------
 // Wave-uniform constants as DPP broadcast operands (full-scenario kernels).  These kernels need ~45 doubles that
 // are the same in every lane (wheel geometry, facet tables, panel normal, atmosphere) on top of the RK4 loop's
@@ -596,11 +622,12 @@ __device__ __forceinline__ double shadow_quick(const SunGeom& g, V3 r, bool& ban
     return umbra ? 0.0 : 1.0;
 }
 
-// per tick: classify, record the panel gain and (when known) the shadow factor of slot t
+// eclipse (classification) -> simpleSolarPanel of one dyn tick: the panel power per unit of lit disc (`gain`), the shadow
+// factor where it is cheap, `band` where the disc is partially covered.  One definition for the single-wave kernels' tick
+// record and the pair form's environment wave: the same operations in the same order.
 template <bool LDSK>
-__device__ __forceinline__ void power_tick(const PowerCfg& pc, const SunGeom& g, V3 r, V3 sig, LdsP L, int t, int lane, double tc) {
-    bool band;
-    const double sh = shadow_quick(g, r, band);
+__device__ __forceinline__ void power_eval(const PowerCfg& pc, const SunGeom& g, V3 r, V3 sig, double tc, double& gain, double& sh, bool& band) {
+    sh = shadow_quick(g, r, band);
     const V3 d = g.sun - r;
     const double d2 = dot(d, d), id = rsqrt_nr(d2);
     const V3 sN = id * d;
@@ -610,21 +637,24 @@ __device__ __forceinline__ void power_tick(const PowerCfg& pc, const SunGeom& g,
     const V3 sB = sN + (8.0 * iop2) * t2 - (4.0 * (1.0 - q2) * iop2) * t1;
     if constexpr (LDSK) {     // panel normal and flux constant from the broadcast table (row C)
         const double proj = fmax(fmac_k<KC_NB>(fmac_k<KC_NB + 1>(mul_k<KC_NB + 2>(tc, sB.z), tc, sB.y), tc, sB.x), 0.0);
-        const double gain = mul_k<KC_KFLUX>(tc, id * id) * proj;
-#if defined(BSK_ABLATE) && BSK_ABLATE == 7
-        asm volatile("" ::"v"(gain));
-#else
-        L->g[t][lane] = gain;
-#endif
+        gain = mul_k<KC_KFLUX>(tc, id * id) * proj;
     } else {
         const double proj = fmax(fma(pc.nB[0], sB.x, fma(pc.nB[1], sB.y, pc.nB[2] * sB.z)), 0.0);
-        const double gain = pc.kflux * (id * id) * proj;
-#if defined(BSK_ABLATE) && BSK_ABLATE == 7
-        asm volatile("" ::"v"(gain));
-#else
-        L->g[t][lane] = gain;
-#endif
+        gain = pc.kflux * (id * id) * proj;
     }
+}
+
+// per tick: classify, record the panel gain and (when known) the shadow factor of slot t
+template <bool LDSK>
+__device__ __forceinline__ void power_tick(const PowerCfg& pc, const SunGeom& g, V3 r, V3 sig, LdsP L, int t, int lane, double tc) {
+    bool band;
+    double sh, gain;
+    power_eval<LDSK>(pc, g, r, sig, tc, gain, sh, band);
+#if defined(BSK_ABLATE) && BSK_ABLATE == 7
+    asm volatile("" ::"v"(gain));
+#else
+    L->g[t][lane] = gain;
+#endif
 #if defined(BSK_ABLATE) && BSK_ABLATE == 7   // timing only: the tick's arithmetic without its LDS record
     asm volatile("" ::"v"(sh), "v"(band ? 1 : 0));
     return;

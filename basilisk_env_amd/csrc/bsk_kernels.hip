@@ -51,15 +51,22 @@ __device__ __forceinline__ int wave_min_uniform(int v) {
 // sums through LDS: twice the waves per SIMD at the same batch size, so one wave's loads and scalar
 // instructions overlap with the other's FMAs.  Only wave 0 stores.
 template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT>
-__global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT_LDSS ? BSK_LDSS_WAVES : BSK_MIN_WAVES)) void step_kernel(const StepArgs<NRW, DIAG> a) {
+__global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2) ? 2 : (FEAT == FEAT_LDSS ? BSK_LDSS_WAVES : BSK_MIN_WAVES)) void step_kernel(const StepArgs<NRW, DIAG> a) {
     const HotCfg<NRW, DIAG>& c = a.hot;
     const ColdCfg* __restrict__ cold = a.cold;
+#ifdef BSK_PAIR_DEBUG_TIME
+    const unsigned long long dbg_t0 = __builtin_readcyclecounter();
+#endif
 #if defined(BSK_ABLATE) && BSK_ABLATE == 1
     return;   // launch + exit only
 #endif
     // SPLIT == 5: waves 0/1 of the workgroup carry spacecraft group 0 (halves 0/1 of the walk), waves 2/3 group 1
+    // SPLIT == 2 (pair form, bsk_device.hpp: PairLds): a 128-thread workgroup = the dynamics wave and the FSW + environment
+    // wave of the SAME 64 spacecraft
+    constexpr bool PAIR = SPLIT == 2;
     const int gid = (SPLIT == 5) ? (int)(blockIdx.x * 128 + (threadIdx.x >> 7) * 64 + (threadIdx.x & 63))
-                                 : (int)(blockIdx.x * blockDim.x + threadIdx.x);
+                  : PAIR ? (int)(blockIdx.x * 64 + (threadIdx.x & 63))
+                         : (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const bool valid = gid < a.n;
     const int i = valid ? gid : a.n - 1;  // tail lanes shadow the last env; their stores are masked
     const int64_t S = a.stride;
@@ -135,9 +142,11 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
     const int lane = (int)(threadIdx.x & 63u);
     if constexpr (POWER) {
         sg = sun_setup(a.power, (double)tick * c.h);
-        L = (LdsP)lds_dyn + (threadIdx.x >> 6);
-        L->sun[0][lane] = sg.sun.x; L->sun[1][lane] = sg.sun.y; L->sun[2][lane] = sg.sun.z;
-        if (lane == 0) L->qcount = 0;
+        if constexpr (!PAIR) {
+            L = (LdsP)lds_dyn + (threadIdx.x >> 6);
+            L->sun[0][lane] = sg.sun.x; L->sun[1][lane] = sg.sun.y; L->sun[2][lane] = sg.sun.z;
+            if (lane == 0) L->qcount = 0;
+        }
     }
     AccP accp = nullptr;
     if constexpr (FEAT == FEAT_LDSS) accp = (AccP)lds_dyn + (threadIdx.x >> 6);
@@ -266,6 +275,240 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
     // of the loop (wave-uniform: the other lanes of the wave wait), so that the FSW chain is instantiated once.
     bool z0 = false;
     if constexpr (NRW > 0) z0 = navlag && tick == 0 && substeps_eff > 0;
+    if constexpr (PAIR) {
+        static_assert(!PAIR || (FEAT >= FEAT_POWER && FEAT != FEAT_FULLG && GRAV != BSK_GRAV_SH), "pair form: power / full-scenario levels, point mass or J2");
+        // ---- pair form: both waves run the SAME control flow on the same counters (every decision below is a function of
+        // cnt / substeps / actions, identical in the two waves), so their barrier counts agree by construction; what each
+        // wave does between two barriers depends on its role and contains no barrier.
+        PairP PL = (PairP)lds_dyn;
+        // wave 0: dynamics, wave 1: FSW + environment - swapped in every other group of 2^pair_shift workgroups, so that the
+        // two waves a SIMD hosts (they come from different workgroups) are one of each kind
+        const bool isD = ((__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) ^ (int)(blockIdx.x >> a.pair_shift)) & 1) == 0;
+        if (!isD) {
+            PL->sun[0][lane] = sg.sun.x; PL->sun[1][lane] = sg.sun.y; PL->sun[2][lane] = sg.sun.z;
+            PL->lext[0][lane] = lext.x; PL->lext[1][lane] = lext.y; PL->lext[2][lane] = lext.z;
+            if (lane == 0) PL->qcount = 0;
+        }
+        const double draw = a.power.draw, cap = a.power.cap;
+        // the environment wave's share of a chunk: eclipse -> panel of each recorded tick, cooperative drain of the
+        // partially eclipsed ones, battery updates in tick order (the arithmetic of power_tick / power_flush)
+        auto env_ticks = [&](int mm, int bb) {
+            if (mm == 0) return;
+#if defined(BSK_PAIR_ABLATE) && BSK_PAIR_ABLATE == 2   // timing only: no EnvTask at all
+            return;
+#endif
+            double gk[PAIR_CHUNK], sk[PAIR_CHUNK];
+            unsigned bandmask = 0u;
+#pragma unroll
+            for (int k = 0; k < PAIR_CHUNK; ++k) {
+                gk[k] = 0.0; sk[k] = 1.0;
+                if (k < mm) {
+                    const V3 r = mk(PL->rr[bb][0][k][lane], PL->rr[bb][1][k][lane], PL->rr[bb][2][k][lane]);
+                    const V3 sig = mk(PL->rs[bb][0][k][lane], PL->rs[bb][1][k][lane], PL->rs[bb][2][k][lane]);
+                    bool band;
+                    power_eval<FULL>(a.power, sg, r, sig, kt.c, gk[k], sk[k], band);
+                    bandmask |= band ? (1u << k) : 0u;
+                }
+            }
+#if defined(BSK_PAIR_ABLATE) && BSK_PAIR_ABLATE == 1   // timing only: no drain
+            bandmask = 0u;
+#endif
+            if (BSK_UNLIKELY(__builtin_amdgcn_ballot_w64(bandmask != 0u) != 0)) {
+#pragma unroll
+                for (int k = 0; k < PAIR_CHUNK; ++k) {
+                    if (bandmask & (1u << k)) {
+                        const int e = __hip_atomic_fetch_add(&PL->qcount, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        PL->qown[e] = lane | (k << 8);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const int qc = PL->qcount;
+                for (int e = lane; e < qc; e += 64) {          // entry e by lane e mod 64, whoever owns it
+                    const int own = PL->qown[e], ol = own & 63, k = own >> 8;
+                    const V3 r = mk(PL->rr[bb][0][k][ol], PL->rr[bb][1][k][ol], PL->rr[bb][2][k][ol]);
+                    const V3 sun = mk(PL->sun[0][ol], PL->sun[1][ol], PL->sun[2][ol]);
+                    PL->sfac[k][ol] = percent_shadow(a.power, sun - r, r, dot(r, r));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+                for (int k = 0; k < PAIR_CHUNK; ++k) {
+                    if (bandmask & (1u << k)) sk[k] = PL->sfac[k][lane];
+                }
+                if (lane == 0) PL->qcount = 0;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+#pragma unroll
+            for (int k = 0; k < PAIR_CHUNK; ++k) {
+                if (k < mm) {
+                    shadow = sk[k];
+                    charge = fmin(fmax(charge + fma(gk[k], sk[k], draw) * c.h, 0.0), cap);
+                }
+            }
+        };
+        // The commands of the FSW wave (box rows 0..9), read by the dynamics wave STRAIGHT into its effectors' copies
+        // (u, ev.thr_*, thr_t0): that is the latch, and no second copy of the messages stays live in its tick loop (which
+        // has 256 registers: every one it does not hold is a scratch reload less per tick).
+        auto read_cmd = [&]() {
+#pragma unroll
+            for (int k = 0; k < NRW; ++k) u[k] = PL->box[k][lane];
+            if constexpr (FULL) {
+#pragma unroll
+                for (int k = 0; k < BSK_MAX_THR / 2; ++k) ev.thr_lim2[k] = (unsigned)PL->box[4 + k][lane];
+                ev.thr_max = (int)PL->box[8][lane];
+                thr_t0 = (int)PL->box[9][lane];
+            }
+        };
+        // One chunk's control decisions: a function of (phase, z0, tick, j) only - both waves evaluate it on identical
+        // inputs, so their barrier sequences agree.
+        struct Chunk { int m; bool cond, fsw_any, anyz, zlane, needB, needB0; int t_latch; };
+        auto next_chunk = [&]() {
+            Chunk q;
+            q.m = substeps_eff - j;
+            q.cond = false; q.fsw_any = false; q.anyz = false; q.zlane = false; q.t_latch = tick;
+            if constexpr (NRW > 0) {
+                const int trig = navlag ? fsw_every - 1 : 0;
+                int dist = trig - phase;
+                if (dist <= 0) dist += fsw_every;
+                q.anyz = navlag && __builtin_amdgcn_ballot_w64(z0) != 0;
+                q.cond = z0 || (!q.anyz && phase == trig);
+                q.fsw_any = __builtin_amdgcn_ballot_w64(q.cond) != 0;
+                q.zlane = z0;
+                q.t_latch = tick + ((navlag && !z0) ? 1 : 0);
+                if (q.cond && navlag) dist = fsw_every;   // latched inside the chunk, after its first RK4 step
+                if (q.anyz) dist = 0;                      // t = 0 tick: latched without a step in between
+                z0 = false;
+                q.m = min(q.m, dist);
+            }
+            q.m = wave_min_uniform(min(q.m, PAIR_CHUNK));
+            if constexpr (NRW > 0) {
+                phase += q.m;
+                if (phase >= fsw_every) phase -= fsw_every;
+            }
+            j += q.m;
+            q.needB0 = q.fsw_any && !navlag;               // same-tick chain: commands before the chunk's first step
+            q.needB = q.fsw_any && navlag;                 // reference priorities: commands latched after the first step
+            return q;
+        };
+        int cb = 0;                                        // ring buffer of this chunk
+        __syncthreads();                                   // the environment wave's Sun positions are in LDS
+        if (isD) {
+            // ---------------------------------------------------------------- dynamics wave
+            while (j < substeps_eff) {
+                const Chunk q = next_chunk();
+                const int m = q.m;
+                if (q.fsw_any) {                           // the navigation / wheel-speed messages of this FSW tick
+                    PL->box[0][lane] = x.r.x; PL->box[1][lane] = x.r.y; PL->box[2][lane] = x.r.z;
+                    PL->box[3][lane] = x.v.x; PL->box[4][lane] = x.v.y; PL->box[5][lane] = x.v.z;
+                    PL->box[6][lane] = x.s.x; PL->box[7][lane] = x.s.y; PL->box[8][lane] = x.s.z;
+                    PL->box[9][lane] = x.w.x; PL->box[10][lane] = x.w.y; PL->box[11][lane] = x.w.z;
+#pragma unroll
+                    for (int k = 0; k < NRW; ++k) PL->box[12 + k][lane] = x.Om[k];
+                }
+                __syncthreads();                           // A: messages written; the previous chunk's ring complete
+                if (q.needB0) {
+                    __syncthreads();                       // B (same-tick chain): wait for the commands
+                    read_cmd();
+                }
+                if constexpr (FULL) {
+                    if (ev.sun_on) third_body_anchor(ev.s3, mk(PL->sun[0][lane], PL->sun[1][lane], PL->sun[2][lane]), a.extra.mu_sun, x.r);
+                }
+                for (int t = 0; t < m; ++t, ++tick) {
+                    const V3 lx = mk(PL->lext[0][lane], PL->lext[1][lane], PL->lext[2][lane]);   // (parked in LDS)
+                    if constexpr (FULL) {
+                        if (drag_cfg) {
+                            const double r2 = dot(x.r, x.r), rm = r2 * rsqrt_nr(r2);
+                            const double rho = mul_k<KC_RHO0>(kt.c, exp_fast(fmac_k<KC_NIH>(get_k<KC_REQIH>(kt.c), kt.c, rm)));
+                            ev.rho = rho >= get_k<KC_RSKIP>(kt.c) ? rho : 0.0;
+                            ev.drag_on = __builtin_amdgcn_ballot_w64(ev.rho != 0.0) != 0;
+                        }
+                        if (desat) {
+                            ev.e2 = 2 * (tick - thr_t0);
+                            ev.thr_on = __builtin_amdgcn_ballot_w64(ev.thr_max > 0 && ev.e2 <= ev.thr_max) != 0;
+                            if (BSK_UNLIKELY(ev.thr_on)) thr_masks(ev);
+                        }
+                        if (BSK_LIKELY(!ev.thr_on)) {
+                            if (BSK_LIKELY(ev.drag_on)) rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT, false, 1>(c, wv, x, u, lx, (double)tick * c.h, ev, accp);
+                            else rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT, false, 2>(c, wv, x, u, lx, (double)tick * c.h, ev, accp);
+                        } else rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT, true, 0>(c, wv, x, u, lx, (double)tick * c.h, ev, accp);
+                    } else {
+                        rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT, false>(c, wv, x, u, lx, (double)tick * c.h, ev, accp);
+                    }
+                    PL->rr[cb][0][t][lane] = x.r.x; PL->rr[cb][1][t][lane] = x.r.y; PL->rr[cb][2][t][lane] = x.r.z;
+                    PL->rs[cb][0][t][lane] = x.s.x; PL->rs[cb][1][t][lane] = x.s.y; PL->rs[cb][2][t][lane] = x.s.z;
+                    if (t == 0 && q.needB) {               // B: the commands of this chunk's FSW tick are there
+                        __syncthreads();
+                        read_cmd();
+                    }
+                }
+                if (m == 0 && q.needB) {                   // the t = 0 chunk has no step
+                    __syncthreads();
+                    read_cmd();
+                }
+                cb ^= 1;
+            }
+            __syncthreads();                               // the last chunk's ring is complete
+            __syncthreads();                               // ... and the environment wave has answered
+            charge = PL->box[0][lane]; shadow = PL->box[1][lane]; sbr = PL->box[2][lane];
+#pragma unroll
+            for (int k = 0; k < NRW; ++k) up[k] = PL->box[3 + k][lane];
+            thr_cnt = (int)PL->box[7][lane];
+            fsw_ran = PL->box[8][lane] != 0.0;
+        } else {
+            // ---------------------------------------------------------------- FSW + environment wave
+            int pm = 0, pb = 0;                            // length / buffer of the chunk whose EnvTask ticks are still owed
+            while (j < substeps_eff) {
+                const Chunk q = next_chunk();
+                __syncthreads();                           // A
+                if (q.fsw_any) {
+                    State<NRW> nav;
+                    nav.r = mk(PL->box[0][lane], PL->box[1][lane], PL->box[2][lane]);
+                    nav.v = mk(PL->box[3][lane], PL->box[4][lane], PL->box[5][lane]);
+                    nav.s = mk(PL->box[6][lane], PL->box[7][lane], PL->box[8][lane]);
+                    nav.w = mk(PL->box[9][lane], PL->box[10][lane], PL->box[11][lane]);
+#pragma unroll
+                    for (int k = 0; k < NRW; ++k) nav.Om[k] = PL->box[12 + k][lane];
+                    if (BSK_UNLIKELY(q.anyz)) {
+                        if (q.zlane) {
+                            nav.r = mk(0, 0, 0); nav.v = mk(0, 0, 0); nav.s = mk(0, 0, 0); nav.w = mk(0, 0, 0);
+#pragma unroll
+                            for (int k = 0; k < NRW; ++k) nav.Om[k] = 0.0;
+                        }
+                    }
+#if !(defined(BSK_PAIR_ABLATE) && BSK_PAIR_ABLATE == 3)   // 3: timing only, no FSW chain
+                    if constexpr (NRW > 0) {
+                        if (q.cond) fsw_tick(nav, q.t_latch);
+                    }
+#endif
+#pragma unroll
+                    for (int k = 0; k < NRW; ++k) PL->box[k][lane] = un[k];
+                    if constexpr (FULL) {
+#pragma unroll
+                        for (int k = 0; k < BSK_MAX_THR / 2; ++k) PL->box[4 + k][lane] = (double)lim2n[k];
+                        PL->box[8][lane] = (double)thr_maxn;
+                        PL->box[9][lane] = (double)thr_t0n;
+                    }
+                    __syncthreads();                       // B (either timing): the commands are there
+                }
+                tick += q.m;
+                env_ticks(pm, pb);                         // the PREVIOUS chunk's EnvTask, beside this chunk's integration
+                pm = q.m; pb = cb;
+                cb ^= 1;
+            }
+            __syncthreads();                               // the last chunk's ring is complete
+            env_ticks(pm, pb);
+            PL->box[0][lane] = charge; PL->box[1][lane] = shadow; PL->box[2][lane] = sbr;
+#pragma unroll
+            for (int k = 0; k < NRW; ++k) PL->box[3 + k][lane] = up[k];
+            PL->box[7][lane] = (double)thr_cnt;
+            PL->box[8][lane] = fsw_ran ? 1.0 : 0.0;
+#ifdef BSK_PAIR_DEBUG_HWID
+            { unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+              PL->box[9][lane] = (double)((hw & 0xFFFFu) | ((xcc & 0xFu) << 16)); }
+#endif
+            __syncthreads();
+            return;                                        // the dynamics wave writes the launch's results
+        }
+    } else {
     int np = 0;   // power system: ticks recorded since the last flush (per lane)
     while (j < substeps_eff) {
         int m = substeps_eff - j;
@@ -393,6 +636,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
         if (__builtin_amdgcn_ballot_w64(np > 0) != 0) power_flush(a.power, L, np, lane, c.h, charge, shadow);
     }
 #endif
+    }   // !PAIR
 
     // Re-read the post-loop arguments from the kernarg segment through an opaque pointer: the
     // compiler cannot hoist these scalar loads above the loop, so they cost it no SGPRs.
@@ -439,6 +683,22 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4) ? 2 : (FEAT == FEAT
     // wavefront reductions (every lane of the wave participates; tail lanes contribute nothing)
     const unsigned long long dmask = __ballot(valid2 && why != 0);
     const double rsum = wave_sum(valid2 ? rew : 0.0);
+#ifdef BSK_PAIR_DEBUG_TIME
+    if constexpr (PAIR) {   // residency probe: (this wave's start clock >> 10) | (end clock >> 10) << 32 instead of the done mask
+        const unsigned long long t1 = __builtin_readcyclecounter();
+        unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const unsigned long long id = (hw & 0xFFFFu) | ((xcc & 0xFu) << 16);
+        if ((threadIdx.x & 63) == 0) { ta.done_mask[gid >> 6] = (((t1 - dbg_t0) >> 10) & 0xFFFFFFFFull) | (id << 32); ta.wave_reward[gid >> 6] = rsum; }
+    } else
+#endif
+#ifdef BSK_PAIR_DEBUG_HWID
+    if constexpr (PAIR) {   // placement probe: (dynamics wave's hardware id) | (environment wave's) << 32 instead of the done mask
+        unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const unsigned long long mine = (hw & 0xFFFFu) | ((xcc & 0xFu) << 16);
+        const unsigned long long other = (unsigned long long)((PairP)lds_dyn)->box[9][0];
+        if ((threadIdx.x & 63) == 0) { ta.done_mask[gid >> 6] = mine | (other << 32); ta.wave_reward[gid >> 6] = rsum; }
+    } else
+#endif
     if ((threadIdx.x & 63) == 0) {
         ta.done_mask[gid >> 6] = dmask;
         ta.wave_reward[gid >> 6] = rsum;
@@ -676,6 +936,7 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     a.cold = b.cold; a.st = b.st; a.cnt = b.cnt; a.act = b.act;
     a.stride = b.stride; a.n = b.n; a.substeps = b.substeps;
     a.nav_lag = p.nav_lag; a.fsw_lag = p.fsw_lag;
+    a.pair_shift = p.pair_shift; a.pad2_ = 0;
     a.power = p.pc;
     a.extra = p.ex;
     a.tail.obs_cfg = p.obs; a.tail.st = b.st; a.tail.cnt = b.cnt; a.tail.obs = b.obs; a.tail.reward = b.reward;
@@ -686,10 +947,12 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     a.tail.fsw_lag = p.fsw_lag; a.tail.nav_lag = p.nav_lag;
     a.tail.env_base = b.env_base; a.tail.pad_ = 0;
     if (SPLIT == 5) block = 256;
-    const int grid = SPLIT == 5 ? (b.n + 127) / 128 : (b.n + block - 1) / block;
+    if (SPLIT == 2) block = 128;      // pair form: dynamics wave + FSW / environment wave of the same 64 spacecraft
+    const int grid = SPLIT == 5 ? (b.n + 127) / 128 : (SPLIT == 2 ? (b.n + 63) / 64 : (b.n + block - 1) / block);
     // the power system keeps a per-wave tick record and penumbra queue in dynamic LDS (bsk_device.hpp: PowerLds)
-    const size_t lds = FEAT >= FEAT_POWER ? sizeof(PowerLds) * (size_t)(block / 64)
-                                           : (FEAT == FEAT_LDSS ? sizeof(AccLds) * (size_t)(block / 64) : 0);
+    const size_t lds = SPLIT == 2 ? sizeof(PairLds)
+                     : FEAT >= FEAT_POWER ? sizeof(PowerLds) * (size_t)(block / 64)
+                                          : (FEAT == FEAT_LDSS ? sizeof(AccLds) * (size_t)(block / 64) : 0);
     // hipExtLaunchKernelGGL stamps ev0/ev1 from the dispatch packet itself (no marker packets), so
     // their difference is the kernel's own duration, as rocprofv3 --kernel-trace reports it.
     if (lds > 48 * 1024) {   // the two-wave harmonics form with the power system: 4 waves x 29 KB of dynamic LDS
@@ -738,10 +1001,26 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
 #endif
 #define BSK_VARIANTS(X) BSK_VARIANTS_P(X, 0) BSK_VARIANTS_P(X, 1) BSK_VARIANTS_P(X, 2) BSK_VARIANTS_P(X, 3) BSK_VARIANTS_L(X)
 
+// pair form (SPLIT == 2): built for the power / full-scenario levels of the point-mass and J2 kernels with a diagonal hub
+template <int G, int R, bool D, int P>
+static hipError_t launch_pair(const StepParams& p, const StepBuffers& b, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    if constexpr (D && G != BSK_GRAV_SH && (P == FEAT_POWER || P == FEAT_FULL)) return launch_t<G, R, D, P, 2>(p, b, 128, s, ev0, ev1);
+    else return hipErrorInvalidValue;
+}
+template <int G, int R, bool D, int P>
+static const void* pair_ptr() {
+    if constexpr (D && G != BSK_GRAV_SH && (P == FEAT_POWER || P == FEAT_FULL)) return (const void*)&step_kernel<G, R, D, P, 2>;
+    else return nullptr;
+}
+bool pair_available(int grav, bool diag, int feat) {
+    return diag && grav != BSK_GRAV_SH && (feat == FEAT_POWER || feat == FEAT_FULL);
+}
+
 hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams& p, const StepBuffers& b, int block,
                        hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
 #define CASE(G, R, D, P) \
     if (grav == G && nrw == R && diag == D && feat == P) {                                                 \
+        if (p.pair) return launch_pair<G, R, D, P>(p, b, s, ev0, ev1);                                      \
         if (G == BSK_GRAV_SH && p.sh_form == 4) return launch_t<G, R, D, P, (G == BSK_GRAV_SH ? 4 : 1)>(p, b, block, s, ev0, ev1); \
         if (G == BSK_GRAV_SH && p.sh_form == 5) return launch_t<G, R, D, P, (G == BSK_GRAV_SH ? 5 : 1)>(p, b, block, s, ev0, ev1); \
         return launch_t<G, R, D, P, 1>(p, b, block, s, ev0, ev1);                                           \
@@ -751,9 +1030,10 @@ hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams&
     return hipErrorInvalidValue;
 }
 
-const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat, int sh_form) {
+const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat, int sh_form, bool pair) {
 #define CASE(G, R, D, P) \
     if (grav == G && nrw == R && diag == D && feat == P) {                                                                     \
+        if (pair) return pair_ptr<G, R, D, P>();                                                                               \
         if (G == BSK_GRAV_SH && sh_form == 4) return (const void*)&step_kernel<G, R, D, P, (G == BSK_GRAV_SH ? 4 : 1)>;        \
         if (G == BSK_GRAV_SH && sh_form == 5) return (const void*)&step_kernel<G, R, D, P, (G == BSK_GRAV_SH ? 5 : 1)>;        \
         return (const void*)&step_kernel<G, R, D, P, 1>;                                                                       \

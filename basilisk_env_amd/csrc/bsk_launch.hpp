@@ -46,6 +46,7 @@ struct StepArgs {
     int n;
     int substeps;
     int nav_lag, fsw_lag;   // both also in TailArgs (post-loop re-read); here for the FSW block inside the loop
+    int pair_shift, pad2_;  // pair form: the roles of a workgroup's two waves swap with bit `pair_shift` of its index
     PowerCfg power;               // read only by FEAT >= FEAT_POWER
     ExtraCfg extra;               // read only by FEAT_FULL
     TailArgs tail;
@@ -66,6 +67,8 @@ struct StepParams {
     int32_t sh_split;       // first Pines column of the second half of the walk
     int32_t sh_bodies, sh_bodies0, sh_bodies1, sh_chunk1;   // DPP stream: bodies (whole / per half), first chunk of half 1
     int sh_form;            // 1 scalar-load stream, 4 DPP broadcast, 5 DPP broadcast over two cooperating waves
+    int pair;               // this launch runs the pair form (dynamics wave + FSW / environment wave per 64 spacecraft)
+    int pair_shift;
     int feat;               // FEAT_BARE / FEAT_POWER / FEAT_FULL
     int fsw_lag, nav_lag;
     PowerCfg pc;
@@ -95,7 +98,8 @@ struct StepBuffers {
 
 hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams& p, const StepBuffers& b, int block,
                        hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
-const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat, int sh_form);
+const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat, int sh_form, bool pair);
+bool pair_available(int grav, bool diag, int feat);
 hipError_t launch_sample_pool(double* pool, int n_pool, int n_rw, unsigned long long seed, double mu, hipStream_t s);
 hipError_t launch_reset_from_pool(double* st, int64_t stride, int nf, const double* pool, int n_pool, const unsigned char* mask,
                                   int n, int2* cnt, int* episodes, unsigned env_base, hipStream_t s);
