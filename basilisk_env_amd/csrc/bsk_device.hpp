@@ -454,10 +454,10 @@ typedef PowerLds __attribute__((address_space(3))) * LdsP;
 // integration instead of after it.  They exchange through this block: the dynamics wave leaves (r, sigma) of every tick in a
 // ring, double-buffered by chunk of PAIR_CHUNK ticks, and the state at FSW ticks in `box`; the other wave answers in `box`
 // with the commands (wheel torques, thruster burst) and, at the end of the launch, with battery charge, shadow factor and
-// the FSW bookkeeping.  37.4 KB per pair: four pairs per CU.
+// the FSW bookkeeping.  80 KB per pair with chunks of 10 ticks (38.9 KB with chunks of 4, which four pairs per CU would need).
 #ifndef PAIR_CHUNK_OVERRIDE
-#define PAIR_CHUNK_OVERRIDE 4
-#endif
+#define PAIR_CHUNK_OVERRIDE 10    // = PEN_CHUNK: the same chunks as the single-wave form (same third-body anchors: bit-identical
+#endif                            // results at every level); 80 KB of LDS per pair - the form is used up to one pair per CU
 constexpr int PAIR_CHUNK = PAIR_CHUNK_OVERRIDE;
 struct PairLds {
     double rr[2][3][PAIR_CHUNK][64];          // ring: position after each tick of the chunk

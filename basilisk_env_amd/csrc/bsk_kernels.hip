@@ -275,6 +275,9 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2) ? 2 :
     // of the loop (wave-uniform: the other lanes of the wave wait), so that the FSW chain is instantiated once.
     bool z0 = false;
     if constexpr (NRW > 0) z0 = navlag && tick == 0 && substeps_eff > 0;
+#ifdef BSK_PAIR_DEBUG_WAIT
+    unsigned long long dbg_waitA_out = 0, dbg_waitB_out = 0;
+#endif
     if constexpr (PAIR) {
         static_assert(!PAIR || (FEAT >= FEAT_POWER && FEAT != FEAT_FULLG && GRAV != BSK_GRAV_SH), "pair form: power / full-scenario levels, point mass or J2");
         // ---- pair form: both waves run the SAME control flow on the same counters (every decision below is a function of
@@ -294,20 +297,26 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2) ? 2 :
         // partially eclipsed ones, battery updates in tick order (the arithmetic of power_tick / power_flush)
         auto env_ticks = [&](int mm, int bb) {
             if (mm == 0) return;
-#if defined(BSK_PAIR_ABLATE) && BSK_PAIR_ABLATE == 2   // timing only: no EnvTask at all
+#if defined(BSK_PAIR_ABLATE) && (BSK_PAIR_ABLATE == 2 || BSK_PAIR_ABLATE == 23)   // timing only: no EnvTask at all (23: nor the FSW chain)
             return;
 #endif
             double gk[PAIR_CHUNK], sk[PAIR_CHUNK];
             unsigned bandmask = 0u;
+            auto eval = [&](int k) __attribute__((always_inline)) {
+                const V3 r = mk(PL->rr[bb][0][k][lane], PL->rr[bb][1][k][lane], PL->rr[bb][2][k][lane]);
+                const V3 sig = mk(PL->rs[bb][0][k][lane], PL->rs[bb][1][k][lane], PL->rs[bb][2][k][lane]);
+                bool band;
+                power_eval<FULL>(a.power, sg, r, sig, kt.c, gk[k], sk[k], band);
+                bandmask |= band ? (1u << k) : 0u;
+            };
+            if (mm == PAIR_CHUNK) {                            // a whole chunk: the evaluations are independent chains in ONE
+#pragma unroll                                                 // scheduling region (each alone is a serial chain through rsq / rcp)
+                for (int k = 0; k < PAIR_CHUNK; ++k) eval(k);
+            } else {
 #pragma unroll
-            for (int k = 0; k < PAIR_CHUNK; ++k) {
-                gk[k] = 0.0; sk[k] = 1.0;
-                if (k < mm) {
-                    const V3 r = mk(PL->rr[bb][0][k][lane], PL->rr[bb][1][k][lane], PL->rr[bb][2][k][lane]);
-                    const V3 sig = mk(PL->rs[bb][0][k][lane], PL->rs[bb][1][k][lane], PL->rs[bb][2][k][lane]);
-                    bool band;
-                    power_eval<FULL>(a.power, sg, r, sig, kt.c, gk[k], sk[k], band);
-                    bandmask |= band ? (1u << k) : 0u;
+                for (int k = 0; k < PAIR_CHUNK; ++k) {
+                    gk[k] = 0.0; sk[k] = 1.0;
+                    if (k < mm) eval(k);
                 }
             }
 #if defined(BSK_PAIR_ABLATE) && BSK_PAIR_ABLATE == 1   // timing only: no drain
@@ -390,7 +399,21 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2) ? 2 :
             return q;
         };
         int cb = 0;                                        // ring buffer of this chunk
-        __syncthreads();                                   // the environment wave's Sun positions are in LDS
+#ifdef BSK_PAIR_DEBUG_WAIT
+        unsigned long long dbg_waitA = 0, dbg_waitB = 0, dbg_chain = 0;
+#endif
+#if defined(BSK_PAIR_ABLATE) && BSK_PAIR_ABLATE >= 4       // timing only: 4 = no barriers, the environment wave leaves at once;
+#define BSK_PAIR_SYNC() ((void)0)                           //              5 = no barriers, it idles (s_sleep) until the end
+        if (!isD) {
+#if BSK_PAIR_ABLATE == 5
+            for (int w = 0; w < substeps_eff * 8; ++w) __builtin_amdgcn_s_sleep(100);
+#endif
+            return;
+        }
+#else
+#define BSK_PAIR_SYNC() __syncthreads()
+#endif
+        BSK_PAIR_SYNC();                                   // the environment wave's Sun positions are in LDS
         if (isD) {
             // ---------------------------------------------------------------- dynamics wave
             while (j < substeps_eff) {
@@ -404,9 +427,15 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2) ? 2 :
 #pragma unroll
                     for (int k = 0; k < NRW; ++k) PL->box[12 + k][lane] = x.Om[k];
                 }
-                __syncthreads();                           // A: messages written; the previous chunk's ring complete
+#ifdef BSK_PAIR_DEBUG_WAIT
+                const unsigned long long wa0 = __builtin_readcyclecounter();
+#endif
+                BSK_PAIR_SYNC();                           // A: messages written; the previous chunk's ring complete
+#ifdef BSK_PAIR_DEBUG_WAIT
+                dbg_waitA += __builtin_readcyclecounter() - wa0;
+#endif
                 if (q.needB0) {
-                    __syncthreads();                       // B (same-tick chain): wait for the commands
+                    BSK_PAIR_SYNC();                       // B (same-tick chain): wait for the commands
                     read_cmd();
                 }
                 if constexpr (FULL) {
@@ -436,29 +465,41 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2) ? 2 :
                     PL->rr[cb][0][t][lane] = x.r.x; PL->rr[cb][1][t][lane] = x.r.y; PL->rr[cb][2][t][lane] = x.r.z;
                     PL->rs[cb][0][t][lane] = x.s.x; PL->rs[cb][1][t][lane] = x.s.y; PL->rs[cb][2][t][lane] = x.s.z;
                     if (t == 0 && q.needB) {               // B: the commands of this chunk's FSW tick are there
-                        __syncthreads();
+#ifdef BSK_PAIR_DEBUG_WAIT
+                        const unsigned long long w0 = __builtin_readcyclecounter();
+#endif
+                        BSK_PAIR_SYNC();
+#ifdef BSK_PAIR_DEBUG_WAIT
+                        dbg_waitB += __builtin_readcyclecounter() - w0;
+#endif
                         read_cmd();
                     }
                 }
                 if (m == 0 && q.needB) {                   // the t = 0 chunk has no step
-                    __syncthreads();
+                    BSK_PAIR_SYNC();
                     read_cmd();
                 }
                 cb ^= 1;
             }
-            __syncthreads();                               // the last chunk's ring is complete
-            __syncthreads();                               // ... and the environment wave has answered
+            BSK_PAIR_SYNC();                               // the last chunk's ring is complete
+            BSK_PAIR_SYNC();                               // ... and the environment wave has answered
             charge = PL->box[0][lane]; shadow = PL->box[1][lane]; sbr = PL->box[2][lane];
 #pragma unroll
             for (int k = 0; k < NRW; ++k) up[k] = PL->box[3 + k][lane];
             thr_cnt = (int)PL->box[7][lane];
             fsw_ran = PL->box[8][lane] != 0.0;
+#ifdef BSK_PAIR_DEBUG_WAIT
+            dbg_waitA_out = dbg_waitA; dbg_waitB_out = dbg_waitB;
+#endif
         } else {
             // ---------------------------------------------------------------- FSW + environment wave
             int pm = 0, pb = 0;                            // length / buffer of the chunk whose EnvTask ticks are still owed
             while (j < substeps_eff) {
                 const Chunk q = next_chunk();
-                __syncthreads();                           // A
+                BSK_PAIR_SYNC();                           // A
+#ifdef BSK_PAIR_DEBUG_WAIT
+                const unsigned long long c0 = __builtin_readcyclecounter();
+#endif
                 if (q.fsw_any) {
                     State<NRW> nav;
                     nav.r = mk(PL->box[0][lane], PL->box[1][lane], PL->box[2][lane]);
@@ -474,7 +515,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2) ? 2 :
                             for (int k = 0; k < NRW; ++k) nav.Om[k] = 0.0;
                         }
                     }
-#if !(defined(BSK_PAIR_ABLATE) && BSK_PAIR_ABLATE == 3)   // 3: timing only, no FSW chain
+#if !(defined(BSK_PAIR_ABLATE) && (BSK_PAIR_ABLATE == 3 || BSK_PAIR_ABLATE == 23))   // 3: timing only, no FSW chain
                     if constexpr (NRW > 0) {
                         if (q.cond) fsw_tick(nav, q.t_latch);
                     }
@@ -487,25 +528,31 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2) ? 2 :
                         PL->box[8][lane] = (double)thr_maxn;
                         PL->box[9][lane] = (double)thr_t0n;
                     }
-                    __syncthreads();                       // B (either timing): the commands are there
+#ifdef BSK_PAIR_DEBUG_WAIT
+                    dbg_chain += __builtin_readcyclecounter() - c0;
+#endif
+                    BSK_PAIR_SYNC();                       // B (either timing): the commands are there
                 }
                 tick += q.m;
                 env_ticks(pm, pb);                         // the PREVIOUS chunk's EnvTask, beside this chunk's integration
                 pm = q.m; pb = cb;
                 cb ^= 1;
             }
-            __syncthreads();                               // the last chunk's ring is complete
+            BSK_PAIR_SYNC();                               // the last chunk's ring is complete
             env_ticks(pm, pb);
             PL->box[0][lane] = charge; PL->box[1][lane] = shadow; PL->box[2][lane] = sbr;
 #pragma unroll
             for (int k = 0; k < NRW; ++k) PL->box[3 + k][lane] = up[k];
             PL->box[7][lane] = (double)thr_cnt;
             PL->box[8][lane] = fsw_ran ? 1.0 : 0.0;
+#ifdef BSK_PAIR_DEBUG_WAIT
+            PL->box[10][lane] = (double)(dbg_chain >> 4);
+#endif
 #ifdef BSK_PAIR_DEBUG_HWID
             { unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
               PL->box[9][lane] = (double)((hw & 0xFFFFu) | ((xcc & 0xFu) << 16)); }
 #endif
-            __syncthreads();
+            BSK_PAIR_SYNC();
             return;                                        // the dynamics wave writes the launch's results
         }
     } else {
@@ -683,6 +730,12 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2) ? 2 :
     // wavefront reductions (every lane of the wave participates; tail lanes contribute nothing)
     const unsigned long long dmask = __ballot(valid2 && why != 0);
     const double rsum = wave_sum(valid2 ? rew : 0.0);
+#ifdef BSK_PAIR_DEBUG_WAIT
+    if constexpr (PAIR) {   // wait probe: cycles/16 the dynamics wave waited at B (bits 0-20), at A (21-41), the other wave's chain time (42-62)
+        const unsigned long long ch = (unsigned long long)((PairP)lds_dyn)->box[10][0];
+        if ((threadIdx.x & 63) == 0) { ta.done_mask[gid >> 6] = ((dbg_waitB_out >> 4) & 0x1FFFFFull) | (((dbg_waitA_out >> 4) & 0x1FFFFFull) << 21) | ((ch & 0x1FFFFFull) << 42); ta.wave_reward[gid >> 6] = rsum; }
+    } else
+#endif
 #ifdef BSK_PAIR_DEBUG_TIME
     if constexpr (PAIR) {   // residency probe: (this wave's start clock >> 10) | (end clock >> 10) << 32 instead of the done mask
         const unsigned long long t1 = __builtin_readcyclecounter();

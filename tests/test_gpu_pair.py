@@ -1,9 +1,7 @@
 """GPU: the pair form of the step kernel (two cooperating waves per 64 spacecraft: a dynamics wave and an FSW + environment
 wave exchanging through LDS; bsk_device.hpp: PairLds) against the single-wave form on the same inputs.  Same arithmetic per
-spacecraft, so the results must be IDENTICAL bit for bit wherever chunk boundaries do not enter the arithmetic (power level,
-full scenario without the Sun's third-body term); with the third body the tidal carry is anchored per chunk (4 ticks against
-10), which moves the last bits (bound 1e-13 here, 7e-15 measured).  Both forms are held to the oracle and the 50-digit goldens
-by the rest of the suite (the pair form is what small batches run by default for launches of >= 16 sub-steps)."""
+spacecraft in the same chunks of the tick loop (the Sun's tidal carry is anchored per chunk), so the results must be IDENTICAL
+bit for bit at every level.  Both forms are held to the oracle and the 50-digit goldens by the rest of the suite (the pair form is what small batches run by default for launches of >= 16 sub-steps)."""
 import os
 
 import numpy as np
@@ -51,7 +49,7 @@ def test_pair_form_equals_single_wave_form(level, n_rw, grav, lags):
     a.reset(ic)
     b.reset(ic)
     rng = np.random.default_rng(4)
-    tol = 1e-13 if level == "full" else 0.0
+    tol = 0.0
     for call, k in enumerate((1, 16, 20, 37, 3, 180, 7, 64)):     # below and above one FSW period, not multiples of the chunk
         act = rng.integers(0, 3, n).astype(np.int32)
         a.step(act, k)
