@@ -493,6 +493,12 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2) ? 2 :
 #endif
         } else {
             // ---------------------------------------------------------------- FSW + environment wave
+            // It has a fifth of the other wave's instructions and sits on its critical path (commands at every FSW tick, a ring
+            // buffer per chunk): where it shares a SIMD with a dynamics wave it must not queue behind it.
+#ifndef BSK_PAIR_PRIO
+#define BSK_PAIR_PRIO 3
+#endif
+            __builtin_amdgcn_s_setprio(BSK_PAIR_PRIO);
             int pm = 0, pb = 0;                            // length / buffer of the chunk whose EnvTask ticks are still owed
             while (j < substeps_eff) {
                 const Chunk q = next_chunk();

@@ -226,3 +226,26 @@ def test_profile_keys():
     assert b.profile_key(b.parse(["--envs", "4194304"]), False) == "4m_k1"
     assert b.profile_key(b.parse(["--envs", "1000"]), False) is None
     assert b.profile_key(b.parse(["--features", "power"]), False) is None
+
+
+def test_with_deadline_returns_fn_result_and_fires_only_on_overrun():
+    """The watchdog around the auxiliary RCCL leg: quiet when the leg returns in time (and it must not fire later), loud
+    when it does not; an exception in the leg is passed on and disarms it too."""
+    import threading
+    import time
+    b = _load_bench()
+    fired = threading.Event()
+    assert b.with_deadline(0.2, fired.set, lambda: 41 + 1) == 42
+    time.sleep(0.4)
+    assert not fired.is_set()
+    assert b.with_deadline(0.05, fired.set, lambda: (time.sleep(0.3), "late")[1]) == "late"
+    assert fired.is_set()
+    fired.clear()
+    try:
+        b.with_deadline(0.2, fired.set, lambda: 1 // 0)
+    except ZeroDivisionError:
+        pass
+    else:
+        raise AssertionError("the leg's exception was swallowed")
+    time.sleep(0.4)
+    assert not fired.is_set()
