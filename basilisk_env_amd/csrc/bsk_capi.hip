@@ -409,6 +409,10 @@ struct bsk_handle {
     // form up to three pairs per CU, 1.6x slower at four (65 536).  BSKGPU_PAIR=0 / 1 forces it off / on for every launch.
     bool pair_ok = false, last_pair = false;
     int pair_min_substeps = 16, pair_max_envs = 16384;
+    // three-wave form (bsk_device.hpp: TriX): the pair form with the dynamics wave cut into a translational and a rotational
+    // wave; full-scenario level only, preferred over the pair form where both apply.  BSKGPU_TRI=0 / 1 forces it off / on.
+    bool tri_ok = false, last_tri = false;
+    int tri_min_substeps = 16, tri_max_envs = 16384;
 };
 
 namespace {
@@ -513,8 +517,10 @@ int do_step(bsk_handle* h, const int* d_actions, int substeps) {
             e1 = h->ev_warm[1];
         }
     }
-    h->sp.pair = (h->pair_ok && substeps >= h->pair_min_substeps && h->n <= h->pair_max_envs) ? 1 : 0;
+    h->sp.tri = (h->tri_ok && substeps >= h->tri_min_substeps && h->n <= h->tri_max_envs) ? 1 : 0;
+    h->sp.pair = (!h->sp.tri && h->pair_ok && substeps >= h->pair_min_substeps && h->n <= h->pair_max_envs) ? 1 : 0;
     h->last_pair = h->sp.pair != 0;
+    h->last_tri = h->sp.tri != 0;
     HIP_TRY(bsk::launch_step(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp.feat, h->sp, b, h->block, h->stream, e0, e1));
     return BSK_OK;
 }
@@ -667,6 +673,12 @@ int bsk_create(const bsk_config* cfg, int n_envs, int device_id, void* stream, b
         const int v = std::atoi(pv);
         if (v == 0) h->pair_ok = false;
         else { h->pair_min_substeps = 1; h->pair_max_envs = 1 << 28; }   // every launch (measurement / tests)
+    }
+    h->tri_ok = bsk::tri_available(cfg->gravity_model, h->diag, h->sp.feat);
+    if (const char* tv = std::getenv("BSKGPU_TRI")) {
+        const int v = std::atoi(tv);
+        if (v == 0) h->tri_ok = false;
+        else { h->tri_min_substeps = 1; h->tri_max_envs = 1 << 28; }     // every launch (measurement / tests)
     }
     if (stream) { h->stream = (hipStream_t)stream; h->own_stream = false; }
     else {
@@ -1065,7 +1077,7 @@ int bsk_kernel_info(bsk_handle* h, char* name, int name_cap, int* vgprs, int* ld
     DeviceGuard guard(h->device);
     const bool sh = h->cfg.gravity_model == BSK_GRAV_SH;
     // (the kernel of the LAST launch: the pair form is chosen per launch by its number of sub-steps)
-    const void* fp = bsk::step_kernel_ptr(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp.feat, h->sp.sh_form, h->last_pair);
+    const void* fp = bsk::step_kernel_ptr(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp.feat, h->sp.sh_form, h->last_pair, h->last_tri);
     if (!fp) return fail(BSK_EINVAL, "no kernel variant for this config");
     hipFuncAttributes at;
     HIP_TRY(hipFuncGetAttributes(&at, fp));
@@ -1073,15 +1085,15 @@ int bsk_kernel_info(bsk_handle* h, char* name, int name_cap, int* vgprs, int* ld
         std::snprintf(name, name_cap, "step_kernel<%s,%d,%s>",
                       h->cfg.gravity_model == BSK_GRAV_PM ? "PM" : (h->cfg.gravity_model == BSK_GRAV_PM_J2 ? "PM_J2" : (h->sp.sh_form == 5 ? "SH/dpp2" : (h->sp.sh_form == 4 ? "SH/dpp" : "SH/scalar"))), h->cfg.n_rw,
                       h->sp.feat >= 2 ? (h->sp.feat == 3 ? (h->diag ? "diag,scenario/generic-facets" : "full,scenario/generic-facets")
-                                                         : (h->last_pair ? "diag,scenario,pair" : (h->diag ? "diag,scenario" : "full,scenario")))
+                                                         : (h->last_tri ? "diag,scenario,tri" : (h->last_pair ? "diag,scenario,pair" : (h->diag ? "diag,scenario" : "full,scenario"))))
                                       : (h->sp.feat == 1 ? (h->last_pair ? "diag,power,pair" : (h->diag ? "diag,power" : "full,power"))
                                                          : (h->sp.feat == -1 ? (h->diag ? "diag,lds-scratch" : "full,lds-scratch") : (h->diag ? "diag" : "full"))));
     if (vgprs) *vgprs = at.numRegs;
     if (lds_bytes) *lds_bytes = (int)at.sharedSizeBytes;
     // the two-wave harmonics form launches 256-thread workgroups of 2 x 64 spacecraft x 2 halves
-    const int blk = (sh && h->sp.sh_form == 5) ? 256 : (h->last_pair ? 128 : h->block);
+    const int blk = (sh && h->sp.sh_form == 5) ? 256 : (h->last_tri ? 192 : (h->last_pair ? 128 : h->block));
     if (block) *block = blk;
-    if (grid) *grid = (sh && h->sp.sh_form == 5) ? (h->n + 127) / 128 : (h->last_pair ? (h->n + 63) / 64 : (h->n + blk - 1) / blk);
+    if (grid) *grid = (sh && h->sp.sh_form == 5) ? (h->n + 127) / 128 : ((h->last_pair || h->last_tri) ? (h->n + 63) / 64 : (h->n + blk - 1) / blk);
     return BSK_OK;
 }
 

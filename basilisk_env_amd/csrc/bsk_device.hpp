@@ -473,6 +473,120 @@ struct PairLds {
 };
 typedef PairLds __attribute__((address_space(3))) * PairP;
 
+constexpr int PART_ALL = 0, PART_ROT = 1, PART_TRA = 2;   // which half of the spacecraft a wave integrates
+
+// Three-wave form (SPLIT == 3; round 3): the pair form with its dynamics wave cut in two - a translational wave (r, v) and a
+// rotational wave (sigma, omega, wheels) of the SAME 64 spacecraft, each on its own SIMD.  For batches that leave SIMDs idle
+// (one workgroup per CU and fewer) an env step is a serial chain of 1 800 ticks, and this shortens the chain: the two halves
+// are coupled only through the drag / thrust rotation (attitude -> force) and the drag torque (velocity -> torque), three
+// doubles each way per integrator stage.  They are exchanged through this block WITHOUT a barrier (the third wave must not
+// take part, and a barrier would put a round trip on the critical path of every stage):
+//  * the k-th value a wave publishes goes to slot k & 3 - its rows first, then the slot's per-lane tag k + 1; the k-th value
+//    the partner consumes is read from the same slot - the tag FIRST, the rows after it, in one batch - and accepted when
+//    every lane's tag is k + 1.  LDS operations of one wave execute in order, so a current tag implies current rows;
+//  * a value is published as soon as it exists (the next stage's attitude right after the kinematics, long before the stage's
+//    torque is known) and its reads are issued a stage's independent work ahead of its first use (`prefetch` / `finish`), so
+//    that in the steady state neither wave waits: the partner's value has been sitting in LDS for tens of instructions;
+//  * four slots: a wave overwrites slot k & 3 with value k + 4 only after it has consumed the partner's value k + 2 or later,
+//    which the partner published after consuming value k (rk4_step_part's order of publish / consume per stage);
+//  * a poll that does not see its tag within TRI_SPIN_LIMIT reads gives up for the rest of the launch and raises `err` (the
+//    observation is then NaN): every wave reaches the end of the kernel whatever the other one does.
+constexpr int TRI_SPIN_LIMIT = 1 << 20;
+struct TriX {
+    double v[4][4][64];                       // translational -> rotational: stage velocity; row 3: the next tick's density
+    double s[4][3][64];                       // rotational -> translational: stage attitude
+    int tv[4][64], ts[4][64];                 // per-lane tags of the slots
+    int err, pad0_;
+    int pad_[4];                              // (probe builds: two 64-bit words)
+};
+struct TriLds {
+    PairLds p;
+    TriX x;
+};
+typedef TriX __attribute__((address_space(3))) * TriXP;
+typedef TriLds __attribute__((address_space(3))) * TriP;
+
+// The exchange's LDS accesses are RELAXED ATOMICS of workgroup scope: the compiler neither merges, drops nor reorders them
+// against each other, and - unlike volatile accesses, each of which it follows with a wait for its completion - it leaves
+// a batch of reads in flight until the first use of a result.
+__device__ __forceinline__ void tri_st(double __attribute__((address_space(3))) * p, double v) {
+    __hip_atomic_store((long long __attribute__((address_space(3)))*)p, __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ double tri_ld(const double __attribute__((address_space(3))) * p) {
+    return __longlong_as_double(__hip_atomic_load((long long __attribute__((address_space(3)))*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+__device__ __forceinline__ void tri_sti(int __attribute__((address_space(3))) * p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int tri_ldi(int __attribute__((address_space(3))) * p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+struct TriPend {     // a consume in flight
+    int tag;
+    V3 a;
+    double e;
+};
+template <int PART>
+struct TriXch {
+    TriXP X;
+    int lane;
+    int np, nc;     // values published / consumed (wave-uniform)
+    bool dead;      // a poll timed out: no more waiting in this launch
+#ifdef BSK_TRI_DEBUG
+    unsigned dbg_miss = 0, dbg_spin = 0;          // finishes whose first read was early; re-reads
+    unsigned long long dbg_cyc = 0;               // cycles spent re-reading
+#endif
+    template <bool EXTRA>
+    __device__ __forceinline__ void publish(V3 a, double extra) {
+        const int slot = np & 3;
+        if constexpr (PART == PART_TRA) {
+            tri_st(&X->v[slot][0][lane], a.x); tri_st(&X->v[slot][1][lane], a.y); tri_st(&X->v[slot][2][lane], a.z);
+            if constexpr (EXTRA) tri_st(&X->v[slot][3][lane], extra);
+            tri_sti(&X->tv[slot][lane], np + 1);
+        } else {
+            tri_st(&X->s[slot][0][lane], a.x); tri_st(&X->s[slot][1][lane], a.y); tri_st(&X->s[slot][2][lane], a.z);
+            tri_sti(&X->ts[slot][lane], np + 1);
+        }
+        ++np;
+    }
+    template <bool EXTRA>
+    __device__ __forceinline__ TriPend prefetch() const {
+        const int slot = nc & 3;
+        TriPend f;
+        f.e = 0.0;
+        if constexpr (PART == PART_TRA) {
+            f.tag = tri_ldi(&X->ts[slot][lane]);
+            f.a = mk(tri_ld(&X->s[slot][0][lane]), tri_ld(&X->s[slot][1][lane]), tri_ld(&X->s[slot][2][lane]));
+        } else {
+            f.tag = tri_ldi(&X->tv[slot][lane]);
+            f.a = mk(tri_ld(&X->v[slot][0][lane]), tri_ld(&X->v[slot][1][lane]), tri_ld(&X->v[slot][2][lane]));
+            if constexpr (EXTRA) f.e = tri_ld(&X->v[slot][3][lane]);
+        }
+        return f;
+    }
+    template <bool EXTRA>
+    __device__ __forceinline__ V3 finish(TriPend f, double& extra) {
+        const int want = nc + 1;
+        if (BSK_UNLIKELY(__builtin_amdgcn_ballot_w64(f.tag != want) != 0)) {
+#ifdef BSK_TRI_DEBUG
+            ++dbg_miss;
+            const unsigned long long c0 = __builtin_readcyclecounter();
+#endif
+            for (int spin = 0; !dead; ++spin) {
+                f = prefetch<EXTRA>();
+#ifdef BSK_TRI_DEBUG
+                ++dbg_spin;
+#endif
+                if (__builtin_amdgcn_ballot_w64(f.tag != want) == 0) break;
+                if (spin > TRI_SPIN_LIMIT) { dead = true; X->err = 1; }
+            }
+#ifdef BSK_TRI_DEBUG
+            dbg_cyc += __builtin_readcyclecounter() - c0;
+#endif
+        }
+        ++nc;
+        if constexpr (EXTRA) extra = f.e;
+        return f.a;
+    }
+};
+
 // ---------------------------------------------------------------------------------------------------------
 // Wave-uniform constants as DPP broadcast operands (full-scenario kernels).  These kernels need ~45 doubles that
 // are the same in every lane (wheel geometry, facet tables, panel normal, atmosphere) on top of the RK4 loop's
@@ -1096,11 +1210,14 @@ __device__ __forceinline__ void thr_masks(Env& ev) {
     thr_row(ev.cold, m0, ev.FB0, ev.LB0);
 }
 // thrust of the active thrusters at integrator stage `de2` (0, 1, 1, 2 half dyn steps after the tick started)
+// PART (three-wave form): 0 = force and torque, PART_ROT = the torque only, PART_TRA = the force only
+template <int PART = PART_ALL>
 __device__ __forceinline__ void thrusters(const Env& ev, int de2, V3 sig, V3& aN, V3& LB) {
     V3 FB = ev.FB0;
     LB = ev.LB0;
     const int mk_ = de2 == 0 ? ev.m0 : (de2 == 1 ? ev.m1 : ev.m2);
     if (mk_ != ev.m0) thr_row(ev.cold, mk_, FB, LB);      // a pulse ends inside this dyn step
+    if constexpr (PART == PART_ROT) { aN = mk(0, 0, 0); return; }
     const double q2 = dot(sig, sig), op = 1.0 + q2, iop2 = rcp_nr(op * op);
     const V3 u1 = cross(sig, FB), u2 = cross(sig, u1);
     const V3 FN = FB + (8.0 * iop2) * u2 + (4.0 * (1.0 - q2) * iop2) * u1;                      // [BN]^T F_B
@@ -1112,8 +1229,11 @@ __device__ __forceinline__ void thrusters(const Env& ev, int de2, V3 sig, V3& aN
 // Rc = sum c_i (n_i . v)+ r_i need the body frame; the force is along -v in ANY frame, so the
 // inertial acceleration is -(1/2 rho S / m) v_N with no rotation back, and L_B = Rc x (-1/2 rho v_B).
 // Accumulates the acceleration into aN and the torque into LB.
-template <bool GENERIC>
+// PART_TRA / PART_ROT: only the projected-area sum and the acceleration / only its moment and the torque (each accumulator
+// takes the same terms in the same order as in the whole form)
+template <bool GENERIC, int PART = PART_ALL>
 __device__ __forceinline__ void facet_drag(const Env& ev, V3 sig, V3 vN, V3& aN, V3& LB) {
+    static_assert(PART == PART_ALL || !GENERIC, "the halves exist for the axis-aligned facet tables only");
     const double q2 = dot(sig, sig), op = 1.0 + q2, iop2 = rcp_nr(op * op);
     const double ka = 8.0 * iop2, kb = 4.0 * (1.0 - q2) * iop2;
     const V3 t1 = cross(sig, vN), t2 = cross(sig, t1);
@@ -1131,6 +1251,18 @@ __device__ __forceinline__ void facet_drag(const Env& ev, V3 sig, V3 vN, V3& aN,
         // is padded with s_nop); the area table carries 1/m, so Sm = S / m.
         const double tb = ev.kt.b;
         double rx = 0.0, ry = 0.0, rz = 0.0;
+        if constexpr (PART == PART_TRA) {
+            S = fmac_k<KB_FAC + 3>(S, tb, vh.x);
+            S = fmac_k_abs<KB_FAC + 0>(S, tb, vh.x);
+            S = fmac_k<KB_FAC + 4>(S, tb, vh.y);
+            S = fmac_k_abs<KB_FAC + 1>(S, tb, vh.y);
+            S = fmac_k<KB_FAC + 5>(S, tb, vh.z);
+            S = fmac_k_abs<KB_FAC + 2>(S, tb, vh.z);
+        } else if constexpr (PART == PART_ROT) {
+            rx = fmac_k<KB_FAD + 3>(rx, tb, vh.x);     ry = fmac_k<KB_FAD + 4>(ry, tb, vh.y);     rz = fmac_k<KB_FAD + 5>(rz, tb, vh.z);
+            rx = fmac_k_abs<KB_FAD + 0>(rx, tb, vh.x); ry = fmac_k_abs<KB_FAD + 1>(ry, tb, vh.y); rz = fmac_k_abs<KB_FAD + 2>(rz, tb, vh.z);
+            Rc.x = rx; Rc.y = ry; Rc.z = rz;
+        } else {
         S = fmac_k<KB_FAC + 3>(S, tb, vh.x);       rx = fmac_k<KB_FAD + 3>(rx, tb, vh.x);
         ry = fmac_k<KB_FAD + 4>(ry, tb, vh.y);     rz = fmac_k<KB_FAD + 5>(rz, tb, vh.z);
         S = fmac_k_abs<KB_FAC + 0>(S, tb, vh.x);   rx = fmac_k_abs<KB_FAD + 0>(rx, tb, vh.x);
@@ -1139,6 +1271,7 @@ __device__ __forceinline__ void facet_drag(const Env& ev, V3 sig, V3 vN, V3& aN,
         S = fmac_k_abs<KB_FAC + 1>(S, tb, vh.y);   Rc.y = ry;
         S = fmac_k<KB_FAC + 5>(S, tb, vh.z);       Rc.z = rz;
         S = fmac_k_abs<KB_FAC + 2>(S, tb, vh.z);
+        }
     } else if (ev.facet_axis == 1) {
         const ColdCfg* cc = ev.cold;
         const double vk[3] = {vh.x, vh.y, vh.z};
@@ -1161,9 +1294,11 @@ __device__ __forceinline__ void facet_drag(const Env& ev, V3 sig, V3 vN, V3& aN,
         }
     }
     const double kq = -0.5 * ev.rho;                      // 0 for a lane above the atmosphere
-    LB = add_cross(LB, Rc, kq * vB);
-    if (!GENERIC) aN = axpy(S * kq, vN, aN);                        // S already carries 1/m
-    else aN = axpy(mul_k<KC_IMASS>(ev.kt.c, S) * kq, vN, aN);
+    if constexpr (PART != PART_TRA) LB = add_cross(LB, Rc, kq * vB);
+    if constexpr (PART != PART_ROT) {
+        if (!GENERIC) aN = axpy(S * kq, vN, aN);                        // S already carries 1/m
+        else aN = axpy(mul_k<KC_IMASS>(ev.kt.c, S) * kq, vN, aN);
+    }
 }
 
 // Integration state inside one RK4 step.  The hub sees the wheels only through their total
@@ -1181,24 +1316,33 @@ struct Core {
 // steps outside bursts - nearly all - carry no thruster code and no branch around it)
 // DRAGM: 0 = the drag switch is tested where it is used (one wave-uniform branch per stage), 1 / 2 = the tick loop has
 // picked the instantiation with / without drag, so that a stage is one branch-free scheduling region
-template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT, bool THR, int DRAGM = 0>
+// PART (three-wave form): PART_TRA evaluates r', v' only (x.s is then the OTHER wave's stage attitude), PART_ROT sigma', w', p'
+// only (x.v is the other wave's stage velocity); every value either half produces is computed by the operations of the whole
+// PH (the halves only): 1 = what does not need the other wave's value (r' and the gravity / Sun part of v'; sigma'),
+// 2 = the rest (drag and thrust; w', p'), 0 = everything
+template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT, bool THR, int DRAGM = 0, int PART = PART_ALL, int PH = 0>
 __device__ __forceinline__ void eom(const HotCfg<NRW, DIAG>& c, const Core& x, V3 rhs0, V3 T, double tsim, const Env& ev,
                                     int de2, Core& d) {
-    d.r = x.v;
+    static_assert(PH == 0 || PART != PART_ALL, "phases exist for the halves");
+    if constexpr (PART != PART_ROT && PH != 2) d.r = x.v;
     if constexpr (is_full<FEAT>()) {
         // Sun third body, unconditionally: with the flag off k and A0 are zero and both FMAs return their addend
-        d.v = tidal(ev.s3, x.r, gravity<GRAV, SPLIT>(c, x.r, tsim, ev.s3.A0));
-        if constexpr (DRAGM == 1) facet_drag<FEAT == FEAT_FULLG>(ev, x.s, x.v, d.v, rhs0);
-        else if constexpr (DRAGM == 0) { if (BSK_LIKELY(ev.drag_on)) facet_drag<FEAT == FEAT_FULLG>(ev, x.s, x.v, d.v, rhs0); }
-        if constexpr (THR) {
-            V3 aN, LB;
-            thrusters(ev, de2, x.s, aN, LB);
-            d.v = d.v + aN;
-            rhs0 = rhs0 + LB;
+        if constexpr (PART != PART_ROT && PH != 2) d.v = tidal(ev.s3, x.r, gravity<GRAV, SPLIT>(c, x.r, tsim, ev.s3.A0));
+        if constexpr (PH != 1) {
+            if constexpr (DRAGM == 1) facet_drag<FEAT == FEAT_FULLG, PART>(ev, x.s, x.v, d.v, rhs0);
+            else if constexpr (DRAGM == 0) { if (BSK_LIKELY(ev.drag_on)) facet_drag<FEAT == FEAT_FULLG, PART>(ev, x.s, x.v, d.v, rhs0); }
+            if constexpr (THR) {
+                V3 aN, LB;
+                thrusters<PART>(ev, de2, x.s, aN, LB);
+                if constexpr (PART != PART_ROT) d.v = d.v + aN;
+                if constexpr (PART != PART_TRA) rhs0 = rhs0 + LB;
+            }
         }
     } else {
-        d.v = gravity<GRAV, SPLIT>(c, x.r, tsim, mk(0, 0, 0));
+        if constexpr (PART != PART_ROT && PH != 2) d.v = gravity<GRAV, SPLIT>(c, x.r, tsim, mk(0, 0, 0));
     }
+    if constexpr (PART == PART_TRA) return;
+    if constexpr (PH != 2) {
     // sigma' = 1/4 [(1 - s^2) w + 2 s x w + 2 (s.w) s],  with hw = w/2:
     //        = (1 - s^2)/2 hw + s x hw + (s.hw) s
     V3 hw = 0.5 * x.w;
@@ -1208,6 +1352,8 @@ __device__ __forceinline__ void eom(const HotCfg<NRW, DIAG>& c, const Core& x, V
     d.s = V3{fma(a, hw.x, fma(b, x.s.x, fma(x.s.y, hw.z, -(x.s.z * hw.y)))),
              fma(a, hw.y, fma(b, x.s.y, fma(x.s.z, hw.x, -(x.s.x * hw.z)))),
              fma(a, hw.z, fma(b, x.s.z, fma(x.s.x, hw.y, -(x.s.y * hw.x))))};
+    }
+    if constexpr (PH == 1) return;
     V3 H;
     if constexpr (NRW > 0) {
         if constexpr (DIAG) H = V3{fma(c.I[0], x.w.x, x.p.x), fma(c.I[1], x.w.y, x.p.y), fma(c.I[2], x.w.z, x.p.z)};
@@ -1222,13 +1368,17 @@ __device__ __forceinline__ void eom(const HotCfg<NRW, DIAG>& c, const Core& x, V
     }
 }
 
-template <int NRW>
+template <int NRW, int PART = PART_ALL>
 __device__ __forceinline__ void core_axpy(double a, const Core& k, const Core& x, Core& o) {
-    o.r = axpy(a, k.r, x.r);
-    o.v = axpy(a, k.v, x.v);
-    o.s = axpy(a, k.s, x.s);
-    o.w = axpy(a, k.w, x.w);
-    if constexpr (NRW > 0) o.p = axpy(a, k.p, x.p);
+    if constexpr (PART != PART_ROT) {
+        o.r = axpy(a, k.r, x.r);
+        o.v = axpy(a, k.v, x.v);
+    }
+    if constexpr (PART != PART_TRA) {
+        o.s = axpy(a, k.s, x.s);
+        o.w = axpy(a, k.w, x.w);
+        if constexpr (NRW > 0) o.p = axpy(a, k.p, x.p);
+    }
 }
 
 // RK4 accumulator staged in LDS (FEAT_LDSS): acc[f][lane], one 512-byte row per component and wave, every lane
@@ -1328,6 +1478,130 @@ __device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, const WV& w
     x.r = yt.r; x.v = yt.v; x.s = yt.s; x.w = yt.w;
     double s2 = dot(x.s, x.s);
     if (BSK_UNLIKELY(s2 > 1.0)) x.s = (-rcp_nr(s2)) * x.s;
+}
+
+// ---- three-wave form (SPLIT == 3): the RK4 step of one half of the spacecraft (exchange protocol: TriX).
+// The translational half (r, v: gravity, Sun, drag force, thrust) needs the attitude of every stage for the drag and thrust
+// rotations, the rotational half (sigma, omega, wheel momentum: kinematics, Euler, drag and thruster torque, wheels) the
+// velocity.  Each wave integrates its own components with the operations of rk4_step, in its order per value; only WHEN a
+// value is computed differs: a stage first does what is independent of the partner (the reads of the partner's value in
+// flight meanwhile), the rotational wave publishes the NEXT stage's attitude as soon as the kinematics are through.
+//   rotational:    prefetch v(i) | sigma' -> acc.s, sigma(i+1) -> publish | finish v(i) | drag torque, w', p' -> acc, w(i+1), p(i+1)
+//   translational: prefetch sigma(i) | r', gravity, Sun -> acc.r, r(i+1) | finish sigma(i) | drag force -> acc.v, v(i+1) -> publish
+// The fourth stage publishes the NEXT tick's first-stage value (attitude after the MRP switch; velocity together with the
+// density at the new position); the tick loop publishes the first tick's before it starts.
+// Rotational half: `tq`, `T`, `p0`, `tqj` are the wheel terms of the tick (wv.head, evaluated by the tick loop while the
+// first-stage velocity v1 was in flight).  Translational half: `p1` unused; rho_next returns the next tick's density.
+template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT, bool THR, int DRAGM, int PART, class WV, class XC, class RHO>
+__device__ __forceinline__ void rk4_step_part(const HotCfg<NRW, DIAG>& c, const WV& wv, State<NRW>& x, V3 lext, double t0,
+                                              const Env& ev, XC& xc, V3 v1, const double* tq, V3 T, V3 pw, const double* tqj,
+                                              RHO&& density, double& rho_next) {
+    static_assert(PART == PART_ROT || PART == PART_TRA, "one half");
+    // a tick without drag and outside thruster bursts couples the halves through nothing: only the tick-boundary values
+    // are exchanged then (they carry the next tick's density, and they keep either wave within a tick of the other)
+    constexpr bool COUPLED = THR || DRAGM != 2;
+    Core y, k, cur, nxt, acc;
+    double none;
+    TriPend f;
+#define BSK_EOM(PH, Z, TS, DE) eom<GRAV, NRW, DIAG, FEAT, SPLIT, THR, DRAGM, PART, PH>(c, Z, rhs0, T, TS, ev, DE, k)
+    if constexpr (PART == PART_ROT) {
+        const V3 rhs0 = lext - T;
+        y.s = x.s; y.w = x.w; y.p = pw; y.v = v1;
+        // stage 1 (its velocity came with the tick's density: consumed by the tick loop)
+        BSK_EOM(1, y, t0, 0);
+        acc.s = axpy(c.h6, k.s, y.s);
+        nxt.s = axpy(c.h2, k.s, y.s);
+        if constexpr (COUPLED) xc.template publish<false>(nxt.s, 0.0);
+        BSK_EOM(2, y, t0, 0);
+        acc.w = axpy(c.h6, k.w, y.w); if constexpr (NRW > 0) acc.p = axpy(c.h6, k.p, y.p);
+        nxt.w = axpy(c.h2, k.w, y.w); if constexpr (NRW > 0) nxt.p = axpy(c.h2, k.p, y.p);
+        cur = nxt;
+        // stage 2
+        if constexpr (COUPLED) f = xc.template prefetch<false>();
+        BSK_EOM(1, cur, t0 + c.h2, 1);
+        acc.s = axpy(c.h3, k.s, acc.s);
+        nxt.s = axpy(c.h2, k.s, y.s);
+        if constexpr (COUPLED) xc.template publish<false>(nxt.s, 0.0);
+        if constexpr (COUPLED) cur.v = xc.template finish<false>(f, none);
+        BSK_EOM(2, cur, t0 + c.h2, 1);
+        acc.w = axpy(c.h3, k.w, acc.w); if constexpr (NRW > 0) acc.p = axpy(c.h3, k.p, acc.p);
+        nxt.w = axpy(c.h2, k.w, y.w); if constexpr (NRW > 0) nxt.p = axpy(c.h2, k.p, y.p);
+        cur = nxt;
+        // stage 3
+        if constexpr (COUPLED) f = xc.template prefetch<false>();
+        BSK_EOM(1, cur, t0 + c.h2, 1);
+        acc.s = axpy(c.h3, k.s, acc.s);
+        nxt.s = axpy(c.h, k.s, y.s);
+        if constexpr (COUPLED) xc.template publish<false>(nxt.s, 0.0);
+        if constexpr (COUPLED) cur.v = xc.template finish<false>(f, none);
+        BSK_EOM(2, cur, t0 + c.h2, 1);
+        acc.w = axpy(c.h3, k.w, acc.w); if constexpr (NRW > 0) acc.p = axpy(c.h3, k.p, acc.p);
+        nxt.w = axpy(c.h, k.w, y.w); if constexpr (NRW > 0) nxt.p = axpy(c.h, k.p, y.p);
+        cur = nxt;
+        // stage 4: the step's attitude, switched to the inner MRP set where needed, is the next tick's first-stage value
+        if constexpr (COUPLED) f = xc.template prefetch<false>();
+        BSK_EOM(1, cur, t0 + c.h, 2);
+        x.s = axpy(c.h6, k.s, acc.s);
+        const double s2 = dot(x.s, x.s);
+        if (BSK_UNLIKELY(s2 > 1.0)) x.s = (-rcp_nr(s2)) * x.s;
+        xc.template publish<false>(x.s, 0.0);
+        if constexpr (COUPLED) cur.v = xc.template finish<false>(f, none);
+        BSK_EOM(2, cur, t0 + c.h, 2);
+        nxt.w = axpy(c.h6, k.w, acc.w);
+        const V3 dw = nxt.w - y.w;
+        double base[NRW > 0 ? NRW : 1];
+        if constexpr (NRW > 0) {
+            wv.bases(c.h, tq, tqj, x.Om, base);
+            wv.tail(dw, base, x.Om);
+        }
+        x.w = nxt.w;
+    } else {
+        const V3 rhs0 = mk(0, 0, 0);
+        y.r = x.r; y.v = x.v;
+        // stage 1
+        f = xc.template prefetch<false>();
+        BSK_EOM(1, y, t0, 0);
+        acc.r = axpy(c.h6, k.r, y.r);
+        nxt.r = axpy(c.h2, k.r, y.r);
+        y.s = xc.template finish<false>(f, none);
+        BSK_EOM(2, y, t0, 0);
+        acc.v = axpy(c.h6, k.v, y.v);
+        nxt.v = axpy(c.h2, k.v, y.v);
+        if constexpr (COUPLED) xc.template publish<false>(nxt.v, 0.0);
+        cur = nxt;
+        // stage 2
+        if constexpr (COUPLED) f = xc.template prefetch<false>();
+        BSK_EOM(1, cur, t0 + c.h2, 1);
+        acc.r = axpy(c.h3, k.r, acc.r);
+        nxt.r = axpy(c.h2, k.r, y.r);
+        if constexpr (COUPLED) cur.s = xc.template finish<false>(f, none);
+        BSK_EOM(2, cur, t0 + c.h2, 1);
+        acc.v = axpy(c.h3, k.v, acc.v);
+        nxt.v = axpy(c.h2, k.v, y.v);
+        if constexpr (COUPLED) xc.template publish<false>(nxt.v, 0.0);
+        cur = nxt;
+        // stage 3
+        if constexpr (COUPLED) f = xc.template prefetch<false>();
+        BSK_EOM(1, cur, t0 + c.h2, 1);
+        acc.r = axpy(c.h3, k.r, acc.r);
+        nxt.r = axpy(c.h, k.r, y.r);
+        if constexpr (COUPLED) cur.s = xc.template finish<false>(f, none);
+        BSK_EOM(2, cur, t0 + c.h2, 1);
+        acc.v = axpy(c.h3, k.v, acc.v);
+        nxt.v = axpy(c.h, k.v, y.v);
+        if constexpr (COUPLED) xc.template publish<false>(nxt.v, 0.0);
+        cur = nxt;
+        // stage 4: the step's velocity goes out together with the density at the step's position
+        if constexpr (COUPLED) f = xc.template prefetch<false>();
+        BSK_EOM(1, cur, t0 + c.h, 2);
+        x.r = axpy(c.h6, k.r, acc.r);
+        rho_next = density(x.r);     // (a serial chain through rsq and exp: here, beside the reads in flight, not at the tick's end)
+        if constexpr (COUPLED) cur.s = xc.template finish<false>(f, none);
+        BSK_EOM(2, cur, t0 + c.h, 2);
+        x.v = axpy(c.h6, k.v, acc.v);
+        xc.template publish<true>(x.v, rho_next);
+    }
+#undef BSK_EOM
 }
 
 // --------------------------------------------------------------------------------------------

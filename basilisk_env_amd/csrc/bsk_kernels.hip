@@ -51,7 +51,7 @@ __device__ __forceinline__ int wave_min_uniform(int v) {
 // sums through LDS: twice the waves per SIMD at the same batch size, so one wave's loads and scalar
 // instructions overlap with the other's FMAs.  Only wave 0 stores.
 template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT>
-__global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2) ? 2 : (FEAT == FEAT_LDSS ? BSK_LDSS_WAVES : BSK_MIN_WAVES)) void step_kernel(const StepArgs<NRW, DIAG> a) {
+__global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPLIT == 3) ? 2 : (FEAT == FEAT_LDSS ? BSK_LDSS_WAVES : BSK_MIN_WAVES)) void step_kernel(const StepArgs<NRW, DIAG> a) {
     const HotCfg<NRW, DIAG>& c = a.hot;
     const ColdCfg* __restrict__ cold = a.cold;
 #ifdef BSK_PAIR_DEBUG_TIME
@@ -63,7 +63,10 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2) ? 2 :
     // SPLIT == 5: waves 0/1 of the workgroup carry spacecraft group 0 (halves 0/1 of the walk), waves 2/3 group 1
     // SPLIT == 2 (pair form, bsk_device.hpp: PairLds): a 128-thread workgroup = the dynamics wave and the FSW + environment
     // wave of the SAME 64 spacecraft
-    constexpr bool PAIR = SPLIT == 2;
+    // SPLIT == 3 (three-wave form, bsk_device.hpp: TriX): a 192-thread workgroup = the rotational wave, the FSW + environment
+    // wave and the translational wave of the same 64 spacecraft
+    constexpr bool TRI = SPLIT == 3;
+    constexpr bool PAIR = SPLIT == 2 || TRI;
     const int gid = (SPLIT == 5) ? (int)(blockIdx.x * 128 + (threadIdx.x >> 7) * 64 + (threadIdx.x & 63))
                   : PAIR ? (int)(blockIdx.x * 64 + (threadIdx.x & 63))
                          : (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -280,17 +283,27 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2) ? 2 :
 #endif
     if constexpr (PAIR) {
         static_assert(!PAIR || (FEAT >= FEAT_POWER && FEAT != FEAT_FULLG && GRAV != BSK_GRAV_SH), "pair form: power / full-scenario levels, point mass or J2");
+        static_assert(!TRI || FEAT == FEAT_FULL, "three-wave form: the full-scenario level");
         // ---- pair form: both waves run the SAME control flow on the same counters (every decision below is a function of
         // cnt / substeps / actions, identical in the two waves), so their barrier counts agree by construction; what each
         // wave does between two barriers depends on its role and contains no barrier.
         PairP PL = (PairP)lds_dyn;
         // wave 0: dynamics, wave 1: FSW + environment - swapped in every other group of 2^pair_shift workgroups, so that the
         // two waves a SIMD hosts (they come from different workgroups) are one of each kind
-        const bool isD = ((__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) ^ (int)(blockIdx.x >> a.pair_shift)) & 1) == 0;
+        // (three-wave form: wave 0 rotational half, wave 1 FSW + environment, wave 2 translational half)
+        const int wave_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const bool isD = TRI ? wave_id != 1 : ((wave_id ^ (int)(blockIdx.x >> a.pair_shift)) & 1) == 0;
+        TriXP TX = nullptr;
+        if constexpr (TRI) TX = (TriXP) & ((TriP)lds_dyn)->x;
         if (!isD) {
             PL->sun[0][lane] = sg.sun.x; PL->sun[1][lane] = sg.sun.y; PL->sun[2][lane] = sg.sun.z;
             PL->lext[0][lane] = lext.x; PL->lext[1][lane] = lext.y; PL->lext[2][lane] = lext.z;
             if (lane == 0) PL->qcount = 0;
+            if constexpr (TRI) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { TX->tv[k][lane] = 0; TX->ts[k][lane] = 0; }   // (LDS keeps the previous launch's tags)
+                if (lane == 0) TX->err = 0;
+            }
         }
         const double draw = a.power.draw, cap = a.power.cap;
         // the environment wave's share of a chunk: eclipse -> panel of each recorded tick, cooperative drain of the
@@ -414,7 +427,128 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2) ? 2 :
 #define BSK_PAIR_SYNC() __syncthreads()
 #endif
         BSK_PAIR_SYNC();                                   // the environment wave's Sun positions are in LDS
-        if (isD) {
+        if constexpr (TRI) {
+          if (isD) {
+            // ------------------------------------------------- rotational / translational wave (one loop per role: a shared
+            // loop would keep the union of both halves' registers live)
+            auto dyn_part = [&](auto ROLE) __attribute__((always_inline)) {
+                constexpr int PART = decltype(ROLE)::value;
+                constexpr bool ROT = PART == PART_ROT;
+                TriXch<PART> xc{TX, lane, 0, 0, false};
+#if defined(BSK_TRI_ABLATE)                                // timing only: neither wave waits for the other (stale values)
+                xc.dead = true;
+                const unsigned long long abl_t0 = __builtin_readcyclecounter();
+#endif
+                // exponentialAtmosphere at a position (the arithmetic of the single-wave tick loop), 0 below the skip density
+                auto density = [&](V3 r) __attribute__((always_inline)) {
+                    double rho = 0.0;
+                    if (drag_cfg) {
+                        const double r2 = dot(r, r), rm = r2 * rsqrt_nr(r2);
+                        const double rh = mul_k<KC_RHO0>(kt.c, exp_fast(fmac_k<KC_NIH>(get_k<KC_REQIH>(kt.c), kt.c, rm)));
+                        rho = rh >= get_k<KC_RSKIP>(kt.c) ? rh : 0.0;
+                    }
+                    return rho;
+                };
+                // the first tick's first-stage values (every later tick's are published by the step before it)
+                if constexpr (ROT) xc.template publish<false>(x.s, 0.0);
+                else { ev.rho = density(x.r); xc.template publish<true>(x.v, ev.rho); }
+                while (j < substeps_eff) {
+                    const Chunk q = next_chunk();
+                    const int m = q.m;
+                    if (q.fsw_any) {                       // each half's share of the navigation / wheel-speed messages
+                        if constexpr (ROT) {
+                            PL->box[6][lane] = x.s.x; PL->box[7][lane] = x.s.y; PL->box[8][lane] = x.s.z;
+                            PL->box[9][lane] = x.w.x; PL->box[10][lane] = x.w.y; PL->box[11][lane] = x.w.z;
+#pragma unroll
+                            for (int k = 0; k < NRW; ++k) PL->box[12 + k][lane] = x.Om[k];
+                        } else {
+                            PL->box[0][lane] = x.r.x; PL->box[1][lane] = x.r.y; PL->box[2][lane] = x.r.z;
+                            PL->box[3][lane] = x.v.x; PL->box[4][lane] = x.v.y; PL->box[5][lane] = x.v.z;
+                        }
+                    }
+                    BSK_PAIR_SYNC();                       // A
+                    if (q.needB0) {
+                        BSK_PAIR_SYNC();                   // B (same-tick chain)
+                        read_cmd();
+                    }
+                    if constexpr (!ROT) {
+                        if (ev.sun_on) third_body_anchor(ev.s3, mk(PL->sun[0][lane], PL->sun[1][lane], PL->sun[2][lane]), a.extra.mu_sun, x.r);
+                    }
+                    for (int t = 0; t < m; ++t, ++tick) {
+                        V3 v1 = mk(0, 0, 0), Tw = mk(0, 0, 0), pw = mk(0, 0, 0);
+                        double tq[NRW > 0 ? NRW : 1], tqj[NRW > 0 ? NRW : 1];
+                        if constexpr (ROT) {
+                            // the first-stage velocity and the tick's density are on their way while the wheels' terms are formed
+                            const TriPend f = xc.template prefetch<true>();
+#pragma unroll
+                            for (int i = 0; i < NRW; ++i) {
+                                const double fs = fmin(fmax(x.Om[i] * 0x1p1000, -c.fc), c.fc);
+                                tq[i] = u[i] - fs;
+                            }
+                            if constexpr (NRW > 0) wv.head(tq, x.Om, Tw, pw, tqj);
+                            double rho = 0.0;
+                            v1 = xc.template finish<true>(f, rho);
+                            ev.rho = rho;
+                        }
+                        ev.drag_on = __builtin_amdgcn_ballot_w64(ev.rho != 0.0) != 0;
+                        if (desat) {
+                            ev.e2 = 2 * (tick - thr_t0);
+                            ev.thr_on = __builtin_amdgcn_ballot_w64(ev.thr_max > 0 && ev.e2 <= ev.thr_max) != 0;
+                            if (BSK_UNLIKELY(ev.thr_on)) thr_masks(ev);
+                        }
+                        const double tt = (double)tick * c.h;
+                        double rho_next = 0.0;
+#define BSK_TRI_STEP(THR, DRAGM) rk4_step_part<GRAV, NRW, DIAG, FEAT, SPLIT, THR, DRAGM, PART>(c, wv, x, lext, tt, ev, xc, v1, tq, Tw, pw, tqj, density, rho_next)
+                        if (BSK_LIKELY(!ev.thr_on)) {
+                            if (BSK_LIKELY(ev.drag_on)) BSK_TRI_STEP(false, 1);
+                            else BSK_TRI_STEP(false, 2);
+                        } else BSK_TRI_STEP(true, 0);
+#undef BSK_TRI_STEP
+                        if constexpr (!ROT) ev.rho = rho_next;
+                        if constexpr (ROT) {
+                            PL->rs[cb][0][t][lane] = x.s.x; PL->rs[cb][1][t][lane] = x.s.y; PL->rs[cb][2][t][lane] = x.s.z;
+                        } else {
+                            PL->rr[cb][0][t][lane] = x.r.x; PL->rr[cb][1][t][lane] = x.r.y; PL->rr[cb][2][t][lane] = x.r.z;
+                        }
+                        if (t == 0 && q.needB) {           // B: the commands of this chunk's FSW tick are there
+                            BSK_PAIR_SYNC();
+                            read_cmd();
+                        }
+                    }
+                    if (m == 0 && q.needB) {               // the t = 0 chunk has no step
+                        BSK_PAIR_SYNC();
+                        read_cmd();
+                    }
+                    cb ^= 1;
+                }
+                if constexpr (!ROT) {                      // the rotational wave writes the launch's results: it gets (r, v)
+                    PL->box[10][lane] = x.r.x; PL->box[11][lane] = x.r.y; PL->box[12][lane] = x.r.z;
+                    PL->box[13][lane] = x.v.x; PL->box[14][lane] = x.v.y; PL->box[15][lane] = x.v.z;
+                }
+#if defined(BSK_TRI_DEBUG) && defined(BSK_TRI_ABLATE)
+                { const unsigned long long w = (((__builtin_readcyclecounter() - abl_t0) >> 6) & 0xFFFFFFFFull) << 32;   // the free-running loop's cycles / 64
+                  if (lane == 0) ((volatile unsigned long long __attribute__((address_space(3)))*)&TX->pad_[0])[ROT ? 0 : 1] = w; }
+#elif defined(BSK_TRI_DEBUG)
+                // probe: misses (16 bits) | re-reads (16) | cycles / 64 spent re-reading (32), per wave
+                { const unsigned long long w = (unsigned long long)(xc.dbg_miss & 0xFFFFu) | ((unsigned long long)(xc.dbg_spin & 0xFFFFu) << 16) | (((xc.dbg_cyc >> 6) & 0xFFFFFFFFull) << 32);
+                  if (lane == 0) ((volatile unsigned long long __attribute__((address_space(3)))*)&TX->pad_[0])[ROT ? 0 : 1] = w; }
+#endif
+                BSK_PAIR_SYNC();                           // the last chunk's ring is complete
+                BSK_PAIR_SYNC();                           // ... and the environment wave has answered
+            };
+            if (wave_id == 0) dyn_part(std::integral_constant<int, PART_ROT>{});
+            else { dyn_part(std::integral_constant<int, PART_TRA>{}); return; }
+            x.r = mk(PL->box[10][lane], PL->box[11][lane], PL->box[12][lane]);
+            x.v = mk(PL->box[13][lane], PL->box[14][lane], PL->box[15][lane]);
+            charge = PL->box[0][lane]; shadow = PL->box[1][lane]; sbr = PL->box[2][lane];
+#pragma unroll
+            for (int k = 0; k < NRW; ++k) up[k] = PL->box[3 + k][lane];
+            thr_cnt = (int)PL->box[7][lane];
+            fsw_ran = PL->box[8][lane] != 0.0;
+            if (TX->err != 0) { sbr = __builtin_nan(""); charge = sbr; }   // an exchange timed out (cannot happen): fail loudly
+          }
+        }
+        if (isD && !TRI) {
             // ---------------------------------------------------------------- dynamics wave
             while (j < substeps_eff) {
                 const Chunk q = next_chunk();
@@ -491,7 +625,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2) ? 2 :
 #ifdef BSK_PAIR_DEBUG_WAIT
             dbg_waitA_out = dbg_waitA; dbg_waitB_out = dbg_waitB;
 #endif
-        } else {
+        } else if (!isD) {
             // ---------------------------------------------------------------- FSW + environment wave
             // It has a fifth of the other wave's instructions and sits on its critical path (commands at every FSW tick, a ring
             // buffer per chunk): where it shares a SIMD with a dynamics wave it must not queue behind it.
@@ -736,6 +870,12 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2) ? 2 :
     // wavefront reductions (every lane of the wave participates; tail lanes contribute nothing)
     const unsigned long long dmask = __ballot(valid2 && why != 0);
     const double rsum = wave_sum(valid2 ? rew : 0.0);
+#ifdef BSK_TRI_DEBUG
+    if constexpr (TRI) {    // exchange probe instead of the done mask: the rotational wave's word (BSK_TRI_DEBUG=1) or the translational wave's (=2)
+        volatile unsigned long long __attribute__((address_space(3)))* w = (volatile unsigned long long __attribute__((address_space(3)))*)&((TriP)lds_dyn)->x.pad_[0];
+        if ((threadIdx.x & 63) == 0) { ta.done_mask[gid >> 6] = w[BSK_TRI_DEBUG == 2 ? 1 : 0]; ta.wave_reward[gid >> 6] = rsum; }
+    } else
+#endif
 #ifdef BSK_PAIR_DEBUG_WAIT
     if constexpr (PAIR) {   // wait probe: cycles/16 the dynamics wave waited at B (bits 0-20), at A (21-41), the other wave's chain time (42-62)
         const unsigned long long ch = (unsigned long long)((PairP)lds_dyn)->box[10][0];
@@ -1007,9 +1147,10 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     a.tail.env_base = b.env_base; a.tail.pad_ = 0;
     if (SPLIT == 5) block = 256;
     if (SPLIT == 2) block = 128;      // pair form: dynamics wave + FSW / environment wave of the same 64 spacecraft
-    const int grid = SPLIT == 5 ? (b.n + 127) / 128 : (SPLIT == 2 ? (b.n + 63) / 64 : (b.n + block - 1) / block);
+    if (SPLIT == 3) block = 192;      // three-wave form: rotational, FSW / environment and translational wave
+    const int grid = SPLIT == 5 ? (b.n + 127) / 128 : ((SPLIT == 2 || SPLIT == 3) ? (b.n + 63) / 64 : (b.n + block - 1) / block);
     // the power system keeps a per-wave tick record and penumbra queue in dynamic LDS (bsk_device.hpp: PowerLds)
-    const size_t lds = SPLIT == 2 ? sizeof(PairLds)
+    const size_t lds = SPLIT == 3 ? sizeof(TriLds) : SPLIT == 2 ? sizeof(PairLds)
                      : FEAT >= FEAT_POWER ? sizeof(PowerLds) * (size_t)(block / 64)
                                           : (FEAT == FEAT_LDSS ? sizeof(AccLds) * (size_t)(block / 64) : 0);
     // hipExtLaunchKernelGGL stamps ev0/ev1 from the dispatch packet itself (no marker packets), so
@@ -1074,11 +1215,24 @@ static const void* pair_ptr() {
 bool pair_available(int grav, bool diag, int feat) {
     return diag && grav != BSK_GRAV_SH && (feat == FEAT_POWER || feat == FEAT_FULL);
 }
+// three-wave form (SPLIT == 3): the full-scenario level of the same kernels
+template <int G, int R, bool D, int P>
+static hipError_t launch_tri(const StepParams& p, const StepBuffers& b, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    if constexpr (D && G != BSK_GRAV_SH && P == FEAT_FULL) return launch_t<G, R, D, P, 3>(p, b, 192, s, ev0, ev1);
+    else return hipErrorInvalidValue;
+}
+template <int G, int R, bool D, int P>
+static const void* tri_ptr() {
+    if constexpr (D && G != BSK_GRAV_SH && P == FEAT_FULL) return (const void*)&step_kernel<G, R, D, P, 3>;
+    else return nullptr;
+}
+bool tri_available(int grav, bool diag, int feat) { return diag && grav != BSK_GRAV_SH && feat == FEAT_FULL; }
 
 hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams& p, const StepBuffers& b, int block,
                        hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
 #define CASE(G, R, D, P) \
     if (grav == G && nrw == R && diag == D && feat == P) {                                                 \
+        if (p.tri) return launch_tri<G, R, D, P>(p, b, s, ev0, ev1);                                        \
         if (p.pair) return launch_pair<G, R, D, P>(p, b, s, ev0, ev1);                                      \
         if (G == BSK_GRAV_SH && p.sh_form == 4) return launch_t<G, R, D, P, (G == BSK_GRAV_SH ? 4 : 1)>(p, b, block, s, ev0, ev1); \
         if (G == BSK_GRAV_SH && p.sh_form == 5) return launch_t<G, R, D, P, (G == BSK_GRAV_SH ? 5 : 1)>(p, b, block, s, ev0, ev1); \
@@ -1089,9 +1243,10 @@ hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams&
     return hipErrorInvalidValue;
 }
 
-const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat, int sh_form, bool pair) {
+const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat, int sh_form, bool pair, bool tri) {
 #define CASE(G, R, D, P) \
     if (grav == G && nrw == R && diag == D && feat == P) {                                                                     \
+        if (tri) return tri_ptr<G, R, D, P>();                                                                                 \
         if (pair) return pair_ptr<G, R, D, P>();                                                                               \
         if (G == BSK_GRAV_SH && sh_form == 4) return (const void*)&step_kernel<G, R, D, P, (G == BSK_GRAV_SH ? 4 : 1)>;        \
         if (G == BSK_GRAV_SH && sh_form == 5) return (const void*)&step_kernel<G, R, D, P, (G == BSK_GRAV_SH ? 5 : 1)>;        \

@@ -69,6 +69,7 @@ struct StepParams {
     int sh_form;            // 1 scalar-load stream, 4 DPP broadcast, 5 DPP broadcast over two cooperating waves
     int pair;               // this launch runs the pair form (dynamics wave + FSW / environment wave per 64 spacecraft)
     int pair_shift;
+    int tri;                // this launch runs the three-wave form (rotational / FSW + environment / translational wave)
     int feat;               // FEAT_BARE / FEAT_POWER / FEAT_FULL
     int fsw_lag, nav_lag;
     PowerCfg pc;
@@ -98,8 +99,9 @@ struct StepBuffers {
 
 hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams& p, const StepBuffers& b, int block,
                        hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
-const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat, int sh_form, bool pair);
+const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat, int sh_form, bool pair, bool tri = false);
 bool pair_available(int grav, bool diag, int feat);
+bool tri_available(int grav, bool diag, int feat);
 hipError_t launch_sample_pool(double* pool, int n_pool, int n_rw, unsigned long long seed, double mu, hipStream_t s);
 hipError_t launch_reset_from_pool(double* st, int64_t stride, int nf, const double* pool, int n_pool, const unsigned char* mask,
                                   int n, int2* cnt, int* episodes, unsigned env_base, hipStream_t s);

@@ -15,15 +15,19 @@ pytestmark = pytest.mark.gpu
 
 
 def make(cfg, n, pair):
-    old = os.environ.get("BSKGPU_PAIR")
+    """A propagator pinned to the pair form (every launch) or to the single-wave form; the three-wave form
+    (tests/test_gpu_tri.py), which the full-scenario level would otherwise prefer, is off."""
+    old = {k: os.environ.get(k) for k in ("BSKGPU_PAIR", "BSKGPU_TRI")}
     os.environ["BSKGPU_PAIR"] = "1" if pair else "0"
+    os.environ["BSKGPU_TRI"] = "0"
     try:
         return BatchedPropagator(cfg, n)
     finally:
-        if old is None:
-            del os.environ["BSKGPU_PAIR"]
-        else:
-            os.environ["BSKGPU_PAIR"] = old
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
 
 
 LEVELS = {"power": FLAG_POWER, "full-nosun": FLAG_POWER | FLAG_DRAG | FLAG_DESAT,
@@ -93,8 +97,9 @@ def test_pair_form_with_device_side_reset_and_default_selection():
             assert np.array_equal(x, y)
     a.close()
     b.close()
-    p = BatchedPropagator(cfg, n)                     # default rule
-    p.set_ic_pool(pool)
+    pcfg = default_config(4, GRAV_PM_J2)              # default rule at the power level (the full-scenario level prefers the
+    pcfg.flags |= FLAG_POWER                          # three-wave form: tests/test_gpu_tri.py)
+    p = BatchedPropagator(pcfg, n)
     p.reset(ic)
     p.step(act, 20)
     assert "pair" in p.kernel_info()["name"]

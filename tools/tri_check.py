@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Three-wave form of the step kernel against the single-wave form on the same inputs (GPU box).  BSKGPU_LIB may point at a
+variant library.  Prints max deviations; exits non-zero on a mismatch."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from basilisk_env_amd._lib import FLAG_DESAT, FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY, GRAV_PM_J2  # noqa: E402
+from basilisk_env_amd.simulators.dynamics import BatchedPropagator, default_config  # noqa: E402
+from basilisk_env_amd.simulators.initial_conditions.batch import sample_ic_batch  # noqa: E402
+
+
+def make(cfg, n, tri):
+    os.environ["BSKGPU_TRI"] = "1" if tri else "0"
+    os.environ["BSKGPU_PAIR"] = "0"
+    p = BatchedPropagator(cfg, n)
+    del os.environ["BSKGPU_TRI"], os.environ["BSKGPU_PAIR"]
+    return p
+
+
+quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+bad = 0
+for level, flags in (("full-nosun", FLAG_POWER | FLAG_DRAG | FLAG_DESAT), ("full", FLAG_POWER | FLAG_SUN_THIRD_BODY | FLAG_DRAG | FLAG_DESAT)):
+    for n_rw in (4, 3):
+        for n in ((64,) if quick else (64, 100, 1000)):
+            cfg = default_config(n_rw, GRAV_PM_J2)
+            cfg.flags |= flags
+            cfg.base_density, cfg.scale_height = 1e-9, 100e3
+            ic = sample_ic_batch(n, n_rw, seed=5)
+            ic[12:12 + n_rw, ::5] *= 4.0
+            a, b = make(cfg, n, False), make(cfg, n, True)
+            a.reset(ic); b.reset(ic)
+            rng = np.random.default_rng(1)
+            worst = 0.0
+            for k in ((1, 16) if quick else (1, 16, 20, 37, 3, 180, 1)):
+                act = rng.integers(0, 3, n).astype(np.int32)
+                t0 = time.time()
+                a.step(act, k); b.step(act, k)
+                sa, sb = a.get_state(), b.get_state()
+                oa, ob = a.get_obs(), b.get_obs()
+                scale = np.maximum(np.abs(sa).max(axis=1, keepdims=True), 1e-300)
+                dev = float((np.abs(sa - sb) / scale).max())
+                worst = max(worst, dev)
+                same_int = all(np.array_equal(x, y) for x, y in zip(a.get_counters(), b.get_counters())) and np.array_equal(oa[2], ob[2]) and np.array_equal(oa[3], ob[3])
+                odev = np.abs(oa[0] - ob[0]).max()
+                if not same_int or not (dev <= 0.0) or not (odev <= 0.0):
+                    bad += 1
+                    rows = np.argsort(-(np.abs(sa - sb) / scale).max(axis=1))[:4]
+                    print("MISMATCH", level, n_rw, n, "K", k, "state dev", dev, "obs dev", odev, "ints", same_int, "rows", rows.tolist(), "%.2fs" % (time.time() - t0), flush=True)
+            print("%-10s n_rw %d n %4d  max rel state dev %.2e  kernel %s" % (level, n_rw, n, worst, b.kernel_info()["name"]), flush=True)
+            a.close(); b.close()
+sys.exit(1 if bad else 0)
