@@ -65,7 +65,8 @@ def test_three_wave_form_equals_single_wave_form(atmosphere, n_rw, grav, lags):
         r = cfg.req + alt
         ic[0], ic[1], ic[2] = r, 0.0, 0.0
         vc = np.sqrt(cfg.mu / r)
-        ic[3], ic[4], ic[5] = 0.0, vc * np.cos(0.9), vc * np.sin(0.9)
+        ic[3], ic[4], ic[5] = -100.0, vc * np.cos(0.9), vc * np.sin(0.9)    # descending 100 m/s: the wave just above the
+        #                                                                       threshold crosses it during the run
     a, b = make(cfg, n, False), make(cfg, n, True)
     a.reset(ic)
     b.reset(ic)
