@@ -742,6 +742,16 @@ def main():
         extra["strong_65536_total"] = {"envs_per_gpu": ns, "k1_env_steps_per_s": ns * world * 500 / el5,
                                        "k1800_env_steps_per_s": ns * world * 3 / el6, "k1800_ms_per_step": el6 / 3 * 1e3}
         ps.close()
+        # ... and with the scenario the drop-in env runs (small shards run the three-wave form of the kernel)
+        cf = cfg.copy()
+        cf.flags |= scenario_flags("full")
+        pf = BatchedPropagator(cf, ns, device=local)
+        pf.reset(sample_ic_batch(ns, n_rw, seed=2000 + rank))
+        timed_run(pf, d_acts.data_ptr(), 1800, 2, 1, barrier, sync)
+        el7 = max_over_ranks(timed_run(pf, d_acts.data_ptr(), 1800, 5, 1, barrier, sync))
+        extra["strong_65536_total"].update({"full_k1800_env_steps_per_s": ns * world * 5 / el7, "full_k1800_ms_per_step": el7 / 5 * 1e3,
+                                            "full_k1800_kernel": pf.kernel_info()["name"]})
+        pf.close()
     if extra and rank == 0:
         out["extra"] = extra
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
