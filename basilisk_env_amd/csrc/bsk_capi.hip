@@ -406,11 +406,12 @@ struct bsk_handle {
     // pair form of the step kernel (bsk_device.hpp: PairLds): used for launches of >= pair_min_substeps sub-steps of batches
     // of <= pair_max_envs spacecraft where it is built (power / full-scenario levels, point mass or J2, diagonal hub).  Measured
     // (profiles/r03/pair_form.txt): -13 % per env step up to one pair per CU (16 384 spacecraft), level with the single-wave
-    // form up to three pairs per CU, 1.6x slower at four (65 536).  BSKGPU_PAIR=0 / 1 forces it off / on for every launch.
+    // form up to three pairs per CU, 7 % slower at four (65 536).  BSKGPU_PAIR=0 / 1 forces it off / on for every launch.
     bool pair_ok = false, last_pair = false;
     int pair_min_substeps = 16, pair_max_envs = 16384;
     // three-wave form (bsk_device.hpp: TriX): the pair form with the dynamics wave cut into a translational and a rotational
-    // wave; full-scenario level only, preferred over the pair form where both apply.  BSKGPU_TRI=0 / 1 forces it off / on.
+    // wave; full-scenario level only, preferred over the pair form where both apply (profiles/r03/tri_form.txt: -16 % against
+    // the pair form up to one workgroup per CU, twice the time above).  BSKGPU_TRI=0 / 1 forces it off / on.
     bool tri_ok = false, last_tri = false;
     int tri_min_substeps = 16, tri_max_envs = 16384;
 };
