@@ -294,8 +294,12 @@ int bsk_profile_end_samples(bsk_handle* h, double* mean_kernel_ms, int* n_launch
  * 78.6 TFLOP/s. */
 int bsk_calibrate_fp64(int device_id, int waves_per_simd, int repeats, double* tflops, double* ns_per_fma_per_simd);
 
-/* Kernel resource facts for DESIGN.md / bench: name of the kernel variant selected for this
- * handle, its VGPR count, static LDS bytes and the launch geometry. */
+/* Kernel resource facts for DESIGN.md / bench: name of the kernel variant the handle's LAST launch ran, its VGPR count, static
+ * LDS bytes and the launch geometry.  The variant is chosen per launch: batches of <= 16 384 spacecraft run launches of >= 16
+ * sub-steps in a wave-split form of the same arithmetic (bit-identical results: "...,pair" at the power level - a dynamics and
+ * an FSW + environment wave per 64 spacecraft, 128-thread workgroups - and "...,tri" at the full-scenario level - a
+ * translational, a rotational and the FSW + environment wave, 192-thread workgroups), everything else the
+ * single-wave form.  BSKGPU_PAIR / BSKGPU_TRI = 0 | 1 in the environment of bsk_create switch a form off / on for every launch. */
 int bsk_kernel_info(bsk_handle* h, char* name, int name_cap, int* vgprs, int* lds_bytes,
                     int* block, int* grid);
 
