@@ -220,7 +220,13 @@ class LeoPowerAttVecEnv(_Base):
         if self._actions is None:
             raise RuntimeError("step_wait() without a pending step_async()")
         self._actions = None
-        obs, rew, done, why = self.propagator.get_obs()
+        if getattr(self.propagator, "pinned_read_back", False):
+            # views of the propagator's page-locked read-back buffers (overwritten by the next step): everything this
+            # method returns is laid out afresh below
+            obs, rew, done, why = self.propagator.get_obs(copy=False)
+            rew = rew.copy()
+        else:                                          # sharded engine (pinned fan-in of its own), the tests' oracle stand-in
+            obs, rew, done, why = self.propagator.get_obs()
         self.episode_returns += rew
         # one fresh dict per env: a plain list for ordinary batch sizes, made on first access for very large ones
         infos = InfoList(self.num_envs) if self.num_envs > INFO_LAZY_ABOVE else [{} for _ in range(self.num_envs)]

@@ -90,6 +90,11 @@ class BatchedPropagator(object):
         if getattr(self, "_h", None):
             self._lib.bsk_destroy(self._h)
             self._h = None
+        pin = getattr(self, "_pin", None)
+        if pin is not None:
+            for b in pin["bufs"]:
+                b.free()
+            self._pin = None
 
     def __del__(self):
         try:
@@ -161,8 +166,26 @@ class BatchedPropagator(object):
     def step_device(self, d_actions_ptr, substeps):
         check(self._lib.bsk_step_device(self._handle(), C.c_void_p(int(d_actions_ptr)), int(substeps)))
 
-    def get_obs(self):
-        """-> obs (5, N) f64, reward (N,) f64, done (N,) bool, reason (N,) uint8."""
+    pinned_read_back = True     # get_obs(copy=False) exists
+
+    def get_obs(self, copy=True):
+        """-> obs (5, N) f64, reward (N,) f64, done (N,) bool, reason (N,) uint8.
+
+        ``copy=False``: obs / reward / reason are views of page-locked host buffers the propagator owns and the NEXT
+        call overwrites - the device-to-host copies then run as plain DMA (no staging through a bounce buffer, no
+        first-touch page faults on fresh arrays): what ``LeoPowerAttVecEnv.step_wait`` reads, which lays the
+        observations out afresh anyway."""
+        if not copy:
+            pin = getattr(self, "_pin", None)
+            if pin is None:
+                from ... import _hip
+                n = self.n_envs
+                f64, u8 = _hip.PinnedBuffer(6 * n * 8), _hip.PinnedBuffer(max(n, 1))
+                blk = f64.array.view(np.float64).reshape(6, n)
+                pin = self._pin = {"bufs": [f64, u8], "obs": blk[:5], "rew": blk[5], "why": u8.array[:n],
+                                   "p_obs": f64.ptr, "p_rew": f64.ptr + 5 * n * 8, "p_why": u8.ptr}
+            check(self._lib.bsk_get_obs(self._handle(), pin["p_obs"], pin["p_rew"], None, pin["p_why"]))
+            return pin["obs"], pin["rew"], pin["why"] != 0, pin["why"]
         obs = np.empty((5, self.n_envs), dtype=np.float64)
         rew = np.empty(self.n_envs, dtype=np.float64)
         done = np.empty(self.n_envs, dtype=np.uint8)
