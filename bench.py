@@ -713,6 +713,23 @@ def main():
             extra["small_batch"] = sb
         except Exception as e:
             extra["small_batch"] = {"error": repr(e)}
+        # the boundary with HOST buffers on both sides (bsk_step with host actions + bsk_get_obs into page-locked host arrays,
+        # one synchronisation per step): the PCIe-inclusive rate of DESIGN.md section 7 - never `value`
+        try:
+            acts_h = np.zeros(n, np.int32)
+            for _ in range(20):
+                prop.step(acts_h, 1)
+                prop.get_obs(copy=False)
+            t0 = time.perf_counter()
+            for _ in range(300):
+                prop.step(acts_h, 1)
+                prop.get_obs(copy=False)
+            dt = (time.perf_counter() - t0) / 300
+            extra["host_buffers_k1"] = {"env_steps_per_s": n / dt, "ms_per_step": dt * 1e3,
+                                        "bytes_per_step": {"h2d": 4 * n, "d2h": 49 * n},
+                                        "what": "bsk_step (host int32 actions) + bsk_get_obs (obs, reward, reason -> pinned host arrays), synchronised every step"}
+        except Exception as e:
+            extra["host_buffers_k1"] = {"error": repr(e)}
         # the device-resident RL loop (row f4): on-GPU policy -> step_tensors, at K = 1 and at the reference's K = 1 800
         try:
             extra["rl_loop"] = {"k1": rl_loop(torch, n, 1, 200), "k1800": rl_loop(torch, n, 1800, 200 if a.steps >= 1000 else 40)}
