@@ -263,6 +263,46 @@ def test_c_program_through_the_abi_matches_python_binding(tmp_path):
     prop.close()
 
 
+def test_c_program_runs_the_env_step_the_reference_binding_would(tmp_path):
+    """tests/c_abi/c_abi_env_step.c: the per-env-step sequence of INTEGRATION.md section 2 from plain C - full reference
+    scenario, one 1 800-sub-step launch per action (the three-wave form at this batch size), observation + state behind one
+    synchronisation, counters / kernel facts / timing / stream / env base around it - equals the Python binding's numbers."""
+    import os
+    import subprocess
+    from basilisk_env_amd import _lib
+    from basilisk_env_amd._lib import FLAG_DESAT, FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "c_abi_env_step"
+    libdir = os.path.dirname(_lib.lib_path())
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c_abi", "c_abi_env_step.c"), "-L", libdir, "-lbskgpu",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    for n in (1, 70):
+        cfg = default_config(3, GRAV_PM)
+        cfg.flags |= FLAG_POWER | FLAG_SUN_THIRD_BODY | FLAG_DRAG | FLAG_DESAT
+        ic = sample_ic_batch(n, 3, seed=45)
+        ic_file = tmp_path / ("ic%d.bin" % n)
+        ic.tofile(ic_file)
+        lines = subprocess.check_output([str(exe), str(ic_file), str(n)]).decode().strip().split("\n")
+        prop = BatchedPropagator(cfg, n)
+        prop.set_env_base(1000)
+        prop.reset(ic)
+        for s, a in enumerate((0, 2, 1)):
+            prop.step(np.full(n, a, np.int32), 1800)
+            obs, rew, done, why = prop.get_obs()
+            got = lines[s].split()
+            assert [float(v) for v in got[:5]] == [obs[k, 0] for k in range(5)]
+            assert float(got[5]) == rew[0] and int(got[6]) == int(why[0])
+        info = prop.kernel_info()
+        steps, ticks = prop.get_counters()
+        tail = lines[3].split()
+        assert tail[0] == info["name"] and "tri" in tail[0]
+        assert int(tail[1]) == info["block"] == 192 and int(tail[2]) == info["grid"]
+        assert int(tail[3]) == 3 and tail[4] == "1"                      # three launches stamped, a sane mean duration
+        assert int(tail[5]) == steps[0] == 3 and int(tail[6]) == ticks[0] == 5400 and tail[7] == "1"
+        prop.close()
+
+
 def test_long_horizon_error_growth():
     """30 reference-length env steps (30 x 1 800 = 54 000 RK4 steps, 1.5 h of flight) with mode
     switches: relative state error vs the oracle stays below the 1e-9 budget quoted for 1 000 steps."""
