@@ -98,11 +98,13 @@ def test_header_is_valid_c99():
 
 
 def test_c_consumer_links_against_the_library(tmp_path):
-    """A plain C program builds and links against libbskgpu.so through the header alone."""
+    """Plain C programs build and link against libbskgpu.so through the header alone."""
     import subprocess
-    exe = tmp_path / "c_abi_smoke"
     libdir = os.path.dirname(_lib.lib_path())
-    r = subprocess.run(["gcc", "-std=c99", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_abi", "c_abi_smoke.c"),
-                        "-L", libdir, "-lbskgpu", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)],
-                       capture_output=True)
-    assert r.returncode == 0, r.stderr.decode()
+    for prog in ("c_abi_smoke", "c_abi_env_step"):
+        exe = tmp_path / prog
+        r = subprocess.run(["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "tests", "c_abi", prog + ".c"),
+                            "-L", libdir, "-lbskgpu", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)],
+                           capture_output=True)
+        assert r.returncode == 0, r.stderr.decode()
