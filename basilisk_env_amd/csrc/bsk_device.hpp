@@ -466,8 +466,8 @@ struct PairLds {
     double sfac[PAIR_CHUNK][64];              // shadow factors the cooperative drain filled in
     double sun[3][64];                        // each lane's Sun position of this launch
     double lext[3][64];                       // each lane's disturbance torque (parked here: the dynamics wave's tick loop has
-                                              // 256 registers, and what does not fit goes to scratch memory, whose reloads miss the
-                                              // L1 once eight waves per CU spill - measured as a 40 % cliff at four pairs per CU)
+                                              // 256 registers, and what does not fit goes to scratch memory - the first version
+                                              // reloaded two spilled doubles per tick and lost 15 % to it)
     int qown[PAIR_CHUNK * 64];                // penumbra queue: owner lane | slot << 8
     int qcount, pad_[3];
 };
@@ -1490,8 +1490,9 @@ __device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, const WV& w
 //   translational: prefetch sigma(i) | r', gravity, Sun -> acc.r, r(i+1) | finish sigma(i) | drag force -> acc.v, v(i+1) -> publish
 // The fourth stage publishes the NEXT tick's first-stage value (attitude after the MRP switch; velocity together with the
 // density at the new position); the tick loop publishes the first tick's before it starts.
-// Rotational half: `tq`, `T`, `p0`, `tqj` are the wheel terms of the tick (wv.head, evaluated by the tick loop while the
-// first-stage velocity v1 was in flight).  Translational half: `p1` unused; rho_next returns the next tick's density.
+// Rotational half: `v1` is the first-stage velocity (it came with the tick's density, which the tick loop needs to pick the
+// instantiation), `tq`, `T`, `pw`, `tqj` the wheel terms of the tick (wv.head, evaluated by the tick loop while v1 was in
+// flight).  Translational half: those are unused; `density` evaluates the atmosphere, rho_next returns the next tick's.
 template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT, bool THR, int DRAGM, int PART, class WV, class XC, class RHO>
 __device__ __forceinline__ void rk4_step_part(const HotCfg<NRW, DIAG>& c, const WV& wv, State<NRW>& x, V3 lext, double t0,
                                               const Env& ev, XC& xc, V3 v1, const double* tq, V3 T, V3 pw, const double* tqj,

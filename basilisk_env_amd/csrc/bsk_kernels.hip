@@ -121,7 +121,6 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
     // SGPRs its constants need) stays out of the inner loop, which holds only HotCfg.
     const int fsw_every = c.fsw_every;
     const int substeps = a.substeps;
-    // wheel geometry: parked in VGPRs, except at the full-scenario levels where it is read from LDS at each use
     // wheel geometry: parked in VGPRs, except at the full-scenario levels where it comes through the DPP broadcast
     // table (bsk_device.hpp: KTab)
 #ifndef BSK_BARE_DPP

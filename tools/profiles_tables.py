@@ -7,6 +7,14 @@ d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "p
 J = lambda n: json.load(open(os.path.join(d, n)))
 kt = J("kernel_trace.json")
 print("fingerprint", kt["fingerprint"])
+CMD = {"65k_k1": "`--steps 40000 --warmup 4000` (65 536 envs, K = 1: the headline kernel)", "4m_k1": "`--envs 4194304 --steps 20 --warmup 3`",
+       "bare_k1800": "`--substeps 1800 --steps 20 --warmup 10`", "power_k1800": "`--scenario power --substeps 1800 --steps 20 --warmup 10`",
+       "full_k1800": "`--scenario full --substeps 1800 --steps 20 --warmup 10`", "sh70": "`--gravity sh --steps 1000 --warmup 300`"}
+def sp(x, nd=2):     # 1 234.56 with a thin-space-free plain space as in the README
+    t = ("%%.%df" % nd) % x
+    i, _, f = t.partition(".")
+    i = i[::-1]; i = " ".join(i[k:k + 3] for k in range(0, len(i), 3))[::-1]
+    return i + ("." + f if f else "")
 print("\n| key | dispatches (ramp dropped) | mean of ALL | p10 / p90 | median | trimmed mean | un-profiled stamped pass (median) |")
 ab = {"65k_k1": "ab_65k_plain.json", "4m_k1": "ab_4m_plain.json", "bare_k1800": "ab_k1800_plain.json", "power_k1800": "ab_power_k1800_plain.json",
       "full_k1800": "ab_full_k1800_plain.json", "sh70": "ab_sh_plain.json"}
@@ -16,7 +24,11 @@ for k in ("65k_k1", "4m_k1", "bare_k1800", "power_k1800", "full_k1800", "sh70"):
         r = J(ab[k])["roofline"]; plain = "%.2f (%.2f)" % (r["kernel_us_stamped"], r.get("median_us", float("nan")))
     except Exception as e:
         plain = "n/a"
-    print("| `%s` | %d (%d) | %.2f | %.2f / %.2f | %.2f | **%.2f** | %s |" % (k, v["dispatches"], v["ramp_dispatches_dropped"], v["mean_all_us"], v["p10_us"], v["p90_us"], v["median_us"], v["trimmed_mean_us"], plain))
+    try:
+        plain = "%s (%s)" % (sp(r["kernel_us_stamped"]), sp(r.get("median_us", float("nan"))))
+    except Exception:
+        pass
+    print("| `%s` | %s | %s (%s%s) | %s | %s / %s | %s | **%s** | %s%s |" % (k, CMD[k], sp(v["dispatches"], 0), sp(v["ramp_dispatches_dropped"], 0), " ramp dropped" if k == "65k_k1" else "", sp(v["mean_all_us"]), sp(v["p10_us"]), sp(v["p90_us"]), sp(v["median_us"]), sp(v["trimmed_mean_us"]), plain.replace("(", "(median " if k == "65k_k1" else "("), ""))
 b = J("bench_default.json")
 r = b["roofline"]; e = b["extra"]
 print("\nbench_default: value %.3e, ms_per_step %.5f, stamped %.2f us, rocprof %.2f (fresh %s), frac %.3f, frac_stamped %.3f" % (b["value"], b["ms_per_step"], r["kernel_us_stamped"], r.get("kernel_us_rocprof") or float("nan"), r.get("kernel_us_rocprof_fresh"), r["frac"], r.get("frac_stamped", float("nan"))))
