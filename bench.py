@@ -244,6 +244,9 @@ def settle_roofline(roof, key, stamped_us, wall_us, work, peak, fp=None):
     used = stamped_us
     if rp:
         fresh = rp.get("fingerprint") == fp
+        if rp.get("trimmed_mean_us_median_of_boxes"):      # the command was traced on several boxes: their median
+            roof["kernel_us_rocprof_boxes"] = [b["trimmed_mean_us"] for b in rp.get("boxes", [])]
+            rp["trimmed_mean_us"] = rp["trimmed_mean_us_median_of_boxes"]
         roof["kernel_us_rocprof"] = rp.get("trimmed_mean_us")
         roof["kernel_us_rocprof_median"] = rp.get("median_us")
         roof["kernel_us_rocprof_source"] = "%s [%s]" % (rp["source"], rp.get("csv", key))
@@ -255,7 +258,7 @@ def settle_roofline(roof, key, stamped_us, wall_us, work, peak, fp=None):
     else:
         roof["kernel_us_rocprof"] = None
     roof["kernel_us"] = used
-    roof["kernel_us_rule"] = "max(stamped pass of this run, committed rocprofv3 steady-state trimmed mean of the same command)"
+    roof["kernel_us_rule"] = "max(stamped pass of this run, committed rocprofv3 steady-state trimmed mean of the same command; median over the boxes it was traced on)"
     unit = 1e3 if roof.get("unit") == "GB/s" else 1e6        # bytes/us -> GB/s ; flop/us -> TFLOP/s
     if work is not None and used > 0:
         roof["achieved"] = work / used / unit
