@@ -209,12 +209,41 @@ def test_roofline_is_priced_on_the_more_conservative_duration(monkeypatch):
                                                           "csv": "kt_65k", "fingerprint": "0" * 16})
     r = b.settle_roofline(roof(), "65k_k1", 6.6, 7.7, work, 8000.0, fp)        # profile of another kernel: shown, not used
     assert r["kernel_us"] == 6.6 and r["kernel_us_rocprof"] == 9.9 and not r["kernel_us_rocprof_fresh"] and "kernel_us_rocprof_note" in r
+    # a command traced on several boxes: the median of their trimmed means is the profile figure
+    monkeypatch.setattr(b, "rocprof_kernel", lambda key: {"trimmed_mean_us": 7.9, "median_us": 7.8, "source": "profiles/rXX/kernel_trace.json",
+                                                          "csv": "kt_65k", "fingerprint": fp, "trimmed_mean_us_median_of_boxes": 7.3,
+                                                          "boxes": [{"trimmed_mean_us": 7.9}, {"trimmed_mean_us": 7.1}, {"trimmed_mean_us": 7.3}]})
+    r = b.settle_roofline(roof(), "65k_k1", 6.6, 7.7, work, 8000.0, fp)
+    assert r["kernel_us"] == 7.3 and r["kernel_us_rocprof"] == 7.3 and r["kernel_us_rocprof_boxes"] == [7.9, 7.1, 7.3]
     monkeypatch.setattr(b, "rocprof_kernel", lambda key: None)
     r = b.settle_roofline(roof(), None, 6.6, 7.7, work, 8000.0, fp)
     assert r["kernel_us"] == 6.6 and r["kernel_us_rocprof"] is None
     f = {"bound": "fp64", "unit": "TFLOP/s", "peak": 78.6}
     r = b.settle_roofline(f, None, 3700.0, 3710.0, 1.5e11, 78.6, fp)
     assert abs(r["achieved"] - 1.5e11 / 3700.0 / 1e6) < 1e-9 and abs(r["frac"] - r["achieved"] / 78.6) < 1e-12
+
+
+def test_committed_kernel_trace_is_consistent_with_its_dispatch_files():
+    """profiles/rNN/kernel_trace.json: every figure can be recomputed from the per-dispatch CSVs committed beside it, and
+    where a key was traced on several boxes the median of their trimmed means is what it offers."""
+    import csv
+    b = _load_bench()
+    path = b._latest_profile("kernel_trace.json")
+    d = json.load(open(path))
+    base = os.path.dirname(path)
+    for key, rec in d["runs"].items():
+        for box in rec.get("boxes", [rec]):
+            rows = list(csv.DictReader(open(os.path.join(base, box["csv"]))))
+            dur = [(float(r["start_offset_us"]), int(r["duration_ns"])) for r in rows]
+            n_ramp = min(sum(1 for s, _ in dur if s < 25.0 * 1e3), len(dur) // 2)
+            steady = sorted(x for _, x in dur[n_ramp:])
+            cut = len(steady) // 10
+            core = steady[cut:len(steady) - cut] if len(steady) >= 10 else steady
+            assert abs(sum(core) / len(core) / 1e3 - box["trimmed_mean_us"]) < 1e-6 * box["trimmed_mean_us"], (key, box["csv"])
+        if "boxes" in rec:
+            tm = sorted(x["trimmed_mean_us"] for x in rec["boxes"])
+            med = tm[len(tm) // 2] if len(tm) % 2 else 0.5 * (tm[len(tm) // 2 - 1] + tm[len(tm) // 2])
+            assert rec["trimmed_mean_us_median_of_boxes"] == med and rec["boxes"][0]["trimmed_mean_us"] == rec["trimmed_mean_us"]
 
 
 def test_profile_keys():
