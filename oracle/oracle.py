@@ -24,7 +24,10 @@ def load(omp=False):
     if name in _LIBS:
         return _LIBS[name]
     path = os.path.join(_HERE, name)
-    if not os.path.exists(path):
+    override = os.environ.get("BSK_ORACLE_LIB")          # tests/test_oracle_sanitizers.py: an instrumented build of the same source
+    if override and not omp:
+        path = override
+    elif not os.path.exists(path):
         build()
     lib = C.CDLL(path)
     P, vp = C.POINTER, C.c_void_p
