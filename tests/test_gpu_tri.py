@@ -103,6 +103,28 @@ def test_three_wave_form_full_env_step_and_one_spacecraft():
         b.close()
 
 
+def test_three_wave_form_at_one_workgroup_per_cu():
+    """16 384 spacecraft = 256 workgroups of 192 threads and 96 KB of LDS each, one per CU: the largest batch the form takes."""
+    n = 16384
+    cfg = default_config(4, GRAV_PM_J2)
+    cfg.flags |= FULL
+    ic = sample_ic_batch(n, 4, seed=8)
+    ic[12:16, ::7] *= 4.0
+    a, b = make(cfg, n, False), make(cfg, n, True)
+    a.reset(ic)
+    b.reset(ic)
+    rng = np.random.default_rng(9)
+    for k in (40, 25):
+        act = rng.integers(0, 3, n).astype(np.int32)
+        a.step(act, k)
+        b.step(act, k)
+        _same(a, b, (n, k))
+    info = b.kernel_info()
+    assert "tri" in info["name"] and info["grid"] == 256 and info["block"] == 192
+    a.close()
+    b.close()
+
+
 def test_three_wave_form_with_device_side_reset_and_default_selection():
     n = 200
     cfg = default_config(4, GRAV_PM_J2)
