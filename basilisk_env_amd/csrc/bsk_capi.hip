@@ -667,6 +667,9 @@ int bsk_create(const bsk_config* cfg, int n_envs, int device_id, void* stream, b
     }
     // the power-system kernels carry 37.6 KB of LDS per wave: one wave per workgroup at every batch size
     if (cfg->flags & BSK_FLAG_POWER) h->block = 64;
+    // both wave-split forms pay while every workgroup has a CU (and its LDS) to itself: 64 spacecraft per CU of THIS device
+    // (256 CUs on a whole MI355X; fewer in a partitioned mode)
+    if (prop.multiProcessorCount > 0) h->pair_max_envs = h->tri_max_envs = 64 * prop.multiProcessorCount;
     h->pair_ok = bsk::pair_available(cfg->gravity_model, h->diag, h->sp.feat);
     h->sp.pair_shift = 31;     // no swap: the hardware already places one wave 0 and one wave 1 of different workgroups on a SIMD (tools/micro/placement.hip)
     if (const char* ps = std::getenv("BSKGPU_PAIR_SHIFT")) h->sp.pair_shift = std::max(0, std::min(31, std::atoi(ps)));
