@@ -759,7 +759,12 @@ int bsk_set_gravity_sh(bsk_handle* h, int degree, const double* cbar, const doub
     // Form of the harmonics kernel.  Below two 64-lane waves per SIMD (1 024 SIMDs on MI355X) each
     // spacecraft's walk is split over two cooperating waves (form 5), above that one wave walks it
     // (form 4); the two give bit-identical results.  BSKGPU_SH_FORM=1|4|5 forces a form (measurement).
-    h->sp.sh_form = (h->n < 2 * 1024 * 64) ? 5 : 4;
+    int n_cu = 256;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+    }
+    h->sp.sh_form = (h->n < 2 * (4 * n_cu) * 64) ? 5 : 4;
     if (const char* f = std::getenv("BSKGPU_SH_FORM")) {
         const int v = std::atoi(f);
         if (v == 1 || v == 4 || v == 5) h->sp.sh_form = v;
