@@ -308,7 +308,10 @@ class LeoPowerAttVecEnv(_Base):
         finished envs are restarted by the kernel itself; ``info`` holds device tensors ``reason`` (N,) uint8,
         ``terminal_observation`` (N,5,1) (rows valid where ``done``) and ``episodes`` (N,) int32.
         Host-side episode statistics (``episode_returns`` / ``episode_lengths``, ``reset_init``'s IC mirror) are not
-        updated by this path.  Replaces reference envs/leoPowerAttitudeEnvironment.py:65-145 and
+        updated by this path.  Fastest with policy and env on ONE non-default torch stream (``stream=s.cuda_stream``, loop
+        under ``torch.cuda.stream(s)``): torch's legacy default stream synchronises with every other stream of the process
+        (measured 76 against 41 us per step of a K = 1 loop; a ``torch.cuda.CUDAGraph`` capture of the step also works and
+        buys nothing on top, tools/exp/rl_graph.py).  Replaces reference envs/leoPowerAttitudeEnvironment.py:65-145 and
         simulators/leoPowerAttitudeSimulator.py:598-619 for an on-GPU policy."""
         import torch
         if self.auto_reset and not self.device_reset:
