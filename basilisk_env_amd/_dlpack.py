@@ -7,7 +7,7 @@ Device type is kDLROCM (10); a ROCm build of PyTorch maps it to its ``cuda`` dev
 import ctypes as C
 
 kDLROCM = 10
-_CODES = {"f": 2, "i": 0, "u": 1}   # kDLFloat, kDLInt, kDLUInt
+_CODES = {"f": 2, "i": 0, "u": 1, "b": 6}   # kDLFloat, kDLInt, kDLUInt, kDLBool
 
 
 class DLDevice(C.Structure):
@@ -59,7 +59,7 @@ def _capsule_dtor(cap):
 
 
 def typestr_to_dl(typestr):
-    """numpy-style typestr ('<f8', '<u8', '|u1', '<i4') -> DLDataType."""
+    """numpy-style typestr ('<f8', '<u8', '|u1', '<i4', '|b1') -> DLDataType."""
     kind, size = typestr[1], int(typestr[2:])
     return DLDataType(_CODES[kind], 8 * size, 1)
 

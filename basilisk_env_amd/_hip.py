@@ -27,6 +27,7 @@ def runtime():
     rt.hipGetErrorString.restype = C.c_char_p
     rt.hipGetErrorString.argtypes = [C.c_int]
     rt.hipSetDevice.argtypes = [C.c_int]
+    rt.hipGetDevice.argtypes = [C.POINTER(C.c_int)]
     rt.hipGetDeviceCount.argtypes = [C.POINTER(C.c_int)]
     rt.hipMalloc.argtypes = [C.POINTER(vp), sz]
     rt.hipFree.argtypes = [vp]
@@ -52,14 +53,40 @@ def device_count():
     return n.value if rc == 0 else 0
 
 
+def current_device():
+    d = C.c_int(-1)
+    check(runtime().hipGetDevice(C.byref(d)), "hipGetDevice")
+    return d.value
+
+
+class device_guard(object):
+    """``with device_guard(d): ...`` - the calling thread's current HIP device is ``d`` inside and whatever it was before
+    afterwards (the C library's DeviceGuard, for the handful of runtime calls this package makes from Python).  A process
+    that shards a batch over several GPUs usually also runs a torch policy: that one must keep finding ITS device current."""
+
+    def __init__(self, device):
+        self.device, self.prev = int(device), None
+
+    def __enter__(self):
+        self.prev = current_device()
+        if self.prev != self.device:
+            set_device(self.device)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None and self.prev != self.device:
+            set_device(self.prev)
+        return False
+
+
 class DeviceBuffer(object):
     """hipMalloc'ed bytes on ``device``; exposes ``__cuda_array_interface__`` through ``view``."""
 
     def __init__(self, nbytes, device):
         rt = runtime()
-        check(rt.hipSetDevice(int(device)), "hipSetDevice")
         p = C.c_void_p()
-        check(rt.hipMalloc(C.byref(p), int(nbytes)), "hipMalloc")
+        with device_guard(device):
+            check(rt.hipMalloc(C.byref(p), int(nbytes)), "hipMalloc")
         self.ptr, self.nbytes, self.device = p.value, int(nbytes), int(device)
 
     def free(self):

@@ -12,6 +12,7 @@ BSK_MAX_THR = 8
 
 GRAV_PM, GRAV_PM_J2, GRAV_SH = 0, 1, 2
 FLAG_SUN_THIRD_BODY, FLAG_POWER, FLAG_DESAT, FLAG_DRAG, FLAG_AUTO_RESET, FLAG_LDS_SCRATCH = 1, 2, 4, 8, 16, 32
+FLAG_EPISODE_STATS, FLAG_OBS_ROWMAJOR = 64, 128
 DONE_LENGTH, DONE_WHEELS, DONE_BATTERY, DONE_ORBIT = 1, 2, 4, 8
 
 # state field offsets (include/bskgpu.h)
@@ -64,7 +65,7 @@ class BskConfig(C.Structure):
 
 EXPORTS = [
     "bsk_default_config", "bsk_create", "bsk_destroy", "bsk_set_gravity_sh", "bsk_reset", "bsk_step",
-    "bsk_step_device", "bsk_get_obs", "bsk_get_obs_device", "bsk_get_obs_state", "bsk_get_stream", "bsk_get_terminal_obs_device", "bsk_get_state_device", "bsk_get_batch_stats", "bsk_n_fields",
+    "bsk_step_device", "bsk_step_device_i64", "bsk_get_episode_device", "bsk_get_batch_stats_device", "bsk_reset_from_pool_device", "bsk_debug_counters", "bsk_debug_words", "bsk_get_obs", "bsk_get_obs_device", "bsk_get_obs_state", "bsk_get_stream", "bsk_get_terminal_obs_device", "bsk_get_state_device", "bsk_get_batch_stats", "bsk_n_fields",
     "bsk_get_state", "bsk_set_state", "bsk_get_counters", "bsk_set_counters", "bsk_set_ic_pool", "bsk_sample_ic_pool", "bsk_reset_from_pool", "bsk_get_ic_pool", "bsk_get_terminal_obs", "bsk_set_env_base", "bsk_set_sim_time", "bsk_sync",
     "bsk_profile_begin", "bsk_profile_set_stride", "bsk_profile_end", "bsk_profile_end_samples", "bsk_calibrate_fp64", "bsk_kernel_info", "bsk_last_error", "bsk_version",
 ]
@@ -125,6 +126,12 @@ def load():
     lib.bsk_reset.argtypes = [vp, vp, vp]
     lib.bsk_step.argtypes = [vp, vp, C.c_int]
     lib.bsk_step_device.argtypes = [vp, vp, C.c_int]
+    for name, args in (("bsk_step_device_i64", [vp, vp, C.c_int]), ("bsk_get_episode_device", [vp, P(vp), P(vp), P(vp), P(vp), P(vp)]),
+                       ("bsk_get_batch_stats_device", [vp, P(vp)]), ("bsk_reset_from_pool_device", [vp, vp]),
+                       ("bsk_debug_counters", [P(C.c_int64), P(C.c_int64)]), ("bsk_debug_words", [vp, vp])):
+        # (a BSKGPU_LIB variant built from an older tree - kernel A/B against a previous round - may predate these)
+        if hasattr(lib, name) or not os.environ.get("BSKGPU_LIB"):
+            getattr(lib, name).argtypes = args
     lib.bsk_get_obs.argtypes = [vp, vp, vp, vp, vp]
     lib.bsk_get_obs_device.argtypes = [vp, P(vp), P(vp), P(vp), P(vp), P(C.c_int64)]
     lib.bsk_get_obs_state.argtypes = [vp, vp, vp, vp, vp]

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
@@ -31,6 +32,12 @@ int fail(int code, const std::string& msg) {
             return fail(e_ == hipErrorOutOfMemory ? BSK_ENOMEM : BSK_EHIP,                              \
                         std::string(#expr) + ": " + hipGetErrorString(e_));                             \
     } while (0)
+
+// how many copies / stream synchronisations this library has issued (bsk_debug_counters: tests assert that the
+// device-resident entry points issue none)
+std::atomic<long long> g_n_copies{0}, g_n_syncs{0};
+#define HIP_COPY(expr) do { g_n_copies.fetch_add(1, std::memory_order_relaxed); HIP_TRY(expr); } while (0)
+#define HIP_SYNC(expr) do { g_n_syncs.fetch_add(1, std::memory_order_relaxed); HIP_TRY(expr); } while (0)
 
 bool inv3(const double* m, double* o) {
     double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
@@ -200,7 +207,7 @@ int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool&
         p.js[i] = c.js[i];
     }
     if (!inv3(D, p.dinv)) return fail(BSK_EINVAL, "hub inertia minus wheel inertia is singular");
-    for (int i = 0; i < 9; ++i) p.wmat[i] = c.inertia[i] - D[i];
+    for (int i = 0; i < 9; ++i) { p.dmat[i] = D[i]; p.wmat[i] = c.inertia[i] - D[i]; }
     // Diagonal fast path: only when every off-diagonal of I_sc and of (I_sc - sum Js g g^T) is
     // EXACTLY zero (true for the reference's cuboid hub with the triad or the symmetric pyramid).
     diag = true;
@@ -351,6 +358,16 @@ int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool&
     k.kt[32 + bsk::KC_NIH] = -p.ex.inv_scale_height;
     k.kt[32 + bsk::KC_REQIH] = c.req * p.ex.inv_scale_height;
     k.kt[32 + bsk::KC_RSKIP] = p.ex.rho_skip;
+    k.kt[32 + bsk::KC_LOG2E] = 1.4426950408889634074;
+    {   // row E: rho0 / k!, k = 0..13 (bsk_device.hpp: atmosphere_density), -ln2 split in two parts
+        long double f = 1.0L;
+        for (int i = 0; i < 14; ++i) {
+            if (i > 1) f *= (long double)i;
+            k.kt[64 + bsk::KE_POLY + i] = (double)((long double)p.ex.base_density / f);
+        }
+        k.kt[64 + bsk::KE_NLN2HI] = -6.93147180369123816490e-01;
+        k.kt[64 + bsk::KE_NLN2LO] = -1.90821492927058770002e-10;
+    }
     // thruster subset table: row m = sums over the set bits of m, ascending thruster index
     for (int m = 0; m < (1 << BSK_MAX_THR); ++m) {
         double f[6] = {0, 0, 0, 0, 0, 0};
@@ -403,6 +420,16 @@ struct bsk_handle {
     bool prof = false;
     double sim_time = 0.0;
     unsigned env_base = 0;   // global index of env 0 (bsk_set_env_base)
+    // device-resident surface (BSK_FLAG_EPISODE_STATS / BSK_FLAG_OBS_ROWMAJOR)
+    double* d_ep_return = nullptr;
+    double* d_term_return = nullptr;
+    int* d_term_len = nullptr;
+    unsigned char* d_done = nullptr;
+    double* d_obs_rm = nullptr;
+    unsigned long long* d_dbg = nullptr;   // one word per wave for probe builds (bsk_probes.hpp)
+    double* d_stats2 = nullptr;   // {sum of rewards, number of done envs} of the last step, as two doubles (all-reduce operand)
+    // error word the kernels can raise (page-locked host memory, device-visible): checked by every synchronising entry point
+    int* h_err = nullptr;
     // pair form of the step kernel (bsk_device.hpp: PairLds): used for launches of >= pair_min_substeps sub-steps of batches
     // of <= pair_max_envs spacecraft where it is built (power / full-scenario levels, point mass or J2, diagonal hub).  Measured
     // (profiles/r03/pair_form.txt): -13 % per env step up to one pair per CU (16 384 spacecraft), level with the single-wave
@@ -472,7 +499,29 @@ int ensure_stage(bsk_handle* h, size_t m) {
     return BSK_OK;
 }
 
-int do_step(bsk_handle* h, const int* d_actions, int substeps) {
+bsk::ResetOut reset_out(const bsk_handle* h) {
+    bsk::ResetOut ro;
+    ro.obs = h->d_obs; ro.obs_rm = h->d_obs_rm; ro.reward = h->d_reward; ro.reason = h->d_reason; ro.done = h->d_done;
+    ro.ep_return = h->d_ep_return;
+    ro.inv_wheel_limit = h->sp.obs.inv_wheel_limit; ro.charge_scale = h->sp.obs.charge_scale;
+    ro.n_rw = h->cfg.n_rw;
+    return ro;
+}
+
+// After a stream synchronisation: has a kernel raised the handle's error word?  (bsk_device.hpp: BSK_DEVERR_*)
+int check_device_error(bsk_handle* h) {
+    if (!h->h_err) return BSK_OK;
+    const int e = *(volatile int*)h->h_err;
+    if (e == 0) return BSK_OK;
+    *(volatile int*)h->h_err = 0;
+    if (e == bsk::BSK_DEVERR_TRI_EXCHANGE)
+        return fail(BSK_EHIP, "step kernel (three-wave form): a wave waited 2^20 polls for its partner's stage value and gave up; "
+                              "the results of that launch are invalid (observations were set to NaN)");
+    return fail(BSK_EHIP, "step kernel raised device error " + std::to_string(e));
+}
+#define SYNC_CHECKED(h) do { HIP_SYNC(hipStreamSynchronize((h)->stream)); int rc_ = check_device_error(h); if (rc_) return rc_; } while (0)
+
+int do_step(bsk_handle* h, const void* d_actions, int substeps, int act_shift) {
     if (h->cfg.gravity_model == BSK_GRAV_SH && !h->sp.sh_tab)
         return fail(BSK_EINVAL, "BSK_GRAV_SH: call bsk_set_gravity_sh before stepping");
     if ((h->cfg.flags & BSK_FLAG_AUTO_RESET) && h->n_pool == 0)
@@ -481,7 +530,10 @@ int do_step(bsk_handle* h, const int* d_actions, int substeps) {
     b.cold = h->d_cold;
     b.st = h->d_state;
     b.cnt = h->d_cnt;
-    b.act = d_actions;
+    b.act = (const int*)d_actions;
+    b.act_shift = act_shift;
+    b.ep_return = h->d_ep_return; b.term_return = h->d_term_return; b.term_len = h->d_term_len; b.done = h->d_done;
+    b.obs_rm = h->d_obs_rm; b.err = h->h_err; b.dbg = h->d_dbg;
     b.obs = h->d_obs;
     b.reward = h->d_reward;
     b.done_mask = h->d_done_mask;
@@ -707,6 +759,19 @@ int bsk_create(const bsk_config* cfg, int n_envs, int device_id, void* stream, b
     if (e == hipSuccess) e = alloc((void**)&h->d_wave_reward, (size_t)(S / 64) * sizeof(double));
     if (e == hipSuccess) e = alloc((void**)&h->d_stat_sum, sizeof(double));
     if (e == hipSuccess) e = alloc((void**)&h->d_stat_done, sizeof(long long));
+    if (e == hipSuccess) e = alloc((void**)&h->d_stats2, 2 * sizeof(double));
+    if (e == hipSuccess) e = alloc((void**)&h->d_dbg, (size_t)(S / 64) * sizeof(unsigned long long));
+    if (e == hipSuccess && (cfg->flags & BSK_FLAG_EPISODE_STATS)) {
+        e = alloc((void**)&h->d_ep_return, (size_t)S * sizeof(double));
+        if (e == hipSuccess) e = alloc((void**)&h->d_term_return, (size_t)S * sizeof(double));
+        if (e == hipSuccess) e = alloc((void**)&h->d_term_len, (size_t)S * sizeof(int));
+        if (e == hipSuccess) e = alloc((void**)&h->d_done, (size_t)S);
+    }
+    if (e == hipSuccess && (cfg->flags & BSK_FLAG_OBS_ROWMAJOR)) e = alloc((void**)&h->d_obs_rm, (size_t)5 * S * sizeof(double));
+    if (e == hipSuccess) {
+        e = hipHostMalloc((void**)&h->h_err, sizeof(int), hipHostMallocDefault);
+        if (e == hipSuccess) *h->h_err = 0;
+    }
     if (e == hipSuccess) e = alloc((void**)&h->d_cold, sizeof(bsk::ColdCfg));
     if (e == hipSuccess) e = hipMemcpyAsync(h->d_cold, &h->cold, sizeof(bsk::ColdCfg), hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -727,9 +792,11 @@ void bsk_destroy(bsk_handle* h) {
     for (hipEvent_t ev : h->ev_warm)
         if (ev) (void)hipEventDestroy(ev);
     void* bufs[] = {h->d_state, h->d_cnt, h->d_act, h->d_obs, h->d_reward, h->d_done_mask, h->d_reason,
-                    h->d_wave_reward, h->d_stat_sum, h->d_stat_done, h->d_ic_stage, h->d_idx_stage, h->d_mask_stage, h->d_cold, h->d_sh_tab, h->d_sh_tab4, h->d_pool, h->d_term_obs, h->d_episodes};
+                    h->d_wave_reward, h->d_stat_sum, h->d_stat_done, h->d_ic_stage, h->d_idx_stage, h->d_mask_stage, h->d_cold, h->d_sh_tab, h->d_sh_tab4, h->d_pool, h->d_term_obs, h->d_episodes,
+                    h->d_ep_return, h->d_term_return, h->d_term_len, h->d_done, h->d_obs_rm, h->d_stats2, h->d_dbg};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
+    if (h->h_err) (void)hipHostFree(h->h_err);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -743,13 +810,13 @@ int bsk_set_gravity_sh(bsk_handle* h, int degree, const double* cbar, const doub
     std::vector<double> tab, tab4;
     build_sh_table(degree, cbar, sbar, tab);
     const ShLayout lay = build_sh_table_dpp(degree, cbar, sbar, tab4);
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_SYNC(hipStreamSynchronize(h->stream));
     if (h->d_sh_tab) { (void)hipFree(h->d_sh_tab); h->d_sh_tab = nullptr; }
     if (h->d_sh_tab4) { (void)hipFree(h->d_sh_tab4); h->d_sh_tab4 = nullptr; }
     HIP_TRY(hipMalloc(&h->d_sh_tab, tab.size() * sizeof(double)));
-    HIP_TRY(hipMemcpy(h->d_sh_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_COPY(hipMemcpy(h->d_sh_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&h->d_sh_tab4, tab4.size() * sizeof(double)));
-    HIP_TRY(hipMemcpy(h->d_sh_tab4, tab4.data(), tab4.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_COPY(hipMemcpy(h->d_sh_tab4, tab4.data(), tab4.size() * sizeof(double), hipMemcpyHostToDevice));
     h->sp.sh_degree = degree;
     h->sp.sh_split = lay.split;
     h->sp.sh_chunk1 = lay.chunk1;
@@ -780,10 +847,11 @@ int bsk_reset(bsk_handle* h, const uint8_t* mask, const double* ic) {
     DeviceGuard guard(h->device);
     const size_t row = (size_t)h->n * sizeof(double);
     if (!mask) {
-        HIP_TRY(hipMemcpy2DAsync(h->d_state, (size_t)h->stride * sizeof(double), ic, row, row, h->nf,
+        HIP_COPY(hipMemcpy2DAsync(h->d_state, (size_t)h->stride * sizeof(double), ic, row, row, h->nf,
                                  hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipMemsetAsync(h->d_cnt, 0, (size_t)h->stride * sizeof(int2), h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(bsk::launch_init_outputs(h->d_state, h->stride, nullptr, h->n, reset_out(h), h->stream));
+        HIP_SYNC(hipStreamSynchronize(h->stream));
         return BSK_OK;
     }
     std::vector<int> idx;
@@ -796,10 +864,11 @@ int bsk_reset(bsk_handle* h, const uint8_t* mask, const double* ic) {
         for (size_t t = 0; t < m; ++t) compact[(size_t)f * m + t] = ic[(size_t)f * h->n + idx[t]];
     int rc = ensure_stage(h, m);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(h->d_ic_stage, compact.data(), compact.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->d_idx_stage, idx.data(), m * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_COPY(hipMemcpyAsync(h->d_ic_stage, compact.data(), compact.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_COPY(hipMemcpyAsync(h->d_idx_stage, idx.data(), m * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(bsk::launch_scatter_reset(h->d_state, h->stride, h->nf, h->d_ic_stage, h->d_idx_stage, (int)m, h->d_cnt, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(bsk::launch_init_outputs(h->d_state, h->stride, h->d_idx_stage, (int)m, reset_out(h), h->stream));
+    HIP_SYNC(hipStreamSynchronize(h->stream));
     return BSK_OK;
 }
 
@@ -807,15 +876,22 @@ int bsk_step(bsk_handle* h, const int32_t* actions, int substeps) {
     if (!h || !actions) return fail(BSK_EINVAL, "handle/actions is NULL");
     if (substeps < 1) return fail(BSK_EINVAL, "substeps must be >= 1");
     DeviceGuard guard(h->device);
-    HIP_TRY(hipMemcpyAsync(h->d_act, actions, (size_t)h->n * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    return do_step(h, h->d_act, substeps);
+    HIP_COPY(hipMemcpyAsync(h->d_act, actions, (size_t)h->n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    return do_step(h, h->d_act, substeps, 1);
 }
 
 int bsk_step_device(bsk_handle* h, const int32_t* d_actions, int substeps) {
     if (!h || !d_actions) return fail(BSK_EINVAL, "handle/actions is NULL");
     if (substeps < 1) return fail(BSK_EINVAL, "substeps must be >= 1");
     DeviceGuard guard(h->device);
-    return do_step(h, d_actions, substeps);
+    return do_step(h, d_actions, substeps, 1);
+}
+
+int bsk_step_device_i64(bsk_handle* h, const int64_t* d_actions, int substeps) {
+    if (!h || !d_actions) return fail(BSK_EINVAL, "handle/actions is NULL");
+    if (substeps < 1) return fail(BSK_EINVAL, "substeps must be >= 1");
+    DeviceGuard guard(h->device);
+    return do_step(h, d_actions, substeps, 0);       // the kernel reads the low word of every little-endian int64
 }
 
 int bsk_get_obs(bsk_handle* h, double* obs, double* reward, uint8_t* done, uint8_t* done_reason) {
@@ -823,13 +899,13 @@ int bsk_get_obs(bsk_handle* h, double* obs, double* reward, uint8_t* done, uint8
     DeviceGuard guard(h->device);
     const size_t row = (size_t)h->n * sizeof(double);
     if (obs)
-        HIP_TRY(hipMemcpy2DAsync(obs, row, h->d_obs, (size_t)h->stride * sizeof(double), row, 5, hipMemcpyDeviceToHost, h->stream));
-    if (reward) HIP_TRY(hipMemcpyAsync(reward, h->d_reward, row, hipMemcpyDeviceToHost, h->stream));
+        HIP_COPY(hipMemcpy2DAsync(obs, row, h->d_obs, (size_t)h->stride * sizeof(double), row, 5, hipMemcpyDeviceToHost, h->stream));
+    if (reward) HIP_COPY(hipMemcpyAsync(reward, h->d_reward, row, hipMemcpyDeviceToHost, h->stream));
     std::vector<unsigned char> why;
     unsigned char* wp = done_reason;
     if (done && !done_reason) { why.resize(h->n); wp = why.data(); }
-    if (wp) HIP_TRY(hipMemcpyAsync(wp, h->d_reason, (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (wp) HIP_COPY(hipMemcpyAsync(wp, h->d_reason, (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+    SYNC_CHECKED(h);
     if (done)
         for (int i = 0; i < h->n; ++i) done[i] = wp[i] != 0;
     return BSK_OK;
@@ -839,11 +915,11 @@ int bsk_get_obs_state(bsk_handle* h, double* obs, double* reward, uint8_t* done_
     if (!h) return fail(BSK_EINVAL, "handle is NULL");
     DeviceGuard guard(h->device);
     const size_t row = (size_t)h->n * sizeof(double), pitch = (size_t)h->stride * sizeof(double);
-    if (obs) HIP_TRY(hipMemcpy2DAsync(obs, row, h->d_obs, pitch, row, 5, hipMemcpyDeviceToHost, h->stream));
-    if (reward) HIP_TRY(hipMemcpyAsync(reward, h->d_reward, row, hipMemcpyDeviceToHost, h->stream));
-    if (done_reason) HIP_TRY(hipMemcpyAsync(done_reason, h->d_reason, (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
-    if (state) HIP_TRY(hipMemcpy2DAsync(state, row, h->d_state, pitch, row, h->nf, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (obs) HIP_COPY(hipMemcpy2DAsync(obs, row, h->d_obs, pitch, row, 5, hipMemcpyDeviceToHost, h->stream));
+    if (reward) HIP_COPY(hipMemcpyAsync(reward, h->d_reward, row, hipMemcpyDeviceToHost, h->stream));
+    if (done_reason) HIP_COPY(hipMemcpyAsync(done_reason, h->d_reason, (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+    if (state) HIP_COPY(hipMemcpy2DAsync(state, row, h->d_state, pitch, row, h->nf, hipMemcpyDeviceToHost, h->stream));
+    SYNC_CHECKED(h);
     return BSK_OK;
 }
 
@@ -885,9 +961,9 @@ int bsk_get_batch_stats(bsk_handle* h, double* reward_sum, int64_t* n_done) {
     HIP_TRY(bsk::launch_stats(h->d_wave_reward, h->d_done_mask, n_waves, h->d_stat_sum, h->d_stat_done, h->stream));
     double s = 0;
     long long d = 0;
-    HIP_TRY(hipMemcpyAsync(&s, h->d_stat_sum, sizeof s, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(&d, h->d_stat_done, sizeof d, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_COPY(hipMemcpyAsync(&s, h->d_stat_sum, sizeof s, hipMemcpyDeviceToHost, h->stream));
+    HIP_COPY(hipMemcpyAsync(&d, h->d_stat_done, sizeof d, hipMemcpyDeviceToHost, h->stream));
+    SYNC_CHECKED(h);
     if (reward_sum) *reward_sum = s;
     if (n_done) *n_done = d;
     return BSK_OK;
@@ -897,8 +973,8 @@ int bsk_get_state(bsk_handle* h, double* state) {
     if (!h || !state) return fail(BSK_EINVAL, "handle/state is NULL");
     DeviceGuard guard(h->device);
     const size_t row = (size_t)h->n * sizeof(double);
-    HIP_TRY(hipMemcpy2DAsync(state, row, h->d_state, (size_t)h->stride * sizeof(double), row, h->nf, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_COPY(hipMemcpy2DAsync(state, row, h->d_state, (size_t)h->stride * sizeof(double), row, h->nf, hipMemcpyDeviceToHost, h->stream));
+    SYNC_CHECKED(h);
     return BSK_OK;
 }
 
@@ -906,8 +982,8 @@ int bsk_set_state(bsk_handle* h, const double* state) {
     if (!h || !state) return fail(BSK_EINVAL, "handle/state is NULL");
     DeviceGuard guard(h->device);
     const size_t row = (size_t)h->n * sizeof(double);
-    HIP_TRY(hipMemcpy2DAsync(h->d_state, (size_t)h->stride * sizeof(double), state, row, row, h->nf, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_COPY(hipMemcpy2DAsync(h->d_state, (size_t)h->stride * sizeof(double), state, row, row, h->nf, hipMemcpyHostToDevice, h->stream));
+    HIP_SYNC(hipStreamSynchronize(h->stream));
     return BSK_OK;
 }
 
@@ -915,8 +991,8 @@ int bsk_get_counters(bsk_handle* h, int32_t* steps, int32_t* ticks) {
     if (!h) return fail(BSK_EINVAL, "handle is NULL");
     DeviceGuard guard(h->device);
     std::vector<int2> tmp(h->n);
-    HIP_TRY(hipMemcpyAsync(tmp.data(), h->d_cnt, (size_t)h->n * sizeof(int2), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_COPY(hipMemcpyAsync(tmp.data(), h->d_cnt, (size_t)h->n * sizeof(int2), hipMemcpyDeviceToHost, h->stream));
+    HIP_SYNC(hipStreamSynchronize(h->stream));
     for (int i = 0; i < h->n; ++i) {
         if (steps) steps[i] = tmp[i].x & 0xFFFFF;  // high bits carry the FSW phase
         if (ticks) ticks[i] = tmp[i].y;
@@ -933,8 +1009,8 @@ int bsk_set_counters(bsk_handle* h, const int32_t* steps, const int32_t* ticks) 
         tmp[i].x = steps[i] | ((ticks[i] % h->cfg.fsw_every) << 20);
         tmp[i].y = ticks[i];
     }
-    HIP_TRY(hipMemcpyAsync(h->d_cnt, tmp.data(), (size_t)h->n * sizeof(int2), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_COPY(hipMemcpyAsync(h->d_cnt, tmp.data(), (size_t)h->n * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+    HIP_SYNC(hipStreamSynchronize(h->stream));
     return BSK_OK;
 }
 
@@ -943,10 +1019,10 @@ int bsk_set_ic_pool(bsk_handle* h, int n_pool, const double* ic_pool) {
     if (!(h->cfg.flags & BSK_FLAG_AUTO_RESET)) return fail(BSK_EINVAL, "handle was not created with BSK_FLAG_AUTO_RESET");
     if (n_pool < 1) return fail(BSK_EINVAL, "n_pool must be >= 1");
     DeviceGuard guard(h->device);
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_SYNC(hipStreamSynchronize(h->stream));
     int rc = ensure_pool_buffers(h, n_pool);
     if (rc) return rc;
-    HIP_TRY(hipMemcpy(h->d_pool, ic_pool, (size_t)h->nf * n_pool * sizeof(double), hipMemcpyHostToDevice));
+    HIP_COPY(hipMemcpy(h->d_pool, ic_pool, (size_t)h->nf * n_pool * sizeof(double), hipMemcpyHostToDevice));
     h->n_pool = n_pool;
     return BSK_OK;
 }
@@ -971,11 +1047,11 @@ int bsk_sample_ic_pool(bsk_handle* h, int n_pool, uint64_t seed) {
     if (!(h->cfg.flags & BSK_FLAG_AUTO_RESET)) return fail(BSK_EINVAL, "handle was not created with BSK_FLAG_AUTO_RESET");
     if (n_pool < 1) return fail(BSK_EINVAL, "n_pool must be >= 1");
     DeviceGuard guard(h->device);
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_SYNC(hipStreamSynchronize(h->stream));
     int rc = ensure_pool_buffers(h, n_pool);
     if (rc) return rc;
     HIP_TRY(bsk::launch_sample_pool(h->d_pool, n_pool, h->cfg.n_rw, (unsigned long long)seed, h->cfg.mu, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_SYNC(hipStreamSynchronize(h->stream));
     h->n_pool = n_pool;
     return BSK_OK;
 }
@@ -988,11 +1064,53 @@ int bsk_reset_from_pool(bsk_handle* h, const uint8_t* mask) {
     if (mask) {
         if (!h->d_mask_stage) HIP_TRY(hipMalloc(&h->d_mask_stage, (size_t)h->stride));   // kept for the handle's lifetime
         d_mask = h->d_mask_stage;
-        HIP_TRY(hipMemcpyAsync(d_mask, mask, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+        HIP_COPY(hipMemcpyAsync(d_mask, mask, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
     }
     HIP_TRY(bsk::launch_reset_from_pool(h->d_state, h->stride, h->nf, h->d_pool, h->n_pool, d_mask, h->n, h->d_cnt,
-                                        h->d_episodes, h->env_base, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+                                        h->d_episodes, h->env_base, reset_out(h), h->stream));
+    HIP_SYNC(hipStreamSynchronize(h->stream));
+    return BSK_OK;
+}
+
+int bsk_reset_from_pool_device(bsk_handle* h, const uint8_t* d_mask) {
+    if (!h) return fail(BSK_EINVAL, "handle is NULL");
+    if (h->n_pool == 0) return fail(BSK_EINVAL, "no IC pool staged (bsk_set_ic_pool / bsk_sample_ic_pool)");
+    DeviceGuard guard(h->device);
+    HIP_TRY(bsk::launch_reset_from_pool(h->d_state, h->stride, h->nf, h->d_pool, h->n_pool, d_mask, h->n, h->d_cnt,
+                                        h->d_episodes, h->env_base, reset_out(h), h->stream));
+    return BSK_OK;       // asynchronous on the handle's stream: no host data, no copy, no synchronisation
+}
+
+int bsk_get_episode_device(bsk_handle* h, double** d_ep_return, double** d_term_return, int32_t** d_term_len, uint8_t** d_done,
+                           double** d_obs_rowmajor) {
+    if (!h) return fail(BSK_EINVAL, "handle is NULL");
+    if (d_ep_return) *d_ep_return = h->d_ep_return;
+    if (d_term_return) *d_term_return = h->d_term_return;
+    if (d_term_len) *d_term_len = h->d_term_len;
+    if (d_done) *d_done = h->d_done;
+    if (d_obs_rowmajor) *d_obs_rowmajor = h->d_obs_rm;
+    return BSK_OK;
+}
+
+int bsk_get_batch_stats_device(bsk_handle* h, double** d_stats2) {
+    if (!h || !d_stats2) return fail(BSK_EINVAL, "handle/d_stats2 is NULL");
+    DeviceGuard guard(h->device);
+    HIP_TRY(bsk::launch_stats2(h->d_wave_reward, h->d_done_mask, (h->n + 63) / 64, h->d_stats2, h->stream));
+    *d_stats2 = h->d_stats2;
+    return BSK_OK;       // asynchronous: the two doubles are valid once the handle's stream has reached this point
+}
+
+int bsk_debug_words(bsk_handle* h, uint64_t* words) {
+    if (!h || !words) return fail(BSK_EINVAL, "handle/words is NULL");
+    DeviceGuard guard(h->device);
+    HIP_COPY(hipMemcpyAsync(words, h->d_dbg, (size_t)((h->n + 63) / 64) * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+    SYNC_CHECKED(h);
+    return BSK_OK;
+}
+
+int bsk_debug_counters(int64_t* n_copies, int64_t* n_syncs) {
+    if (n_copies) *n_copies = g_n_copies.load(std::memory_order_relaxed);
+    if (n_syncs) *n_syncs = g_n_syncs.load(std::memory_order_relaxed);
     return BSK_OK;
 }
 
@@ -1000,8 +1118,8 @@ int bsk_get_ic_pool(bsk_handle* h, double* ic_pool) {
     if (!h || !ic_pool) return fail(BSK_EINVAL, "handle/ic_pool is NULL");
     if (h->n_pool == 0) return fail(BSK_EINVAL, "no IC pool staged (bsk_set_ic_pool / bsk_sample_ic_pool)");
     DeviceGuard guard(h->device);
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemcpy(ic_pool, h->d_pool, (size_t)h->nf * h->n_pool * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_SYNC(hipStreamSynchronize(h->stream));
+    HIP_COPY(hipMemcpy(ic_pool, h->d_pool, (size_t)h->nf * h->n_pool * sizeof(double), hipMemcpyDeviceToHost));
     return BSK_OK;
 }
 
@@ -1011,9 +1129,9 @@ int bsk_get_terminal_obs(bsk_handle* h, double* term_obs, int32_t* episodes) {
     DeviceGuard guard(h->device);
     const size_t row = (size_t)h->n * sizeof(double);
     if (term_obs)
-        HIP_TRY(hipMemcpy2DAsync(term_obs, row, h->d_term_obs, (size_t)h->stride * sizeof(double), row, 5, hipMemcpyDeviceToHost, h->stream));
-    if (episodes) HIP_TRY(hipMemcpyAsync(episodes, h->d_episodes, (size_t)h->n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_COPY(hipMemcpy2DAsync(term_obs, row, h->d_term_obs, (size_t)h->stride * sizeof(double), row, 5, hipMemcpyDeviceToHost, h->stream));
+    if (episodes) HIP_COPY(hipMemcpyAsync(episodes, h->d_episodes, (size_t)h->n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    SYNC_CHECKED(h);
     return BSK_OK;
 }
 
@@ -1034,7 +1152,7 @@ int bsk_set_env_base(bsk_handle* h, int64_t env_base) {
 int bsk_sync(bsk_handle* h) {
     if (!h) return fail(BSK_EINVAL, "handle is NULL");
     DeviceGuard guard(h->device);
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    SYNC_CHECKED(h);
     return BSK_OK;
 }
 
@@ -1062,7 +1180,7 @@ int bsk_profile_end_samples(bsk_handle* h, double* mean_kernel_ms, int* n_launch
     if (!h) return fail(BSK_EINVAL, "handle is NULL");
     DeviceGuard guard(h->device);
     h->prof = false;
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_SYNC(hipStreamSynchronize(h->stream));
     double tot = 0.0;
     const int n = h->ev_used / 2;
     for (int k = 0; k < n; ++k) {

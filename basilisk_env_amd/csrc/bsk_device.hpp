@@ -27,19 +27,15 @@
 #include <type_traits>
 
 #include "../../include/bskgpu.h"
+#include "bsk_probes.hpp"
 
 namespace bsk {
 
 // A taken branch costs a wave that runs alone on its SIMD ~55 clocks of instruction fetch (SQ_WAIT_ANY of the
 // full-scenario level: 12 taken branches per tick = 15 % of its cycles).  Blocks that are rarely entered are marked so
 // that the compiler lays them out of line and the common path falls through.
-#ifdef BSK_NO_EXPECT
-#define BSK_UNLIKELY(x) (x)
-#define BSK_LIKELY(x) (x)
-#else
 #define BSK_LIKELY(x) __builtin_expect(!!(x), 1)
 #define BSK_UNLIKELY(x) __builtin_expect(!!(x), 0)
-#endif
 
 struct V3 {
     double x, y, z;
@@ -85,29 +81,6 @@ __device__ __forceinline__ double rcp_nr(double x) {
     e = fma(-x, y, 1.0);
     return fma(y, e, y);
 }
-// exp(x) for the atmosphere's density (|x| far from the overflow range; underflows to 0 through ldexp): one
-// range reduction x = n ln2 + r, |r| <= ln2 / 2, and the degree-13 Taylor polynomial (truncation 4e-18): 19
-// instructions against ~35 of the library routine with its special-case handling.
-__device__ __forceinline__ double exp_fast(double x) {
-    const double n = __builtin_rint(x * 1.4426950408889634074);
-    double r = fma(-n, 6.93147180369123816490e-01, x);
-    r = fma(-n, 1.90821492927058770002e-10, r);
-    double p = 1.0 / 6227020800.0;
-    p = fma(p, r, 1.0 / 479001600.0);
-    p = fma(p, r, 1.0 / 39916800.0);
-    p = fma(p, r, 1.0 / 3628800.0);
-    p = fma(p, r, 1.0 / 362880.0);
-    p = fma(p, r, 1.0 / 40320.0);
-    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);
-    p = fma(p, r, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return ldexp(p, (int)n);
-}
 // sqrt(x) for x >= 0 (0 -> 0): x * rsqrt(x)
 __device__ __forceinline__ double sqrt_nr(double x) { return x > 0.0 ? x * rsqrt_nr(x) : 0.0; }
 
@@ -142,9 +115,9 @@ template <int NRW, bool DIAG>
 struct HotCfg {
     double h, h2, h3, h6;  // dt, dt/2, dt/3, dt/6
     double nmu, j2k;       // -mu,  1.5 * J2 * mu * req^2
-    double I[DIAG ? 3 : 9];
-    double Di[DIAG ? 3 : 9];  // (I_sc - sum Js g g^T)^-1
-    double W[DIAG ? 3 : 9];   // sum Js g g^T  (wheel-momentum ODE, see rk4_step)
+    double Dm[DIAG ? 3 : 9];  // I_sc - sum Js g g^T   (the hub's inertia without the wheels' spin-axis part)
+    double Di[DIAG ? 3 : 9];  // its inverse
+    double W[DIAG ? 3 : 9];   // sum Js g g^T  (wheel momentum as a function of omega, see rk4_step)
     double g[NRW > 0 ? NRW : 1][3];
     double js[NRW > 0 ? NRW : 1], ijs[NRW > 0 ? NRW : 1];
     double fc;
@@ -185,7 +158,7 @@ struct ColdCfg {
     int32_t nav_lag, pad3_;   // bsk_config.nav_lag: FSW ticks run before the dynamics task of their time
     // wave-uniform constants of the full-scenario kernels: three rows of 16 doubles, fetched lane-wise into three
     // VGPR pairs (lane l holds entry l & 15 of each row) and fed to the FMAs through the DPP row broadcast (KTab)
-    double kt[64];
+    double kt[80];
     // force / torque sums of every subset of the thrusters at full thrust, body frame: row m = sum over the bits
     // of m of (thr_f[i], thr_l[i]) added in ascending i (the oracle's order), so an 8-term conditional sum with
     // 48 table loads per integrator stage becomes one 6-double row picked by the activity mask
@@ -194,8 +167,9 @@ struct ColdCfg {
 // entries of the broadcast table (ColdCfg::kt): row A, row B, row C
 enum { KA_G = 0, KA_JS = 12 };                                 // wheel spin axes g[i][k] at 3 i + k, Js_i
 enum { KB_IJS = 0, KB_FAC = 4, KB_FAD = 10 };                  // 1/Js_i, facet half sums / differences (6 + 6)
-enum { KC_IMASS = 0, KC_NB = 1, KC_KFLUX = 4, KC_RHO0 = 5, KC_NIH = 6, KC_REQIH = 7, KC_RSKIP = 8 };   // 1/m, panel normal, ...
+enum { KC_IMASS = 0, KC_NB = 1, KC_KFLUX = 4, KC_RHO0 = 5, KC_NIH = 6, KC_REQIH = 7, KC_RSKIP = 8, KC_LOG2E = 9 };   // 1/m, panel normal, ...
 enum { KD_JG = 0, KD_HIJS = 12 };                              // row D: Js_i g[i][k] at 3 i + k, dt / Js_i
+enum { KE_POLY = 0, KE_NLN2HI = 14, KE_NLN2LO = 15 };          // row E: rho0 / k!, k = 0..13 (atmosphere_density); -ln2 in two parts
 
 // Guidance / observation / reward constants: by value in the kernarg (used once per launch, outside
 // the RK4 loop, so they may be parked in VGPR lanes across it at no cost to the loop).
@@ -209,9 +183,7 @@ struct ObsCfg {
 // wheels, and together with the rest of HotCfg they overflow the SGPR file; a VGPR operand costs
 // a VALU instruction nothing, an SGPR spill costs a v_readlane per use.
 __device__ __forceinline__ double to_vgpr(double x) {
-#ifndef BSK_WHEEL_SGPR
     asm volatile("" : "+v"(x));
-#endif
     return x;
 }
 template <int NRW>
@@ -226,10 +198,9 @@ struct WheelV {
             js_[i] = to_vgpr(c.js[i]); ijs_[i] = to_vgpr(c.ijs[i]);
         }
     }
-    // head of an RK4 step: T = sum tq_i g_i, p = sum (Js_i Om_i) g_i, tqj_i = tq_i / Js_i
+    // head of an RK4 step: T = sum tq_i g_i, p += sum (Js_i Om_i) g_i (the caller's W w0, see rk4_step), tqj_i = tq_i / Js_i
     __device__ __forceinline__ void head(const double* tq, const double* Om, V3& T, V3& p, double* tqj) const {
         T = mk(0, 0, 0);
-        p = mk(0, 0, 0);
 #pragma unroll
         for (int i = 0; i < NRW; ++i) {
             const V3 g = mk(g_[i][0], g_[i][1], g_[i][2]);
@@ -399,18 +370,6 @@ __device__ __forceinline__ double percent_shadow(const PowerCfg& pc, V3 r_HB, V3
     return percent_shadow_generic(sa, sb, cc);
 }
 
-__device__ __forceinline__ double shadow_factor(const PowerCfg& pc, const SunGeom& g, V3 r) {
-    const double rs = dot(r, g.sun), r2 = dot(r, r);
-    if (r2 < 2.0 * rs) return 1.0;                       // day side of the planet
-    const double s0 = -rs * g.ism;
-    const double c1 = s0 + g.re_sf1, c2 = s0 - g.re_sf2;
-    const double l2v = fma(-s0, s0, r2);                 // squared distance from the shadow axis
-    const double l1 = c1 * g.tf1, l2 = c2 * g.tf2;
-    if (l2v < l2 * l2 && c2 < 0.0) return 0.0;          // inside the umbra cone: the disc is fully covered
-    if (l2v < l2 * l2 || l2v < l1 * l1) return percent_shadow(pc, g.sun - r, r, r2);   // penumbra / antumbra band
-    return 1.0;
-}
-
 // The EnvTask of one dyn tick (eclipse -> simpleSolarPanel -> simpleBattery <- simplePowerSink), split so that the
 // one expensive piece — the partially eclipsed disc, percent_shadow, ~250 issue slots — leaves the tick loop.
 // With one spacecraft per lane the wave pays that path whenever ANY of its 64 spacecraft is in the penumbra, and
@@ -431,10 +390,7 @@ __device__ __forceinline__ double shadow_factor(const PowerCfg& pc, const SunGeo
 // entries and a tick that finds it full evaluates its factor on the spot (never in LEO: 192 entries are three spacecraft in
 // the penumbra for the whole record), so the worst case costs time, not correctness.
 constexpr int PEN_CHUNK = 10;                 // RK4 ticks per trip of the inner loop at most (third-body anchor)
-#ifndef PEN_SLOTS_OVERRIDE
-#define PEN_SLOTS_OVERRIDE 30
-#endif
-constexpr int PEN_SLOTS = PEN_SLOTS_OVERRIDE; // ticks recorded between two flushes
+constexpr int PEN_SLOTS = 30;                 // ticks recorded between two flushes
 constexpr int PEN_QCAP = 192;                 // penumbra queue entries per record
 struct PowerLds {                             // one per wavefront, in dynamic LDS (38.5 KB: four waves per CU fit the 160 KB)
     double g[PEN_SLOTS][64];
@@ -455,10 +411,9 @@ typedef PowerLds __attribute__((address_space(3))) * LdsP;
 // ring, double-buffered by chunk of PAIR_CHUNK ticks, and the state at FSW ticks in `box`; the other wave answers in `box`
 // with the commands (wheel torques, thruster burst) and, at the end of the launch, with battery charge, shadow factor and
 // the FSW bookkeeping.  80 KB per pair with chunks of 10 ticks (38.9 KB with chunks of 4, which four pairs per CU would need).
-#ifndef PAIR_CHUNK_OVERRIDE
-#define PAIR_CHUNK_OVERRIDE 10    // = PEN_CHUNK: the same chunks as the single-wave form (same third-body anchors: bit-identical
-#endif                            // results at every level); 80 KB of LDS per pair - the form is used up to one pair per CU
-constexpr int PAIR_CHUNK = PAIR_CHUNK_OVERRIDE;
+// = PEN_CHUNK: the same chunks as the single-wave form (same third-body anchors: bit-identical results at every level);
+// 80 KB of LDS per pair - the form is used up to one pair per CU
+constexpr int PAIR_CHUNK = 10;
 struct PairLds {
     double rr[2][3][PAIR_CHUNK][64];          // ring: position after each tick of the chunk
     double rs[2][3][PAIR_CHUNK][64];          // ring: sigma_BN after each tick
@@ -492,6 +447,7 @@ constexpr int PART_ALL = 0, PART_ROT = 1, PART_TRA = 2;   // which half of the s
 //  * a poll that does not see its tag within TRI_SPIN_LIMIT reads gives up for the rest of the launch and raises `err` (the
 //    observation is then NaN): every wave reaches the end of the kernel whatever the other one does.
 constexpr int TRI_SPIN_LIMIT = 1 << 20;
+enum { BSK_DEVERR_TRI_EXCHANGE = 1 };      // values of the handle's device error word (bsk_capi.hip: check_device_error)
 struct TriX {
     double v[4][4][64];                       // translational -> rotational: stage velocity; row 3: the next tick's density
     double s[4][3][64];                       // rotational -> translational: stage attitude
@@ -506,9 +462,16 @@ struct TriLds {
 typedef TriX __attribute__((address_space(3))) * TriXP;
 typedef TriLds __attribute__((address_space(3))) * TriP;
 
-// The exchange's LDS accesses are RELAXED ATOMICS of workgroup scope: the compiler neither merges, drops nor reorders them
-// against each other, and - unlike volatile accesses, each of which it follows with a wait for its completion - it leaves
-// a batch of reads in flight until the first use of a result.
+// The exchange's LDS accesses are RELAXED ATOMICS of workgroup scope: the compiler neither merges nor drops them, and - unlike
+// volatile accesses, each of which it follows with a wait for its completion - it leaves a batch of reads in flight until
+// the first use of a result.  What relaxed atomics do NOT promise is their order against each other (different addresses), and
+// the protocol needs two orders: rows BEFORE the tag on the publishing side, tag BEFORE the rows on the consuming side.
+//  * against the COMPILER: tri_order() between the two groups - a compiler barrier, no instruction;
+//  * in the HARDWARE: the LDS operations of one wave are issued and executed in program order (one in-order queue per CU),
+//    so no wait is needed between them.  A release store / acquire load of workgroup scope would say the same thing
+//    portably, and costs an s_waitcnt vmcnt(0) lgkmcnt(0) per publish / consume on this target - eight drains of the
+//    wave's whole memory pipeline per tick on the critical path of the form whose only purpose is latency.
+__device__ __forceinline__ void tri_order() { asm volatile("" ::: "memory"); }
 __device__ __forceinline__ void tri_st(double __attribute__((address_space(3))) * p, double v) {
     __hip_atomic_store((long long __attribute__((address_space(3)))*)p, __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -529,21 +492,23 @@ struct TriXch {
     int lane;
     int np, nc;     // values published / consumed (wave-uniform)
     bool dead;      // a poll timed out: no more waiting in this launch
-#ifdef BSK_TRI_DEBUG
-    unsigned dbg_miss = 0, dbg_spin = 0;          // finishes whose first read was early; re-reads
-    unsigned long long dbg_cyc = 0;               // cycles spent re-reading
-#endif
+    unsigned dbg_miss = 0, dbg_spin = 0;          // probe builds only (bsk_probes.hpp: TRI_XCHG): finishes whose first read
+    unsigned long long dbg_cyc = 0;               // was early; re-reads; cycles spent re-reading
     template <bool EXTRA>
     __device__ __forceinline__ void publish(V3 a, double extra) {
+        if constexpr (probe::TRI_NOPUBLISH && PART == PART_TRA) { ++np; return; }   // fault injection (probe builds): the partner times out
         const int slot = np & 3;
         if constexpr (PART == PART_TRA) {
             tri_st(&X->v[slot][0][lane], a.x); tri_st(&X->v[slot][1][lane], a.y); tri_st(&X->v[slot][2][lane], a.z);
             if constexpr (EXTRA) tri_st(&X->v[slot][3][lane], extra);
+            tri_order();                               // rows, THEN the tag
             tri_sti(&X->tv[slot][lane], np + 1);
         } else {
             tri_st(&X->s[slot][0][lane], a.x); tri_st(&X->s[slot][1][lane], a.y); tri_st(&X->s[slot][2][lane], a.z);
+            tri_order();
             tri_sti(&X->ts[slot][lane], np + 1);
         }
+        tri_order();
         ++np;
     }
     template <bool EXTRA>
@@ -553,9 +518,11 @@ struct TriXch {
         f.e = 0.0;
         if constexpr (PART == PART_TRA) {
             f.tag = tri_ldi(&X->ts[slot][lane]);
+            tri_order();                               // the tag, THEN the rows
             f.a = mk(tri_ld(&X->s[slot][0][lane]), tri_ld(&X->s[slot][1][lane]), tri_ld(&X->s[slot][2][lane]));
         } else {
             f.tag = tri_ldi(&X->tv[slot][lane]);
+            tri_order();
             f.a = mk(tri_ld(&X->v[slot][0][lane]), tri_ld(&X->v[slot][1][lane]), tri_ld(&X->v[slot][2][lane]));
             if constexpr (EXTRA) f.e = tri_ld(&X->v[slot][3][lane]);
         }
@@ -565,21 +532,15 @@ struct TriXch {
     __device__ __forceinline__ V3 finish(TriPend f, double& extra) {
         const int want = nc + 1;
         if (BSK_UNLIKELY(__builtin_amdgcn_ballot_w64(f.tag != want) != 0)) {
-#ifdef BSK_TRI_DEBUG
-            ++dbg_miss;
-            const unsigned long long c0 = __builtin_readcyclecounter();
-#endif
+            if constexpr (probe::TRI_XCHG != 0) ++dbg_miss;
+            const probe::Stamp c0 = probe::stamp<probe::TRI_XCHG != 0>();
             for (int spin = 0; !dead; ++spin) {
                 f = prefetch<EXTRA>();
-#ifdef BSK_TRI_DEBUG
-                ++dbg_spin;
-#endif
+                if constexpr (probe::TRI_XCHG != 0) ++dbg_spin;
                 if (__builtin_amdgcn_ballot_w64(f.tag != want) == 0) break;
                 if (spin > TRI_SPIN_LIMIT) { dead = true; X->err = 1; }
             }
-#ifdef BSK_TRI_DEBUG
-            dbg_cyc += __builtin_readcyclecounter() - c0;
-#endif
+            probe::since<probe::TRI_XCHG != 0>(dbg_cyc, c0);
         }
         ++nc;
         if constexpr (EXTRA) extra = f.e;
@@ -598,7 +559,7 @@ struct TriXch {
 // of the wave must be active where these are used: the full-scenario kernels keep the RK4 loop's trip count and
 // the drag / thruster switches wave-uniform.  asm volatile keeps the compiler from sinking one into a branch.
 struct KTab {
-    double a, b, c;
+    double a, b, c, e;
 };
 template <int K>
 __device__ __forceinline__ double fmac_k(double acc, double tab, double x) {        // acc + tab[K] * x
@@ -625,12 +586,40 @@ __device__ __forceinline__ double get_k(double tab) {                           
     return r;
 }
 
+// exponentialAtmosphere (leoPowerAttitudeSimulator.py:265-271): rho0 exp(-(|r| - Re) / H) from rm = |r|, 0 below the skip
+// density (|a_drag| < 1e-19 m/s^2 there).  exp(x) = 2^n e^r with x = n ln2 + r, |r| <= ln2 / 2, and the degree-13 Taylor
+// polynomial (truncation 4e-18), its coefficients - scaled by rho0 - in row E of the broadcast table.  A polynomial wants
+// its constants as ADDENDS and gfx950 has neither 64-bit literals nor a free scalar register in this loop: left to the
+// compiler the thirteen literals are hoisted out of the tick loop and, the register file being full, parked in AGPRs (two
+// v_accvgpr_read per use plus the moves that re-pair them: 27 issue slots per tick); materialised in VCC at each use they
+// cost two scalar moves each - and with one wave per SIMD a scalar instruction takes an issue slot like any other (measured:
+// 81 VALU instructions less, 23 scalar ones more, 3.7 % instead of 9 % faster).  So: seven first-degree pairs c_2j + c_2j+1 r,
+// each a broadcast move + a broadcast FMA, combined by Horner's rule in r^2 - 28 instructions, no scalar ones, no constants
+// in registers.  Moves first, FMAs after: no DPP instruction directly behind the one that wrote its accumulator.
+__device__ __forceinline__ double atmosphere_density(const KTab& kt, double rm) {
+    const double x = fmac_k<KC_NIH>(get_k<KC_REQIH>(kt.c), kt.c, rm);        // Re/H - |r|/H
+    const double n = __builtin_rint(mul_k<KC_LOG2E>(kt.c, x));
+    double r = fmac_k<KE_NLN2HI>(x, kt.e, n);
+    double t0 = get_k<KE_POLY + 0>(kt.e), t1 = get_k<KE_POLY + 2>(kt.e), t2 = get_k<KE_POLY + 4>(kt.e), t3 = get_k<KE_POLY + 6>(kt.e);
+    r = fmac_k<KE_NLN2LO>(r, kt.e, n);
+    double t4 = get_k<KE_POLY + 8>(kt.e), t5 = get_k<KE_POLY + 10>(kt.e), t6 = get_k<KE_POLY + 12>(kt.e);
+    const double r2 = r * r;
+    t0 = fmac_k<KE_POLY + 1>(t0, kt.e, r); t1 = fmac_k<KE_POLY + 3>(t1, kt.e, r); t2 = fmac_k<KE_POLY + 5>(t2, kt.e, r);
+    t3 = fmac_k<KE_POLY + 7>(t3, kt.e, r); t4 = fmac_k<KE_POLY + 9>(t4, kt.e, r); t5 = fmac_k<KE_POLY + 11>(t5, kt.e, r);
+    t6 = fmac_k<KE_POLY + 13>(t6, kt.e, r);
+    double p = fma(t6, r2, t5);
+    p = fma(p, r2, t4);
+    p = fma(p, r2, t3);
+    p = fma(p, r2, t2);
+    p = fma(p, r2, t1);
+    p = fma(p, r2, t0);
+    const double rho = ldexp(p, (int)n);
+    return rho >= get_k<KC_RSKIP>(kt.c) ? rho : 0.0;
+}
+
 // wheel geometry through the broadcast table (rows A and B of KTab): the same operations in the same order per
 // accumulator as WheelV, issued wheel-interleaved so that no DPP FMA follows the instruction that produced one of
 // its operands (the compiler pads that distance with s_nop, and every s_nop costs a one-wave SIMD an issue slot)
-#ifndef BSK_FOLD_JS
-#define BSK_FOLD_JS 1
-#endif
 // FOLD (the full-scenario levels): the wheel inertia folded into the table.  The LDS-scratch level keeps the unfolded
 // form, whose operations per accumulator are those of WheelV - it is held bit-identical to the register kernel.
 template <int NRW, bool FOLD>
@@ -664,8 +653,7 @@ struct WheelDpp<NRW, true> : WheelDppBase<NRW> {
     // directly and the end-of-step base is one DPP FMA per wheel - no Js Om_i / tq_i / Js_i intermediates, each of
     // which cost a zero-initialising move and a one-term chain (16 issue slots per step less)
     __device__ __forceinline__ void head(const double* tq, const double* Om, V3& T, V3& p, double* tqj) const {
-        T = mk(0, 0, 0);
-        p = mk(0, 0, 0);
+        T = mk(0, 0, 0);        // (p comes in as W w0 and takes the wheels' momentum on top)
         auto wheel = [&](auto IC) {
             constexpr int i = decltype(IC)::value;
             T.x = fmac_k<KA_G + 3 * i>(T.x, ta, tq[i]); T.y = fmac_k<KA_G + 3 * i + 1>(T.y, ta, tq[i]); T.z = fmac_k<KA_G + 3 * i + 2>(T.z, ta, tq[i]);
@@ -696,8 +684,7 @@ struct WheelDpp<NRW, false> : WheelDppBase<NRW> {
     }
     __device__ __forceinline__ void head(const double* tq, const double* Om, V3& T, V3& p, double* tqj) const {
         double jo[NRW > 0 ? NRW : 1];
-        T = mk(0, 0, 0);
-        p = mk(0, 0, 0);
+        T = mk(0, 0, 0);        // (p comes in as W w0)
 #pragma unroll
         for (int i = 0; i < NRW; ++i) { jo[i] = 0.0; tqj[i] = 0.0; }
         if constexpr (NRW > 0) jo[0] = fmac_k<KA_JS + 0>(jo[0], ta, Om[0]);
@@ -720,11 +707,32 @@ struct WheelDpp<NRW, false> : WheelDppBase<NRW> {
     }
 };
 
-// shadow factor where it is cheap (1 lit, 0 umbra), `band` where the disc is partially covered
-__device__ __forceinline__ double shadow_quick(const SunGeom& g, V3 r, bool& band) {
+// The two coefficients of the MRP rotation  [BN] = I + (8 s~^2 - 4 (1 - s^2) s~) / (1 + s^2)^2:  ka = 8 / (1 + s^2)^2,
+// kb = 4 (1 - s^2) / (1 + s^2)^2 (12 instructions, one of them a quarter-rate reciprocal).  One definition for every place
+// that rotates with an attitude (panel, drag, thrusters), so that a value computed at one site can stand in at another.
+struct MrpRot {
+    double ka, kb;
+};
+__device__ __forceinline__ MrpRot mrp_rot_q2(double q2) {                    // q2 = |sigma|^2
+    const double op = 1.0 + q2, iop2 = rcp_nr(op * op);
+    return MrpRot{8.0 * iop2, 4.0 * (1.0 - q2) * iop2};
+}
+__device__ __forceinline__ MrpRot mrp_rot(V3 sig) { return mrp_rot_q2(dot(sig, sig)); }
+// What the end of one dyn tick already knows about the state the next tick starts from (full-scenario single-wave
+// kernels): the EnvTask evaluates |r|^2 (eclipse) and the rotation coefficients of the attitude (panel) of exactly the
+// state whose first integrator stage needs both again (gravity; drag / thrust rotation), and the atmosphere needs 1/|r|
+// (ir: filled in by the tick's head).  Carried across the tick boundary instead of being computed twice: 21 instructions
+// and two quarter-rate ones per tick less; the same operations on the same operands, so the same bits.
+struct Pre {
+    double r2, ir;
+    MrpRot rot;
+};
+
+// shadow factor where it is cheap (1 lit, 0 umbra), `band` where the disc is partially covered; r2 = |r|^2
+__device__ __forceinline__ double shadow_quick(const SunGeom& g, V3 r, double r2, bool& band) {
     // branch-free: with 64 spacecraft per wave every path is taken by some lane anyway, and each divergent branch
     // costs exec-mask bookkeeping on the scalar unit
-    const double rs = dot(r, g.sun), r2 = dot(r, r);
+    const double rs = dot(r, g.sun);
     const double s0 = -rs * g.ism;
     const double c1 = s0 + g.re_sf1, c2 = s0 - g.re_sf2;
     const double l2v = fma(-s0, s0, r2);                 // squared distance from the shadow axis
@@ -740,39 +748,36 @@ __device__ __forceinline__ double shadow_quick(const SunGeom& g, V3 r, bool& ban
 // factor where it is cheap, `band` where the disc is partially covered.  One definition for the single-wave kernels' tick
 // record and the pair form's environment wave: the same operations in the same order.
 template <bool LDSK>
-__device__ __forceinline__ void power_eval(const PowerCfg& pc, const SunGeom& g, V3 r, V3 sig, double tc, double& gain, double& sh, bool& band) {
-    sh = shadow_quick(g, r, band);
+__device__ __forceinline__ void power_eval(const PowerCfg& pc, const SunGeom& g, V3 r, V3 sig, double tc, double& gain, double& sh, bool& band,
+                                           Pre* next = nullptr, const double* q2_known = nullptr) {
+    const double r2 = dot(r, r);
+    sh = shadow_quick(g, r, r2, band);
     const V3 d = g.sun - r;
     const double d2 = dot(d, d), id = rsqrt_nr(d2);
-    const V3 sN = id * d;
-    // sB = [BN] sN with C = I + (8 s~^2 - 4 (1 - s^2) s~) / (1 + s^2)^2
-    const double q2 = dot(sig, sig), op = 1.0 + q2, iop2 = rcp_nr(op * op);
-    const V3 t1 = cross(sig, sN), t2 = cross(sig, t1);
-    const V3 sB = sN + (8.0 * iop2) * t2 - (4.0 * (1.0 - q2) * iop2) * t1;
+    // dB = [BN] d with the Sun vector left at its length: the panel's cosine is n . dB / |d|, and the flux falls with
+    // 1 / |d|^2, so the three products that would normalise d first fold into one power of 1 / |d|
+    const MrpRot rot = mrp_rot_q2(q2_known ? *q2_known : dot(sig, sig));   // (|sigma|^2 of this attitude: the RK4 step's shadow-set test has it)
+    if (next) { next->r2 = r2; next->rot = rot; }
+    const V3 t1 = cross(sig, d), t2 = cross(sig, t1);
+    const V3 dB = d + rot.ka * t2 - rot.kb * t1;
+    const double id3 = id * id * id;
     if constexpr (LDSK) {     // panel normal and flux constant from the broadcast table (row C)
-        const double proj = fmax(fmac_k<KC_NB>(fmac_k<KC_NB + 1>(mul_k<KC_NB + 2>(tc, sB.z), tc, sB.y), tc, sB.x), 0.0);
-        gain = mul_k<KC_KFLUX>(tc, id * id) * proj;
+        const double proj = fmax(fmac_k<KC_NB>(fmac_k<KC_NB + 1>(mul_k<KC_NB + 2>(tc, dB.z), tc, dB.y), tc, dB.x), 0.0);
+        gain = mul_k<KC_KFLUX>(tc, id3) * proj;
     } else {
-        const double proj = fmax(fma(pc.nB[0], sB.x, fma(pc.nB[1], sB.y, pc.nB[2] * sB.z)), 0.0);
-        gain = pc.kflux * (id * id) * proj;
+        const double proj = fmax(fma(pc.nB[0], dB.x, fma(pc.nB[1], dB.y, pc.nB[2] * dB.z)), 0.0);
+        gain = pc.kflux * id3 * proj;
     }
 }
 
 // per tick: classify, record the panel gain and (when known) the shadow factor of slot t
 template <bool LDSK>
-__device__ __forceinline__ void power_tick(const PowerCfg& pc, const SunGeom& g, V3 r, V3 sig, LdsP L, int t, int lane, double tc) {
+__device__ __forceinline__ void power_tick(const PowerCfg& pc, const SunGeom& g, V3 r, V3 sig, LdsP L, int t, int lane, double tc, Pre* next = nullptr,
+                                           const double* q2_known = nullptr) {
     bool band;
     double sh, gain;
-    power_eval<LDSK>(pc, g, r, sig, tc, gain, sh, band);
-#if defined(BSK_ABLATE) && BSK_ABLATE == 7
-    asm volatile("" ::"v"(gain));
-#else
+    power_eval<LDSK>(pc, g, r, sig, tc, gain, sh, band, next, q2_known);
     L->g[t][lane] = gain;
-#endif
-#if defined(BSK_ABLATE) && BSK_ABLATE == 7   // timing only: the tick's arithmetic without its LDS record
-    asm volatile("" ::"v"(sh), "v"(band ? 1 : 0));
-    return;
-#endif
     if (BSK_UNLIKELY(band)) {
         const int e = __hip_atomic_fetch_add(&L->qcount, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         if (BSK_LIKELY(e < PEN_QCAP)) {
@@ -794,24 +799,15 @@ __device__ __forceinline__ void power_flush(const PowerCfg& pc, LdsP L, int m, i
     // The queue counter and the whole record are read in ONE batch (2 x PEN_SLOTS + 1 LDS reads in flight): the wave
     // is alone on its SIMD and waits every round trip out.  Only when the queue holds something (rare) the record's
     // shadow factors are read again after the drain has filled them in.
-#ifndef BSK_FLUSH_ONE_TRIP
-#define BSK_FLUSH_ONE_TRIP 1
-#endif
     const double draw = pc.draw, cap = pc.cap;
     double sk[PEN_SLOTS], dq[PEN_SLOTS];
     const int qc = min(L->qcount, PEN_QCAP);               // (pushes beyond the capacity were evaluated in place)
-#if BSK_FLUSH_ONE_TRIP
 #pragma unroll
     for (int k = 0; k < PEN_SLOTS; ++k) {
         sk[k] = L->s[k][lane];
         dq[k] = L->g[k][lane];
     }
-#endif
-#if defined(BSK_ABLATE) && BSK_ABLATE == 8   // timing only: record read back and replayed, queue never drained
-    if (false) {
-#else
     if (BSK_UNLIKELY(qc > 0)) {                           // wave-uniform
-#endif
         for (int e = lane; e < qc; e += 64) {
             const int own = L->qown[e], ol = own & 63, k = own >> 8;
             const V3 r = mk(L->qr[0][e], L->qr[1][e], L->qr[2][e]);
@@ -821,21 +817,12 @@ __device__ __forceinline__ void power_flush(const PowerCfg& pc, LdsP L, int m, i
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (lane == 0) L->qcount = 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#if BSK_FLUSH_ONE_TRIP
 #pragma unroll
         for (int k = 0; k < PEN_SLOTS; ++k) sk[k] = L->s[k][lane];
-#endif
     }
     // Replay: the energy increments p_k h in parallel, then only the clamped sums are a dependent chain (three
     // operations per tick; one wave per SIMD pays every dependent instruction's full latency).  charge + (p h) with
     // p h rounded first is what the non-fused reference arithmetic does.
-#if !BSK_FLUSH_ONE_TRIP
-#pragma unroll
-    for (int k = 0; k < PEN_SLOTS; ++k) {
-        sk[k] = L->s[k][lane];
-        dq[k] = L->g[k][lane];
-    }
-#endif
 #pragma unroll
     for (int k = 0; k < PEN_SLOTS; ++k) dq[k] = fma(dq[k], sk[k], draw) * h;
 #pragma unroll
@@ -1124,6 +1111,15 @@ __device__ __forceinline__ V3 tidal(const Sun3& s3, V3 r, V3 base) {
     return mk(fma(s3.k, fma(t, s3.sh.x, -r.x), base.x), fma(s3.k, fma(t, s3.sh.y, -r.y), base.y),
               fma(s3.k, fma(t, s3.sh.z, -r.z), base.z));
 }
+// The third body's acceleration of one RK4 step: A0 + G r_m at the step's midpoint estimate r_m = r + h/2 v, held through
+// the four stages.  The tidal term is linear in r, so RK4's weights integrate its variation along the step exactly to first
+// order either way; what freezing drops is G h^2/6 a_grav per step in the velocity increment (k = 4e-14 s^-2, a_grav =
+// 8.7 m/s^2: 6e-17 h^3 m/s, i.e. 1e-20 of the velocity per step at h = 0.1 s and 8e-18 at h = 1 s) and k v h^3 / 12 in
+// the position (3e-14 m per step at h = 0.1 s) - both far below one ulp, like the anchor's own second-order term.  One
+// evaluation (13 instructions) per step instead of four tidal products (40).  Rounds 2-3 evaluated A0 + G r per stage.
+__device__ __forceinline__ V3 third_body_step(const Sun3& s3, V3 r, V3 v, double h2) {
+    return tidal(s3, axpy(h2, v, r), s3.A0);
+}
 __device__ __forceinline__ void third_body_anchor(Sun3& s3, V3 sun, double mu, V3 rc) {
     const V3 a = third_body_exact(sun, mu, s3.k, rc);
     const V3 g = tidal(s3, rc, mk(0, 0, 0));
@@ -1132,8 +1128,9 @@ __device__ __forceinline__ void third_body_anchor(Sun3& s3, V3 sun, double mu, V
 
 // `base` is added to the result (the third body's constant part at the full-scenario levels: one FMA instead of a
 // multiply and an add per component)
+// `pre` (full-scenario single-wave kernels, first stage): |r|^2 and 1/|r| of this position are known already
 template <int GRAV, int SPLIT, class Hot>
-__device__ __forceinline__ V3 gravity(const Hot& c, V3 r, double tsim, V3 base) {
+__device__ __forceinline__ V3 gravity(const Hot& c, V3 r, double tsim, V3 base, const Pre* pre = nullptr) {
     if constexpr (GRAV == BSK_GRAV_SH) {
         double sn, cs;
         sincos(c.planet_rate * tsim, &sn, &cs);
@@ -1145,8 +1142,8 @@ __device__ __forceinline__ V3 gravity(const Hot& c, V3 r, double tsim, V3 base) 
         return mk(fma(cs, af.x, fma(-sn, af.y, base.x)), fma(sn, af.x, fma(cs, af.y, base.y)), af.z + base.z);
     } else {
         double zz = r.z * r.z;
-        double r2 = fma(r.x, r.x, fma(r.y, r.y, zz));
-        double ir = rsqrt_nr(r2);
+        double r2 = pre ? pre->r2 : fma(r.x, r.x, fma(r.y, r.y, zz));
+        double ir = pre ? pre->ir : rsqrt_nr(r2);
         double ir2 = ir * ir;
         double ir3 = ir * ir2;
         double k0 = c.nmu * ir3;
@@ -1212,15 +1209,14 @@ __device__ __forceinline__ void thr_masks(Env& ev) {
 // thrust of the active thrusters at integrator stage `de2` (0, 1, 1, 2 half dyn steps after the tick started)
 // PART (three-wave form): 0 = force and torque, PART_ROT = the torque only, PART_TRA = the force only
 template <int PART = PART_ALL>
-__device__ __forceinline__ void thrusters(const Env& ev, int de2, V3 sig, V3& aN, V3& LB) {
+__device__ __forceinline__ void thrusters(const Env& ev, int de2, V3 sig, MrpRot rot, V3& aN, V3& LB) {
     V3 FB = ev.FB0;
     LB = ev.LB0;
     const int mk_ = de2 == 0 ? ev.m0 : (de2 == 1 ? ev.m1 : ev.m2);
     if (mk_ != ev.m0) thr_row(ev.cold, mk_, FB, LB);      // a pulse ends inside this dyn step
     if constexpr (PART == PART_ROT) { aN = mk(0, 0, 0); return; }
-    const double q2 = dot(sig, sig), op = 1.0 + q2, iop2 = rcp_nr(op * op);
     const V3 u1 = cross(sig, FB), u2 = cross(sig, u1);
-    const V3 FN = FB + (8.0 * iop2) * u2 + (4.0 * (1.0 - q2) * iop2) * u1;                      // [BN]^T F_B
+    const V3 FN = FB + rot.ka * u2 + rot.kb * u1;                                               // [BN]^T F_B
     aN = mk(mul_k<KC_IMASS>(ev.kt.c, FN.x), mul_k<KC_IMASS>(ev.kt.c, FN.y), mul_k<KC_IMASS>(ev.kt.c, FN.z));   // / m
 }
 
@@ -1232,10 +1228,9 @@ __device__ __forceinline__ void thrusters(const Env& ev, int de2, V3 sig, V3& aN
 // PART_TRA / PART_ROT: only the projected-area sum and the acceleration / only its moment and the torque (each accumulator
 // takes the same terms in the same order as in the whole form)
 template <bool GENERIC, int PART = PART_ALL>
-__device__ __forceinline__ void facet_drag(const Env& ev, V3 sig, V3 vN, V3& aN, V3& LB) {
+__device__ __forceinline__ void facet_drag(const Env& ev, V3 sig, MrpRot rot, V3 vN, V3& aN, V3& LB) {
     static_assert(PART == PART_ALL || !GENERIC, "the halves exist for the axis-aligned facet tables only");
-    const double q2 = dot(sig, sig), op = 1.0 + q2, iop2 = rcp_nr(op * op);
-    const double ka = 8.0 * iop2, kb = 4.0 * (1.0 - q2) * iop2;
+    const double ka = rot.ka, kb = rot.kb;
     const V3 t1 = cross(sig, vN), t2 = cross(sig, t1);
     const V3 vB = vN + ka * t2 - kb * t1;                 // [BN] v
     // |v|^2 (n . v^)+ v^ = (n . v)+ v: the projected-area sums are homogeneous in v, so nothing is normalised
@@ -1303,13 +1298,20 @@ __device__ __forceinline__ void facet_drag(const Env& ev, V3 sig, V3 vN, V3& aN,
 
 // Integration state inside one RK4 step.  The hub sees the wheels only through their total
 // momentum p = sum Js Om_i g_i (body frame), and with the wheel torque tq held over the step the
-// momentum obeys a closed ODE:
-//     [I - W] w' = L_ext - T - w x (I w + p),      p' = T - W w',      T = sum tq_i g_i,  W = sum Js g g^T
-// so the four stages integrate (r, v, sigma, w, p) — 15 doubles — and the individual wheel
-// speeds follow EXACTLY (RK4 is linear in w') from  Om_i(t+h) = Om_i + h tq_i/Js_i - g_i . (w(t+h) - w(t)).
-// That is the same map as RK4 on [.., Om_1..n] with 36 wheel ops per stage replaced by 9.
+// momentum obeys      p' = T - W w',      T = sum tq_i g_i,  W = sum Js g g^T,
+// which is LINEAR in w' with constant T: every RK4 stage value of p follows exactly from that stage's w,
+//     p_i = p_0 + a_i T - W (w_i - w_0)          (a_i = 0, h/2, h/2, h),
+// so p is not integrated at all.  The stage's total angular momentum is
+//     H_i = I w_i + p_i = [I - W] w_i + c_i,     c_i = (p_0 + W w_0) + a_i T,
+// with [I - W] the matrix whose inverse the back-substitution needs anyway:
+//     [I - W] w' = L_ext - T - w x H.
+// The four stages integrate (r, v, sigma, w) - 12 doubles - with `p` of the stage state holding c_i (three values per
+// step: c_1, c_2 = c_3, c_4), and the individual wheel speeds follow EXACTLY (RK4 is linear in w') from
+//     Om_i(t+h) = Om_i + h tq_i/Js_i - g_i . (w(t+h) - w(t)).
+// That is the same map as RK4 on [.., Om_1..n], with 36 wheel operations per stage replaced by 3 (round 4; rounds 1-3
+// integrated p beside w: 9 more per stage).
 struct Core {
-    V3 r, v, s, w, p;
+    V3 r, v, s, w, p;      // p: the stage's momentum offset c_i (above), not integrated
 };
 
 // THR: the step runs inside a thruster burst of some lane of the wave (the tick loop picks the instantiation, so the
@@ -1321,25 +1323,27 @@ struct Core {
 // PH (the halves only): 1 = what does not need the other wave's value (r' and the gravity / Sun part of v'; sigma'),
 // 2 = the rest (drag and thrust; w', p'), 0 = everything
 template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT, bool THR, int DRAGM = 0, int PART = PART_ALL, int PH = 0>
-__device__ __forceinline__ void eom(const HotCfg<NRW, DIAG>& c, const Core& x, V3 rhs0, V3 T, double tsim, const Env& ev,
-                                    int de2, Core& d) {
+__device__ __forceinline__ void eom(const HotCfg<NRW, DIAG>& c, const Core& x, V3 rhs0, V3 a3, double tsim, const Env& ev,
+                                    int de2, Core& d, const Pre* pre = nullptr) {
     static_assert(PH == 0 || PART != PART_ALL, "phases exist for the halves");
     if constexpr (PART != PART_ROT && PH != 2) d.r = x.v;
     if constexpr (is_full<FEAT>()) {
-        // Sun third body, unconditionally: with the flag off k and A0 are zero and both FMAs return their addend
-        if constexpr (PART != PART_ROT && PH != 2) d.v = tidal(ev.s3, x.r, gravity<GRAV, SPLIT>(c, x.r, tsim, ev.s3.A0));
+        // Sun third body: the step's constant (third_body_step), folded into the gravity FMAs
+        if constexpr (PART != PART_ROT && PH != 2) d.v = gravity<GRAV, SPLIT>(c, x.r, tsim, a3, pre);
         if constexpr (PH != 1) {
-            if constexpr (DRAGM == 1) facet_drag<FEAT == FEAT_FULLG, PART>(ev, x.s, x.v, d.v, rhs0);
-            else if constexpr (DRAGM == 0) { if (BSK_LIKELY(ev.drag_on)) facet_drag<FEAT == FEAT_FULLG, PART>(ev, x.s, x.v, d.v, rhs0); }
+            MrpRot rot{0.0, 0.0};       // rotation coefficients of this stage's attitude (drag, thrust)
+            if constexpr (DRAGM != 2 || THR) rot = pre ? pre->rot : mrp_rot(x.s);
+            if constexpr (DRAGM == 1) facet_drag<FEAT == FEAT_FULLG, PART>(ev, x.s, rot, x.v, d.v, rhs0);
+            else if constexpr (DRAGM == 0) { if (BSK_LIKELY(ev.drag_on)) facet_drag<FEAT == FEAT_FULLG, PART>(ev, x.s, rot, x.v, d.v, rhs0); }
             if constexpr (THR) {
                 V3 aN, LB;
-                thrusters<PART>(ev, de2, x.s, aN, LB);
+                thrusters<PART>(ev, de2, x.s, rot, aN, LB);
                 if constexpr (PART != PART_ROT) d.v = d.v + aN;
                 if constexpr (PART != PART_TRA) rhs0 = rhs0 + LB;
             }
         }
     } else {
-        if constexpr (PART != PART_ROT && PH != 2) d.v = gravity<GRAV, SPLIT>(c, x.r, tsim, mk(0, 0, 0));
+        if constexpr (PART != PART_ROT && PH != 2) d.v = gravity<GRAV, SPLIT>(c, x.r, tsim, a3);
     }
     if constexpr (PART == PART_TRA) return;
     if constexpr (PH != 2) {
@@ -1354,18 +1358,14 @@ __device__ __forceinline__ void eom(const HotCfg<NRW, DIAG>& c, const Core& x, V
              fma(a, hw.z, fma(b, x.s.z, fma(x.s.x, hw.y, -(x.s.y * hw.x))))};
     }
     if constexpr (PH == 1) return;
-    V3 H;
+    V3 H;      // [I - W] w + c_i
     if constexpr (NRW > 0) {
-        if constexpr (DIAG) H = V3{fma(c.I[0], x.w.x, x.p.x), fma(c.I[1], x.w.y, x.p.y), fma(c.I[2], x.w.z, x.p.z)};
-        else H = mv(c.I, x.w) + x.p;
+        if constexpr (DIAG) H = V3{fma(c.Dm[0], x.w.x, x.p.x), fma(c.Dm[1], x.w.y, x.p.y), fma(c.Dm[2], x.w.z, x.p.z)};
+        else H = mv(c.Dm, x.w) + x.p;
     } else {
-        H = mv3<DIAG>(c.I, x.w);
+        H = mv3<DIAG>(c.Dm, x.w);
     }
     d.w = mv3<DIAG>(c.Di, sub_cross(rhs0, x.w, H));
-    if constexpr (NRW > 0) {
-        if constexpr (DIAG) d.p = V3{fma(-c.W[0], d.w.x, T.x), fma(-c.W[1], d.w.y, T.y), fma(-c.W[2], d.w.z, T.z)};
-        else d.p = T - mv(c.W, d.w);
-    }
 }
 
 template <int NRW, int PART = PART_ALL>
@@ -1377,15 +1377,14 @@ __device__ __forceinline__ void core_axpy(double a, const Core& k, const Core& x
     if constexpr (PART != PART_TRA) {
         o.s = axpy(a, k.s, x.s);
         o.w = axpy(a, k.w, x.w);
-        if constexpr (NRW > 0) o.p = axpy(a, k.p, x.p);
     }
 }
 
-// RK4 accumulator staged in LDS (FEAT_LDSS): acc[f][lane], one 512-byte row per component and wave, every lane
+// RK4 accumulator (12 doubles) staged in LDS (FEAT_LDSS): acc[f][lane], one 512-byte row per component and wave, every lane
 // touches only its own column (conflict-free ds_read_b64 / ds_write_b64, no synchronisation).  volatile: the
 // values must really leave the registers between the stages.
 struct AccLds {
-    double v[15][64];
+    double v[12][64];
 };
 typedef AccLds __attribute__((address_space(3))) * AccP;
 template <int NRW>
@@ -1393,37 +1392,26 @@ __device__ __forceinline__ void acc_store(AccP A, int lane, const Core& a) {
     volatile double __attribute__((address_space(3)))* p = &A->v[0][lane];
     p[0 * 64] = a.r.x; p[1 * 64] = a.r.y; p[2 * 64] = a.r.z; p[3 * 64] = a.v.x; p[4 * 64] = a.v.y; p[5 * 64] = a.v.z;
     p[6 * 64] = a.s.x; p[7 * 64] = a.s.y; p[8 * 64] = a.s.z; p[9 * 64] = a.w.x; p[10 * 64] = a.w.y; p[11 * 64] = a.w.z;
-    if constexpr (NRW > 0) { p[12 * 64] = a.p.x; p[13 * 64] = a.p.y; p[14 * 64] = a.p.z; }
 }
 template <int NRW>
 __device__ __forceinline__ void acc_load(AccP A, int lane, Core& a) {
     const volatile double __attribute__((address_space(3)))* p = &A->v[0][lane];
     a.r = mk(p[0 * 64], p[1 * 64], p[2 * 64]); a.v = mk(p[3 * 64], p[4 * 64], p[5 * 64]);
     a.s = mk(p[6 * 64], p[7 * 64], p[8 * 64]); a.w = mk(p[9 * 64], p[10 * 64], p[11 * 64]);
-    if constexpr (NRW > 0) a.p = mk(p[12 * 64], p[13 * 64], p[14 * 64]);
 }
 
 // classic RK4, sequential accumulation x0 + h/6 k1 + h/3 k2 + h/3 k3 + h/6 k4, then the MRP
 // shadow-set switch once per completed step.  Motor torque and Coulomb friction are evaluated
 // from the wheel speeds at the start of the step and held through its four stages (the RW
 // effector updates both once per dyn tick, outside the equations of motion).
-// keeps the RK4 accumulator's update where it is written (between the volatile DPP chains of two stages) instead of
-// letting the scheduler sink it to the end of the step, which keeps k1..k3 alive (45 doubles) until then
-__device__ __forceinline__ void anchor(V3& a) { asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z)); }
-template <int NRW>
-__device__ __forceinline__ void anchor_core(Core& a) {
-#ifdef BSK_ANCHOR_ACC
-    anchor(a.r); anchor(a.v); anchor(a.s); anchor(a.w);
-    if constexpr (NRW > 0) anchor(a.p);
-#endif
-}
-
 template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT, bool THR = false, int DRAGM = 0, class WV>
 __device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, const WV& wv, State<NRW>& x,
-                                         const double* u, V3 lext, double t0, const Env& ev, AccP acc_lds = nullptr) {
+                                         const double* u, V3 lext, double t0, const Env& ev, AccP acc_lds = nullptr,
+                                         const Pre* pre = nullptr, double* q2_out = nullptr) {
     Core y, k, yt, acc;
     y.r = x.r; y.v = x.v; y.s = x.s; y.w = x.w;
     y.p = mk(0, 0, 0);
+    if constexpr (NRW > 0) y.p = mv3<DIAG>(c.W, y.w);      // W w0: the wheels' momentum goes on top (wv.head)
     V3 T = mk(0, 0, 0);
     double tqj[NRW > 0 ? NRW : 1], tq[NRW > 0 ? NRW : 1];
 #pragma unroll
@@ -1431,42 +1419,36 @@ __device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, const WV& w
         // Coulomb friction -fc sign(Om), 0 at rest, as three fp64 instructions: fc sign(Om) = clamp(2^1000 Om, -fc, fc)
         // (exactly +-fc for every |Om| >= fc 2^-1000 - wheel speeds are 1e-10 rad/s and up - and exactly 0 at rest;
         // the sign-copy + compare + two selects it replaces took six)
-#ifndef BSK_FRICTION_CLAMP
-#define BSK_FRICTION_CLAMP 1
-#endif
-#if BSK_FRICTION_CLAMP
         const double fs = fmin(fmax(x.Om[i] * 0x1p1000, -c.fc), c.fc);
         tq[i] = u[i] - fs;
-#else
-        double fr = __builtin_copysign(c.fc, -x.Om[i]);
-        fr = (x.Om[i] == 0.0) ? 0.0 : fr;
-        tq[i] = u[i] + fr;
-#endif
     }
-    if constexpr (NRW > 0) wv.head(tq, x.Om, T, y.p, tqj);
+    if constexpr (NRW > 0) wv.head(tq, x.Om, T, y.p, tqj);      // y.p = c_1 = p_0 + W w_0
     const V3 rhs0 = lext - T;
+    V3 c2 = y.p, c4 = y.p;                                       // c_2 = c_3 = c_1 + h/2 T,  c_4 = c_1 + h T
+    if constexpr (NRW > 0) { c2 = axpy(c.h2, T, y.p); c4 = axpy(c.h, T, y.p); }
+    V3 a3 = mk(0, 0, 0);
+    if constexpr (is_full<FEAT>()) a3 = third_body_step(ev.s3, y.r, y.v, c.h2);
     constexpr bool LDSACC = FEAT == FEAT_LDSS;
     AccP A = nullptr;
     int lane = 0;
     if constexpr (LDSACC) { A = acc_lds; lane = (int)(threadIdx.x & 63u); }
-    eom<GRAV, NRW, DIAG, FEAT, SPLIT, THR, DRAGM>(c, y, rhs0, T, t0, ev, 0, k);
+    eom<GRAV, NRW, DIAG, FEAT, SPLIT, THR, DRAGM>(c, y, rhs0, a3, t0, ev, 0, k, pre);
     core_axpy<NRW>(c.h6, k, y, acc);
-    if constexpr (is_full<FEAT>()) anchor_core<NRW>(acc);
     if constexpr (LDSACC) acc_store<NRW>(A, lane, acc);
     core_axpy<NRW>(c.h2, k, y, yt);
-    eom<GRAV, NRW, DIAG, FEAT, SPLIT, THR, DRAGM>(c, yt, rhs0, T, t0 + c.h2, ev, 1, k);
+    yt.p = c2;
+    eom<GRAV, NRW, DIAG, FEAT, SPLIT, THR, DRAGM>(c, yt, rhs0, a3, t0 + c.h2, ev, 1, k);
     if constexpr (LDSACC) acc_load<NRW>(A, lane, acc);
     core_axpy<NRW>(c.h3, k, acc, acc);
-    if constexpr (is_full<FEAT>()) anchor_core<NRW>(acc);
     if constexpr (LDSACC) acc_store<NRW>(A, lane, acc);
     core_axpy<NRW>(c.h2, k, y, yt);
-    eom<GRAV, NRW, DIAG, FEAT, SPLIT, THR, DRAGM>(c, yt, rhs0, T, t0 + c.h2, ev, 1, k);
+    eom<GRAV, NRW, DIAG, FEAT, SPLIT, THR, DRAGM>(c, yt, rhs0, a3, t0 + c.h2, ev, 1, k);
     if constexpr (LDSACC) acc_load<NRW>(A, lane, acc);
     core_axpy<NRW>(c.h3, k, acc, acc);
-    if constexpr (is_full<FEAT>()) anchor_core<NRW>(acc);
     if constexpr (LDSACC) acc_store<NRW>(A, lane, acc);
     core_axpy<NRW>(c.h, k, y, yt);
-    eom<GRAV, NRW, DIAG, FEAT, SPLIT, THR, DRAGM>(c, yt, rhs0, T, t0 + c.h, ev, 2, k);
+    yt.p = c4;
+    eom<GRAV, NRW, DIAG, FEAT, SPLIT, THR, DRAGM>(c, yt, rhs0, a3, t0 + c.h, ev, 2, k);
     if constexpr (LDSACC) acc_load<NRW>(A, lane, acc);
     core_axpy<NRW>(c.h6, k, acc, yt);
     const V3 dw = yt.w - y.w;
@@ -1477,7 +1459,11 @@ __device__ __forceinline__ void rk4_step(const HotCfg<NRW, DIAG>& c, const WV& w
     }
     x.r = yt.r; x.v = yt.v; x.s = yt.s; x.w = yt.w;
     double s2 = dot(x.s, x.s);
-    if (BSK_UNLIKELY(s2 > 1.0)) x.s = (-rcp_nr(s2)) * x.s;
+    if (BSK_UNLIKELY(s2 > 1.0)) {
+        x.s = (-rcp_nr(s2)) * x.s;
+        if (q2_out) s2 = dot(x.s, x.s);
+    }
+    if (q2_out) *q2_out = s2;        // |sigma|^2 of the step's attitude, for whoever rotates with it next (EnvTask)
 }
 
 // ---- three-wave form (SPLIT == 3): the RK4 step of one half of the spacecraft (exchange protocol: TriX).
@@ -1504,18 +1490,23 @@ __device__ __forceinline__ void rk4_step_part(const HotCfg<NRW, DIAG>& c, const 
     Core y, k, cur, nxt, acc;
     double none;
     TriPend f;
-#define BSK_EOM(PH, Z, TS, DE) eom<GRAV, NRW, DIAG, FEAT, SPLIT, THR, DRAGM, PART, PH>(c, Z, rhs0, T, TS, ev, DE, k)
+    V3 a3 = mk(0, 0, 0);
+    if constexpr (PART == PART_TRA) a3 = third_body_step(ev.s3, x.r, x.v, c.h2);
+#define BSK_EOM(PH, Z, TS, DE) eom<GRAV, NRW, DIAG, FEAT, SPLIT, THR, DRAGM, PART, PH>(c, Z, rhs0, a3, TS, ev, DE, k)
     if constexpr (PART == PART_ROT) {
         const V3 rhs0 = lext - T;
-        y.s = x.s; y.w = x.w; y.p = pw; y.v = v1;
+        y.s = x.s; y.w = x.w; y.p = pw; y.v = v1;               // pw = c_1 = p_0 + W w_0 (the tick loop's wv.head)
+        V3 c2 = pw, c4 = pw;
+        if constexpr (NRW > 0) { c2 = axpy(c.h2, T, pw); c4 = axpy(c.h, T, pw); }
         // stage 1 (its velocity came with the tick's density: consumed by the tick loop)
         BSK_EOM(1, y, t0, 0);
         acc.s = axpy(c.h6, k.s, y.s);
         nxt.s = axpy(c.h2, k.s, y.s);
         if constexpr (COUPLED) xc.template publish<false>(nxt.s, 0.0);
         BSK_EOM(2, y, t0, 0);
-        acc.w = axpy(c.h6, k.w, y.w); if constexpr (NRW > 0) acc.p = axpy(c.h6, k.p, y.p);
-        nxt.w = axpy(c.h2, k.w, y.w); if constexpr (NRW > 0) nxt.p = axpy(c.h2, k.p, y.p);
+        acc.w = axpy(c.h6, k.w, y.w);
+        nxt.w = axpy(c.h2, k.w, y.w);
+        nxt.p = c2;
         cur = nxt;
         // stage 2
         if constexpr (COUPLED) f = xc.template prefetch<false>();
@@ -1525,8 +1516,8 @@ __device__ __forceinline__ void rk4_step_part(const HotCfg<NRW, DIAG>& c, const 
         if constexpr (COUPLED) xc.template publish<false>(nxt.s, 0.0);
         if constexpr (COUPLED) cur.v = xc.template finish<false>(f, none);
         BSK_EOM(2, cur, t0 + c.h2, 1);
-        acc.w = axpy(c.h3, k.w, acc.w); if constexpr (NRW > 0) acc.p = axpy(c.h3, k.p, acc.p);
-        nxt.w = axpy(c.h2, k.w, y.w); if constexpr (NRW > 0) nxt.p = axpy(c.h2, k.p, y.p);
+        acc.w = axpy(c.h3, k.w, acc.w);
+        nxt.w = axpy(c.h2, k.w, y.w);
         cur = nxt;
         // stage 3
         if constexpr (COUPLED) f = xc.template prefetch<false>();
@@ -1536,8 +1527,9 @@ __device__ __forceinline__ void rk4_step_part(const HotCfg<NRW, DIAG>& c, const 
         if constexpr (COUPLED) xc.template publish<false>(nxt.s, 0.0);
         if constexpr (COUPLED) cur.v = xc.template finish<false>(f, none);
         BSK_EOM(2, cur, t0 + c.h2, 1);
-        acc.w = axpy(c.h3, k.w, acc.w); if constexpr (NRW > 0) acc.p = axpy(c.h3, k.p, acc.p);
-        nxt.w = axpy(c.h, k.w, y.w); if constexpr (NRW > 0) nxt.p = axpy(c.h, k.p, y.p);
+        acc.w = axpy(c.h3, k.w, acc.w);
+        nxt.w = axpy(c.h, k.w, y.w);
+        nxt.p = c4;
         cur = nxt;
         // stage 4: the step's attitude, switched to the inner MRP set where needed, is the next tick's first-stage value
         if constexpr (COUPLED) f = xc.template prefetch<false>();

@@ -30,6 +30,9 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// a wave-uniform condition as an integer in a scalar register
+__device__ __forceinline__ int uni(bool b) { return __builtin_amdgcn_readfirstlane(b ? 1 : 0); }
+
 __device__ __forceinline__ int wave_min_uniform(int v) {
     // every lane holds the same value unless a masked reset staggered the FSW phases inside this wave: one ballot
     // settles the common case, the shuffle tree (six trips through the LDS crossbar) only runs when lanes differ
@@ -40,26 +43,16 @@ __device__ __forceinline__ int wave_min_uniform(int v) {
     return __builtin_amdgcn_readfirstlane(v);
 }
 
-#ifndef BSK_LDSS_WAVES
-#define BSK_LDSS_WAVES 3
-#endif
-#ifndef BSK_MIN_WAVES
-#define BSK_MIN_WAVES 1
-#endif
+constexpr int LDSS_WAVES = 3;   // waves per SIMD the LDS-scratch level is built for (168 VGPRs)
 // SPLIT = 5 (harmonics only): a 256-thread workgroup carries 2 x 64 spacecraft; the two waves of a pair run the
 // cheap RK4 redundantly (bit-identical), each walks half of the Pines entries and they exchange partial
 // sums through LDS: twice the waves per SIMD at the same batch size, so one wave's loads and scalar
 // instructions overlap with the other's FMAs.  Only wave 0 stores.
 template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT>
-__global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPLIT == 3) ? 2 : (FEAT == FEAT_LDSS ? BSK_LDSS_WAVES : BSK_MIN_WAVES)) void step_kernel(const StepArgs<NRW, DIAG> a) {
+__global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPLIT == 3) ? 2 : (FEAT == FEAT_LDSS ? LDSS_WAVES : 1)) void step_kernel(const StepArgs<NRW, DIAG> a) {
     const HotCfg<NRW, DIAG>& c = a.hot;
     const ColdCfg* __restrict__ cold = a.cold;
-#ifdef BSK_PAIR_DEBUG_TIME
-    const unsigned long long dbg_t0 = __builtin_readcyclecounter();
-#endif
-#if defined(BSK_ABLATE) && BSK_ABLATE == 1
-    return;   // launch + exit only
-#endif
+    const probe::Stamp t_kernel = probe::stamp<probe::PAIR_TIME>();
     // SPLIT == 5: waves 0/1 of the workgroup carry spacecraft group 0 (halves 0/1 of the walk), waves 2/3 group 1
     // SPLIT == 2 (pair form, bsk_device.hpp: PairLds): a 128-thread workgroup = the dynamics wave and the FSW + environment
     // wave of the SAME 64 spacecraft
@@ -90,7 +83,8 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
                        ldf(FLD(TAIL + BSK_T_LEXT + 2), bo));
     double charge = ldf(FLD(TAIL + BSK_T_CHARGE), bo);
     const int2 cnt = *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(a.cnt) + bo);  // {steps | phase << 20, ticks}
-    const int action = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(a.act) + (bo >> 1));
+    // (int32 actions, or the low words of int64 ones - torch's argmax output - read in place: a.act_shift)
+    const int action = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(a.act) + (bo >> a.act_shift));
     // |sigma_BR| of the att_guidance message the last FSW tick wrote (obs[0] with bsk_config.nav_lag)
     double sbr = ldf(FLD(TAIL + BSK_T_SBR), bo);
     double u[NRW > 0 ? NRW : 1], up[NRW > 0 ? NRW : 1];
@@ -101,11 +95,12 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
 #pragma unroll
     for (int k = 0; k < NRW; ++k) u[k] = ldf(FLD(TAIL + BSK_T_UCMD + k), bo);
 #undef FLD
-#ifndef BSK_NO_EARLY_SCALARS
+    // device-resident episode statistics (BSK_FLAG_EPISODE_STATS): the running return travels with the state's loads
+    double ep_ret = 0.0;
+    if (BSK_UNLIKELY(a.ep_return != nullptr)) ep_ret = ldf(a.ep_return, bo);
     // The loop's first scalar constants, fetched while the state's loads are in flight: left to the compiler their
     // scalar loads sit behind the wait for the state - one more round trip on a K = 1 launch's critical path.
-    asm volatile("" ::"s"(c.fsw_every), "s"(c.h), "s"(c.h2), "s"(c.h3), "s"(c.h6), "s"(c.nmu), "s"(c.j2k), "s"(c.I[0]), "s"(c.I[1]));
-#endif
+    asm volatile("" ::"s"(c.fsw_every), "s"(c.h), "s"(c.h2), "s"(c.h3), "s"(c.h6), "s"(c.nmu), "s"(c.j2k), "s"(c.Dm[0]), "s"(c.Dm[1]));
 
     // desaturation state (full scenario with BSK_FLAG_DESAT)
     constexpr bool FULL = is_full<FEAT>();
@@ -123,19 +118,13 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
     const int substeps = a.substeps;
     // wheel geometry: parked in VGPRs, except at the full-scenario levels where it comes through the DPP broadcast
     // table (bsk_device.hpp: KTab)
-#ifndef BSK_BARE_DPP
-#define BSK_BARE_DPP 0
-#endif
     // (the LDS-scratch level is after a third wave per SIMD: it takes the 36 registers of the wheel geometry too)
-    constexpr bool WDPP = FULL || (FEAT == FEAT_LDSS && NRW > 0) || (BSK_BARE_DPP && FEAT == FEAT_BARE && NRW > 0);
-    std::conditional_t<WDPP, WheelDpp<NRW, (FULL && BSK_FOLD_JS != 0)>, WheelV<NRW>> wv;
-#if defined(BSK_ABLATE) && BSK_ABLATE == 2
-    const int substeps_eff = 0;   // loads + epilogue stores, no RK4 / FSW
-#else
+    constexpr bool WDPP = FULL || (FEAT == FEAT_LDSS && NRW > 0);
+    std::conditional_t<WDPP, WheelDpp<NRW, FULL>, WheelV<NRW>> wv;
     const int substeps_eff = substeps;
-#endif
     int j = 0;
     int tick = cnt.y;
+    bool tri_failed = false;
     double shadow = 1.0;
     SunGeom sg;
     constexpr bool POWER = FEAT >= FEAT_POWER;
@@ -156,7 +145,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
     if constexpr (FULL) {
         // lane l of every 16-lane row fetches entry l & 15 of the three table rows (three coalesced loads)
         const int l16 = lane & 15;
-        kt.a = cold->kt[l16]; kt.b = cold->kt[16 + l16]; kt.c = cold->kt[32 + l16];
+        kt.a = cold->kt[l16]; kt.b = cold->kt[16 + l16]; kt.c = cold->kt[32 + l16]; kt.e = cold->kt[64 + l16];
         wv.ta = kt.a; wv.tb = kt.b; wv.td = cold->kt[48 + l16];
     } else if constexpr (WDPP) {
         const int l16 = lane & 15;
@@ -195,9 +184,13 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
             thr_cnt = (int)ldf(st + (int64_t)(TAIL + BSK_T_THR_CNT) * S, bo);
         }
     }
+    // what the previous tick's EnvTask knows about this tick's initial state (bsk_device.hpp: Pre): here of the loaded state
+    Pre pre{0.0, 0.0, MrpRot{0.0, 0.0}};
+    if constexpr (FULL && !PAIR) { pre.r2 = dot(x.r, x.r); pre.rot = mrp_rot(x.s); }
     bool first_fsw = true;
     bool drag_cfg = false;
     if constexpr (FULL) drag_cfg = a.extra.base_density != 0.0;
+    const int drag_cfg_u = uni(drag_cfg);
     // ---- FSW task timing (bsk_config.nav_lag) -------------------------------------------------------------------
     // The reference creates its FSW tasks with priorities 100 / 50 and its dynamics tasks with the default
     // (...Simulator.py:383-386, :101-103); Basilisk runs higher priorities first at equal time.  So the FSW tick of
@@ -209,9 +202,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
     // to that launch (ExecuteSimulation runs the tasks scheduled at its stop time).  nav_lag = 0: the chain runs at
     // phase 0 on the state of its own time, latched at once.
     bool navlag = false;
-#ifndef BSK_NO_NAVLAG
     if constexpr (NRW > 0) navlag = a.nav_lag != 0;
-#endif
     // The FSW output messages: the newest wheel torque command and thruster burst.  The effectors' copies (u, ev.thr_*,
     // thr_t0) are refreshed from them by plain moves (`latch`) - idempotent, so no "new message" flags are carried.
     double un[NRW > 0 ? NRW : 1];
@@ -277,9 +268,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
     // of the loop (wave-uniform: the other lanes of the wave wait), so that the FSW chain is instantiated once.
     bool z0 = false;
     if constexpr (NRW > 0) z0 = navlag && tick == 0 && substeps_eff > 0;
-#ifdef BSK_PAIR_DEBUG_WAIT
-    unsigned long long dbg_waitA_out = 0, dbg_waitB_out = 0;
-#endif
+    unsigned long long dbg_waitA = 0, dbg_waitB = 0, dbg_chain = 0;      // (probe builds only: bsk_probes.hpp)
     if constexpr (PAIR) {
         static_assert(!PAIR || (FEAT >= FEAT_POWER && FEAT != FEAT_FULLG && GRAV != BSK_GRAV_SH), "pair form: power / full-scenario levels, point mass or J2");
         static_assert(!TRI || FEAT == FEAT_FULL, "three-wave form: the full-scenario level");
@@ -309,9 +298,6 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
         // partially eclipsed ones, battery updates in tick order (the arithmetic of power_tick / power_flush)
         auto env_ticks = [&](int mm, int bb) {
             if (mm == 0) return;
-#if defined(BSK_PAIR_ABLATE) && (BSK_PAIR_ABLATE == 2 || BSK_PAIR_ABLATE == 23)   // timing only: no EnvTask at all (23: nor the FSW chain)
-            return;
-#endif
             double gk[PAIR_CHUNK], sk[PAIR_CHUNK];
             unsigned bandmask = 0u;
             auto eval = [&](int k) __attribute__((always_inline)) {
@@ -331,9 +317,6 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
                     if (k < mm) eval(k);
                 }
             }
-#if defined(BSK_PAIR_ABLATE) && BSK_PAIR_ABLATE == 1   // timing only: no drain
-            bandmask = 0u;
-#endif
             if (BSK_UNLIKELY(__builtin_amdgcn_ballot_w64(bandmask != 0u) != 0)) {
 #pragma unroll
                 for (int k = 0; k < PAIR_CHUNK; ++k) {
@@ -411,20 +394,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
             return q;
         };
         int cb = 0;                                        // ring buffer of this chunk
-#ifdef BSK_PAIR_DEBUG_WAIT
-        unsigned long long dbg_waitA = 0, dbg_waitB = 0, dbg_chain = 0;
-#endif
-#if defined(BSK_PAIR_ABLATE) && BSK_PAIR_ABLATE >= 4       // timing only: 4 = no barriers, the environment wave leaves at once;
-#define BSK_PAIR_SYNC() ((void)0)                           //              5 = no barriers, it idles (s_sleep) until the end
-        if (!isD) {
-#if BSK_PAIR_ABLATE == 5
-            for (int w = 0; w < substeps_eff * 8; ++w) __builtin_amdgcn_s_sleep(100);
-#endif
-            return;
-        }
-#else
 #define BSK_PAIR_SYNC() __syncthreads()
-#endif
         BSK_PAIR_SYNC();                                   // the environment wave's Sun positions are in LDS
         if constexpr (TRI) {
           if (isD) {
@@ -434,17 +404,12 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
                 constexpr int PART = decltype(ROLE)::value;
                 constexpr bool ROT = PART == PART_ROT;
                 TriXch<PART> xc{TX, lane, 0, 0, false};
-#if defined(BSK_TRI_ABLATE)                                // timing only: neither wave waits for the other (stale values)
-                xc.dead = true;
-                const unsigned long long abl_t0 = __builtin_readcyclecounter();
-#endif
                 // exponentialAtmosphere at a position (the arithmetic of the single-wave tick loop), 0 below the skip density
                 auto density = [&](V3 r) __attribute__((always_inline)) {
                     double rho = 0.0;
                     if (drag_cfg) {
-                        const double r2 = dot(r, r), rm = r2 * rsqrt_nr(r2);
-                        const double rh = mul_k<KC_RHO0>(kt.c, exp_fast(fmac_k<KC_NIH>(get_k<KC_REQIH>(kt.c), kt.c, rm)));
-                        rho = rh >= get_k<KC_RSKIP>(kt.c) ? rh : 0.0;
+                        const double r2 = dot(r, r);
+                        rho = atmosphere_density(kt, r2 * rsqrt_nr(r2));
                     }
                     return rho;
                 };
@@ -484,7 +449,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
                                 const double fs = fmin(fmax(x.Om[i] * 0x1p1000, -c.fc), c.fc);
                                 tq[i] = u[i] - fs;
                             }
-                            if constexpr (NRW > 0) wv.head(tq, x.Om, Tw, pw, tqj);
+                            if constexpr (NRW > 0) { pw = mv3<DIAG>(c.W, x.w); wv.head(tq, x.Om, Tw, pw, tqj); }
                             double rho = 0.0;
                             v1 = xc.template finish<true>(f, rho);
                             ev.rho = rho;
@@ -524,14 +489,10 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
                     PL->box[10][lane] = x.r.x; PL->box[11][lane] = x.r.y; PL->box[12][lane] = x.r.z;
                     PL->box[13][lane] = x.v.x; PL->box[14][lane] = x.v.y; PL->box[15][lane] = x.v.z;
                 }
-#if defined(BSK_TRI_DEBUG) && defined(BSK_TRI_ABLATE)
-                { const unsigned long long w = (((__builtin_readcyclecounter() - abl_t0) >> 6) & 0xFFFFFFFFull) << 32;   // the free-running loop's cycles / 64
-                  if (lane == 0) ((volatile unsigned long long __attribute__((address_space(3)))*)&TX->pad_[0])[ROT ? 0 : 1] = w; }
-#elif defined(BSK_TRI_DEBUG)
-                // probe: misses (16 bits) | re-reads (16) | cycles / 64 spent re-reading (32), per wave
-                { const unsigned long long w = (unsigned long long)(xc.dbg_miss & 0xFFFFu) | ((unsigned long long)(xc.dbg_spin & 0xFFFFu) << 16) | (((xc.dbg_cyc >> 6) & 0xFFFFFFFFull) << 32);
-                  if (lane == 0) ((volatile unsigned long long __attribute__((address_space(3)))*)&TX->pad_[0])[ROT ? 0 : 1] = w; }
-#endif
+                if constexpr (probe::TRI_XCHG != 0) {      // exchange probe: misses (16 bits) | re-reads (16) | cycles / 64 spent re-reading (32), per wave
+                    const unsigned long long w = (unsigned long long)(xc.dbg_miss & 0xFFFFu) | ((unsigned long long)(xc.dbg_spin & 0xFFFFu) << 16) | (((xc.dbg_cyc >> 6) & 0xFFFFFFFFull) << 32);
+                    if (lane == 0) ((volatile unsigned long long __attribute__((address_space(3)))*)&TX->pad_[0])[ROT ? 0 : 1] = w;
+                }
                 BSK_PAIR_SYNC();                           // the last chunk's ring is complete
                 BSK_PAIR_SYNC();                           // ... and the environment wave has answered
             };
@@ -544,7 +505,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
             for (int k = 0; k < NRW; ++k) up[k] = PL->box[3 + k][lane];
             thr_cnt = (int)PL->box[7][lane];
             fsw_ran = PL->box[8][lane] != 0.0;
-            if (TX->err != 0) { sbr = __builtin_nan(""); charge = sbr; }   // an exchange timed out (cannot happen): fail loudly
+            tri_failed = TX->err != 0;     // an exchange timed out (cannot happen): reported through the handle's error word below
           }
         }
         if (isD && !TRI) {
@@ -560,13 +521,9 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
 #pragma unroll
                     for (int k = 0; k < NRW; ++k) PL->box[12 + k][lane] = x.Om[k];
                 }
-#ifdef BSK_PAIR_DEBUG_WAIT
-                const unsigned long long wa0 = __builtin_readcyclecounter();
-#endif
+                const probe::Stamp wa0 = probe::stamp<probe::PAIR_WAIT>();
                 BSK_PAIR_SYNC();                           // A: messages written; the previous chunk's ring complete
-#ifdef BSK_PAIR_DEBUG_WAIT
-                dbg_waitA += __builtin_readcyclecounter() - wa0;
-#endif
+                probe::since<probe::PAIR_WAIT>(dbg_waitA, wa0);
                 if (q.needB0) {
                     BSK_PAIR_SYNC();                       // B (same-tick chain): wait for the commands
                     read_cmd();
@@ -578,9 +535,8 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
                     const V3 lx = mk(PL->lext[0][lane], PL->lext[1][lane], PL->lext[2][lane]);   // (parked in LDS)
                     if constexpr (FULL) {
                         if (drag_cfg) {
-                            const double r2 = dot(x.r, x.r), rm = r2 * rsqrt_nr(r2);
-                            const double rho = mul_k<KC_RHO0>(kt.c, exp_fast(fmac_k<KC_NIH>(get_k<KC_REQIH>(kt.c), kt.c, rm)));
-                            ev.rho = rho >= get_k<KC_RSKIP>(kt.c) ? rho : 0.0;
+                            const double r2 = dot(x.r, x.r);
+                            ev.rho = atmosphere_density(kt, r2 * rsqrt_nr(r2));
                             ev.drag_on = __builtin_amdgcn_ballot_w64(ev.rho != 0.0) != 0;
                         }
                         if (desat) {
@@ -598,13 +554,9 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
                     PL->rr[cb][0][t][lane] = x.r.x; PL->rr[cb][1][t][lane] = x.r.y; PL->rr[cb][2][t][lane] = x.r.z;
                     PL->rs[cb][0][t][lane] = x.s.x; PL->rs[cb][1][t][lane] = x.s.y; PL->rs[cb][2][t][lane] = x.s.z;
                     if (t == 0 && q.needB) {               // B: the commands of this chunk's FSW tick are there
-#ifdef BSK_PAIR_DEBUG_WAIT
-                        const unsigned long long w0 = __builtin_readcyclecounter();
-#endif
+                        const probe::Stamp w0 = probe::stamp<probe::PAIR_WAIT>();
                         BSK_PAIR_SYNC();
-#ifdef BSK_PAIR_DEBUG_WAIT
-                        dbg_waitB += __builtin_readcyclecounter() - w0;
-#endif
+                        probe::since<probe::PAIR_WAIT>(dbg_waitB, w0);
                         read_cmd();
                     }
                 }
@@ -621,24 +573,16 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
             for (int k = 0; k < NRW; ++k) up[k] = PL->box[3 + k][lane];
             thr_cnt = (int)PL->box[7][lane];
             fsw_ran = PL->box[8][lane] != 0.0;
-#ifdef BSK_PAIR_DEBUG_WAIT
-            dbg_waitA_out = dbg_waitA; dbg_waitB_out = dbg_waitB;
-#endif
         } else if (!isD) {
             // ---------------------------------------------------------------- FSW + environment wave
             // It has a fifth of the other wave's instructions and sits on its critical path (commands at every FSW tick, a ring
             // buffer per chunk): where it shares a SIMD with a dynamics wave it must not queue behind it.
-#ifndef BSK_PAIR_PRIO
-#define BSK_PAIR_PRIO 3
-#endif
-            __builtin_amdgcn_s_setprio(BSK_PAIR_PRIO);
+            __builtin_amdgcn_s_setprio(3);
             int pm = 0, pb = 0;                            // length / buffer of the chunk whose EnvTask ticks are still owed
             while (j < substeps_eff) {
                 const Chunk q = next_chunk();
                 BSK_PAIR_SYNC();                           // A
-#ifdef BSK_PAIR_DEBUG_WAIT
-                const unsigned long long c0 = __builtin_readcyclecounter();
-#endif
+                const probe::Stamp c0 = probe::stamp<probe::PAIR_WAIT>();
                 if (q.fsw_any) {
                     State<NRW> nav;
                     nav.r = mk(PL->box[0][lane], PL->box[1][lane], PL->box[2][lane]);
@@ -654,11 +598,9 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
                             for (int k = 0; k < NRW; ++k) nav.Om[k] = 0.0;
                         }
                     }
-#if !(defined(BSK_PAIR_ABLATE) && (BSK_PAIR_ABLATE == 3 || BSK_PAIR_ABLATE == 23))   // 3: timing only, no FSW chain
                     if constexpr (NRW > 0) {
                         if (q.cond) fsw_tick(nav, q.t_latch);
                     }
-#endif
 #pragma unroll
                     for (int k = 0; k < NRW; ++k) PL->box[k][lane] = un[k];
                     if constexpr (FULL) {
@@ -667,9 +609,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
                         PL->box[8][lane] = (double)thr_maxn;
                         PL->box[9][lane] = (double)thr_t0n;
                     }
-#ifdef BSK_PAIR_DEBUG_WAIT
-                    dbg_chain += __builtin_readcyclecounter() - c0;
-#endif
+                    probe::since<probe::PAIR_WAIT>(dbg_chain, c0);
                     BSK_PAIR_SYNC();                       // B (either timing): the commands are there
                 }
                 tick += q.m;
@@ -684,13 +624,8 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
             for (int k = 0; k < NRW; ++k) PL->box[3 + k][lane] = up[k];
             PL->box[7][lane] = (double)thr_cnt;
             PL->box[8][lane] = fsw_ran ? 1.0 : 0.0;
-#ifdef BSK_PAIR_DEBUG_WAIT
-            PL->box[10][lane] = (double)(dbg_chain >> 4);
-#endif
-#ifdef BSK_PAIR_DEBUG_HWID
-            { unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-              PL->box[9][lane] = (double)((hw & 0xFFFFu) | ((xcc & 0xFu) << 16)); }
-#endif
+            if constexpr (probe::PAIR_WAIT) PL->box[10][lane] = (double)(dbg_chain >> 4);
+            if constexpr (probe::PAIR_HWID) PL->box[9][lane] = (double)probe::hw_id();
             BSK_PAIR_SYNC();
             return;                                        // the dynamics wave writes the launch's results
         }
@@ -698,11 +633,11 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
     int np = 0;   // power system: ticks recorded since the last flush (per lane)
     while (j < substeps_eff) {
         int m = substeps_eff - j;
+        bool fsw_here = false;                         // this lane's FSW chain ran at the head of this chunk
         if constexpr (NRW > 0) {
             const int trig = navlag ? fsw_every - 1 : 0;
             int dist = trig - phase;                   // ticks to the next FSW tick of this lane
             if (dist <= 0) dist += fsw_every;
-#if !(defined(BSK_ABLATE) && (BSK_ABLATE == 3 || BSK_ABLATE == 6))   // 3: timing only, no FSW chain; 6: dynamics path only
             const bool anyz = navlag && __builtin_amdgcn_ballot_w64(z0) != 0;
             if (z0 || (!anyz && phase == trig)) {
                 State<NRW> nav = x;
@@ -714,12 +649,12 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
                     }
                 }
                 fsw_tick(nav, tick + ((navlag && !z0) ? 1 : 0));
+                fsw_here = true;
                 if (!navlag) latch();
                 else dist = fsw_every;                 // latched inside the chunk, after its first RK4 step
             }
             if (anyz) dist = 0;                        // t = 0 tick: latched below without a step in between
             z0 = false;
-#endif
             m = min(m, dist);
             if constexpr (POWER) m = min(m, PEN_CHUNK);
             // The DPP-broadcast harmonics need every lane active inside the RK4 loop, so the trip count is
@@ -728,9 +663,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
             // (the full-scenario levels take their wave-uniform constants through DPP broadcasts: same requirement;
             // and every level with the power system: the penumbra queue is drained cooperatively - entry e by lane
             // e mod 64, whoever owns it - so a flush must find all 64 lanes in the same loop iteration)
-#if !(defined(BSK_ABLATE) && BSK_ABLATE == 5)   // 5: timing only, per-lane trip count
             if constexpr (GRAV == BSK_GRAV_SH || WDPP || POWER) m = wave_min_uniform(m);
-#endif
             phase += m;
             if (phase >= fsw_every) phase -= fsw_every;
         }
@@ -738,7 +671,6 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
             m = min(m, PEN_CHUNK);
             if constexpr (FULL) m = wave_min_uniform(m);
         }
-#if !(defined(BSK_ABLATE) && (BSK_ABLATE == 4 || BSK_ABLATE == 6))   // 4: timing only, no drain / battery replay
         if constexpr (POWER) {
             // the tick record is flushed (queue drained cooperatively, battery replayed) when some lane's would overflow
             if (__builtin_amdgcn_ballot_w64(np + m > PEN_SLOTS) != 0) {
@@ -746,82 +678,133 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
                 np = 0;
             }
         }
-#endif
         j += m;
         if constexpr (FULL) {
             if (ev.sun_on) third_body_anchor(ev.s3, sg.sun, a.extra.mu_sun, x.r);   // exact at the chunk's first position
         }
-        auto one_tick = [&](int t) __attribute__((always_inline)) {
+        // ---- the chunk's ticks.  A tick = head (what decides which instantiation of the step runs: the atmosphere's density,
+        // the burst test) + body (RK4 step, EnvTask).  Three instantiations at the full-scenario levels: with drag (nearly
+        // always in LEO below ~460 km), without, inside a thruster burst (rare).
+        // The run's control flags live in SCALAR registers as integers (uni()): as `bool`s the compiler keeps wave-uniform
+        // conditions as lane masks and tests them with a v_cndmask + v_cmp + s_andn2 triple per branch.
+        int burst_any = 0;           // some thruster of some lane inside a burst (wave-uniform, settled per chunk: below)
+        int drag_now = 0, thr_now = 0;   // this tick: some lane inside the atmosphere / inside a burst
+        int t = 0;
+        auto tick_head = [&]() __attribute__((always_inline)) {
             if constexpr (FULL) {
-                if (drag_cfg) {   // exponentialAtmosphere, refreshed once per dyn tick
-                    const double r2 = dot(x.r, x.r), rm = r2 * rsqrt_nr(r2);
-                    // rho0 exp(-(|r| - Re)/H) with the exponent as one FMA on table constants: Re/H - |r|/H
-#ifndef BSK_EXP_FAST
-#define BSK_EXP_FAST 1
-#endif
-#if BSK_EXP_FAST
-                    const double rho = mul_k<KC_RHO0>(kt.c, exp_fast(fmac_k<KC_NIH>(get_k<KC_REQIH>(kt.c), kt.c, rm)));
-#else
-                    const double rho = mul_k<KC_RHO0>(kt.c, exp(fmac_k<KC_NIH>(get_k<KC_REQIH>(kt.c), kt.c, rm)));
-#endif
-                    // below the skip density |a_drag| < 1e-19 m/s^2: dropped.  (The threshold comes from the broadcast
-                    // table: as a kernel argument it was re-read by a scalar load, and waited for, on every tick.)
-                    ev.rho = rho >= get_k<KC_RSKIP>(kt.c) ? rho : 0.0;
-                    ev.drag_on = __builtin_amdgcn_ballot_w64(ev.rho != 0.0) != 0;   // any lane of the wave inside the atmosphere
+                pre.ir = rsqrt_nr(pre.r2);                   // 1 / |r|: the atmosphere below, the first stage's gravity
+                if (drag_cfg_u) {   // exponentialAtmosphere, refreshed once per dyn tick
+                    ev.rho = atmosphere_density(kt, pre.r2 * pre.ir);
+                    drag_now = uni(__builtin_amdgcn_ballot_w64(ev.rho != 0.0) != 0);   // any lane of the wave inside the atmosphere
                 }
-                if (desat) {
-                    ev.e2 = 2 * (tick - thr_t0);
-                    // some thruster of some lane still inside its burst
-                    ev.thr_on = __builtin_amdgcn_ballot_w64(ev.thr_max > 0 && ev.e2 <= ev.thr_max) != 0;
-                    if (BSK_UNLIKELY(ev.thr_on)) thr_masks(ev);
-                }
+                // some thruster of some lane still inside its burst
+                if (BSK_UNLIKELY(burst_any)) thr_now = uni(__builtin_amdgcn_ballot_w64(ev.thr_max > 0 && 2 * (tick - thr_t0) <= ev.thr_max) != 0);
             }
-            if constexpr (FULL) {
-#ifndef BSK_DRAG_TEMPLATE
-#define BSK_DRAG_TEMPLATE 1
-#endif
-#if BSK_DRAG_TEMPLATE
-                // the drag switch picks the instantiation too: each integrator stage is then one branch-free region
-                if (BSK_LIKELY(!ev.thr_on)) {
-                    if (BSK_LIKELY(ev.drag_on)) rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT, false, 1>(c, wv, x, u, lext, (double)tick * c.h, ev, accp);
-                    else rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT, false, 2>(c, wv, x, u, lext, (double)tick * c.h, ev, accp);
-                } else rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT, true, 0>(c, wv, x, u, lext, (double)tick * c.h, ev, accp);
-#else
-                if (BSK_LIKELY(!ev.thr_on)) rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT, false>(c, wv, x, u, lext, (double)tick * c.h, ev, accp);
-                else rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT, true>(c, wv, x, u, lext, (double)tick * c.h, ev, accp);
-#endif
-            } else {
-                rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT, false>(c, wv, x, u, lext, (double)tick * c.h, ev, accp);
-            }
-#if defined(BSK_ABLATE) && BSK_ABLATE == 6
-            if constexpr (POWER) {   // what the dynamics wave of a two-wave design would do instead: hand (r, sigma) over
-                L->s[t][lane] = x.r.x; L->s[(t + 1) % PEN_SLOTS][lane] = x.r.y; L->s[(t + 2) % PEN_SLOTS][lane] = x.r.z;
-                L->sun[0][lane] = x.s.x; L->sun[1][lane] = x.s.y; L->sun[2][lane] = x.s.z;
-            }
-#else
-            if constexpr (POWER) power_tick<FULL>(a.power, sg, x.r, x.s, L, np + t, lane, kt.c);
-#endif
-            // after a chunk's first step the new commands act; plain moves, no-ops on every later step (measured
-            // against a conditional latch and against splitting the chunk: profiles/r02/fsw_timing_cost.txt)
-            if constexpr (NRW > 0) latch();
         };
-        if constexpr (FEAT == 0 && GRAV != BSK_GRAV_SH) {
-            // two ticks per trip at the bare level: the RK4 step's register rotation (16 moves per step) disappears
-            // between the copies, -2 % at K = 1800; the levels above it lose as much to their larger bodies (and a
-            // `#pragma unroll 1` there is not neutral either: it moved SGPR spill reloads into the power level's loop)
-#pragma unroll 2
-            for (int t = 0; t < m; ++t, ++tick) one_tick(t);
+        auto tick_body = [&](auto THR_, auto DM_) __attribute__((always_inline)) {
+            constexpr bool THR = decltype(THR_)::value;
+            constexpr int DM = decltype(DM_)::value;
+            double q2 = 0.0;         // |sigma|^2 after the step (full-scenario levels: the EnvTask's rotation starts from it)
+            if constexpr (FULL && THR) {      // (only here: the burst's masks and rows must not be carried around the other runs' loops)
+                ev.e2 = 2 * (tick - thr_t0);
+                ev.drag_on = drag_now != 0;       // (this instantiation tests the drag switch per stage)
+                thr_masks(ev);
+            }
+            if constexpr (FULL) rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT, THR, DM>(c, wv, x, u, lext, (double)tick * c.h, ev, accp, &pre, &q2);
+            else rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT, false>(c, wv, x, u, lext, (double)tick * c.h, ev, accp);
+            if constexpr (POWER) power_tick<FULL>(a.power, sg, x.r, x.s, L, np + t, lane, kt.c, FULL ? &pre : nullptr, FULL ? &q2 : nullptr);
+            ++t;
+            ++tick;
+        };
+        using B0 = std::integral_constant<bool, false>;
+        using B1 = std::integral_constant<bool, true>;
+        using I0_ = std::integral_constant<int, 0>;
+        using I1_ = std::integral_constant<int, 1>;
+        using I2_ = std::integral_constant<int, 2>;
+        // Is some thruster of some lane inside a burst?  Bursts begin only where the dynamics task latches an on-time message
+        // (latch(), after a chunk's first step) and last one control period at most, so the question is settled per chunk -
+        // here for its first step, again after the latch - and the ticks of a wave without a burst (nearly all) skip the
+        // per-tick test (eleven instructions) altogether.
+        auto burst_pending = [&]() __attribute__((always_inline)) {
+            int any = 0;
+            if constexpr (FULL) {
+                if (desat) any = uni(__builtin_amdgcn_ballot_w64(ev.thr_max > 0 && 2 * (tick - thr_t0) <= ev.thr_max) != 0);
+                if (!any) thr_now = 0;
+            }
+            return any;
+        };
+        burst_any = burst_pending();
+        // The chunk's first tick runs alone when an FSW tick opened the chunk under the reference's task priorities: after it
+        // the dynamics task's effectors latch the new commands (idempotent moves, a no-op for lanes without a new message).
+        // No other tick latches anything.
+        if constexpr (NRW > 0) {
+            bool lat = navlag && fsw_here;
+            if constexpr (GRAV == BSK_GRAV_SH || WDPP || POWER) lat = __builtin_amdgcn_ballot_w64(lat) != 0;   // wave-uniform trip counts
+            if (lat && m > 0) {
+                tick_head();
+                if constexpr (FULL) {
+                    if (BSK_LIKELY(!thr_now)) {
+                        if (BSK_LIKELY(drag_now)) tick_body(B0{}, I1_{});
+                        else tick_body(B0{}, I2_{});
+                    } else tick_body(B1{}, I0_{});
+                } else tick_body(B0{}, I0_{});
+                latch();
+                burst_any = burst_pending();
+            }
+        }
+        // The rest of the chunk as RUNS of ticks of one instantiation, two ticks per trip of the run's loop.  A loop whose body
+        // is one tick cannot produce the step's results in the registers its header expects (the old state is read until the
+        // last stage: ~30 register moves per tick); a loop that picks the instantiation per tick merges three alternative
+        // results after every step (nine more).  A run's loop contains one instantiation only, its second copy ping-pongs
+        // between two register sets, and it ends when the next tick's head asks for another kind (or the chunk is through).
+        auto run = [&](auto THR_, auto DM_) __attribute__((always_inline)) {      // -> the next tick's head has been evaluated
+            constexpr bool THR = decltype(THR_)::value;
+            constexpr int DM = decltype(DM_)::value;
+            auto same = [&]() __attribute__((always_inline)) {
+                if constexpr (!FULL) return true;
+                else if constexpr (THR) return false;                              // bursts: one tick at a time
+                else return !thr_now && drag_now == (DM == 1 ? 1 : 0);
+            };
+#pragma nounroll
+            for (;;) {
+                tick_body(THR_, DM_);
+                if (t >= m) return false;
+                tick_head();
+                if (BSK_UNLIKELY(!same())) return true;
+                tick_body(THR_, DM_);
+                if (t >= m) return false;
+                tick_head();
+                if (BSK_UNLIKELY(!same())) return true;
+            }
+        };
+        if constexpr (POWER) {
+            bool headed = false;
+#pragma nounroll
+            while (t < m) {
+                if (!headed) tick_head();
+                if constexpr (FULL) {
+                    if (BSK_LIKELY(!thr_now)) {
+                        if (BSK_LIKELY(drag_now)) headed = run(B0{}, I1_{});
+                        else headed = run(B0{}, I2_{});
+                    } else headed = run(B1{}, I0_{});
+                } else headed = run(B0{}, I0_{});
+            }
         } else {
-            for (int t = 0; t < m; ++t, ++tick) one_tick(t);
+            // the bare levels have one instantiation and no head: pairs, then the odd tick (measured: the run machinery costs
+            // them 5 VALU instructions per tick, 1 - 2 %)
+#pragma nounroll
+            while (t + 1 < m) {
+                tick_body(B0{}, I0_{});
+                tick_body(B0{}, I0_{});
+            }
+            if (t < m) tick_body(B0{}, I0_{});
         }
         np += m;
-        if constexpr (NRW > 0) latch();        // the t = 0 chunk has no step
+        if constexpr (NRW > 0) latch();        // (the t = 0 chunk has no step: its commands are latched here)
     }
-#if !(defined(BSK_ABLATE) && (BSK_ABLATE == 4 || BSK_ABLATE == 6))
     if constexpr (POWER) {
         if (__builtin_amdgcn_ballot_w64(np > 0) != 0) power_flush(a.power, L, np, lane, c.h, charge, shadow);
     }
-#endif
     }   // !PAIR
 
     // Re-read the post-loop arguments from the kernarg segment through an opaque pointer: the
@@ -837,6 +820,14 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
     const int64_t S2 = uniform64(ta.stride);
     const int n2 = ta.n;
     const bool valid2 = gid < n2;
+    if constexpr (TRI) {
+        // the three-wave exchange gave up on a value: the launch's results are not to be trusted.  NaN observations AND
+        // the handle's error word, which every synchronising entry point checks (bsk_get_obs / bsk_sync -> BSK_EHIP)
+        if (BSK_UNLIKELY(tri_failed)) {
+            sbr = __builtin_nan(""); charge = sbr;
+            if (lane == 0) __hip_atomic_store(ta.err, BSK_DEVERR_TRI_EXCHANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 
     // observation: [|sigma_BR|, |omega_BN|, |Omega|/limit, charge/3600/power_max, shadow]
     // obs[0] is the logged att_guidance message: with nav_lag the one the last FSW tick wrote (held in `sbr`),
@@ -869,34 +860,19 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
     // wavefront reductions (every lane of the wave participates; tail lanes contribute nothing)
     const unsigned long long dmask = __ballot(valid2 && why != 0);
     const double rsum = wave_sum(valid2 ? rew : 0.0);
-#ifdef BSK_TRI_DEBUG
-    if constexpr (TRI) {    // exchange probe instead of the done mask: the rotational wave's word (BSK_TRI_DEBUG=1) or the translational wave's (=2)
-        volatile unsigned long long __attribute__((address_space(3)))* w = (volatile unsigned long long __attribute__((address_space(3)))*)&((TriP)lds_dyn)->x.pad_[0];
-        if ((threadIdx.x & 63) == 0) { ta.done_mask[gid >> 6] = w[BSK_TRI_DEBUG == 2 ? 1 : 0]; ta.wave_reward[gid >> 6] = rsum; }
-    } else
-#endif
-#ifdef BSK_PAIR_DEBUG_WAIT
-    if constexpr (PAIR) {   // wait probe: cycles/16 the dynamics wave waited at B (bits 0-20), at A (21-41), the other wave's chain time (42-62)
-        const unsigned long long ch = (unsigned long long)((PairP)lds_dyn)->box[10][0];
-        if ((threadIdx.x & 63) == 0) { ta.done_mask[gid >> 6] = ((dbg_waitB_out >> 4) & 0x1FFFFFull) | (((dbg_waitA_out >> 4) & 0x1FFFFFull) << 21) | ((ch & 0x1FFFFFull) << 42); ta.wave_reward[gid >> 6] = rsum; }
-    } else
-#endif
-#ifdef BSK_PAIR_DEBUG_TIME
-    if constexpr (PAIR) {   // residency probe: (this wave's start clock >> 10) | (end clock >> 10) << 32 instead of the done mask
-        const unsigned long long t1 = __builtin_readcyclecounter();
-        unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        const unsigned long long id = (hw & 0xFFFFu) | ((xcc & 0xFu) << 16);
-        if ((threadIdx.x & 63) == 0) { ta.done_mask[gid >> 6] = (((t1 - dbg_t0) >> 10) & 0xFFFFFFFFull) | (id << 32); ta.wave_reward[gid >> 6] = rsum; }
-    } else
-#endif
-#ifdef BSK_PAIR_DEBUG_HWID
-    if constexpr (PAIR) {   // placement probe: (dynamics wave's hardware id) | (environment wave's) << 32 instead of the done mask
-        unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        const unsigned long long mine = (hw & 0xFFFFu) | ((xcc & 0xFu) << 16);
-        const unsigned long long other = (unsigned long long)((PairP)lds_dyn)->box[9][0];
-        if ((threadIdx.x & 63) == 0) { ta.done_mask[gid >> 6] = mine | (other << 32); ta.wave_reward[gid >> 6] = rsum; }
-    } else
-#endif
+    if constexpr (probe::ANY) {
+        // probe builds (bsk_probes.hpp): one 64-bit word per wave in the handle's debug buffer - never in the done mask
+        unsigned long long w = 0ull;
+        if constexpr (TRI && probe::TRI_XCHG != 0)      // the rotational wave's exchange word (1) or the translational wave's (2)
+            w = ((volatile unsigned long long __attribute__((address_space(3)))*)&((TriP)lds_dyn)->x.pad_[0])[probe::TRI_XCHG == 2 ? 1 : 0];
+        if constexpr (PAIR && probe::PAIR_WAIT)         // cycles / 16 the dynamics wave waited at B (bits 0-20), at A (21-41), the other wave's chain time (42-62)
+            w = ((dbg_waitB >> 4) & 0x1FFFFFull) | (((dbg_waitA >> 4) & 0x1FFFFFull) << 21) | (((unsigned long long)((PairP)lds_dyn)->box[10][0] & 0x1FFFFFull) << 42);
+        if constexpr (PAIR && probe::PAIR_TIME)         // residency: this wave's cycles / 1024 | its hardware id << 32
+            w = ((probe::elapsed(t_kernel) >> 10) & 0xFFFFFFFFull) | (probe::hw_id() << 32);
+        if constexpr (PAIR && probe::PAIR_HWID)         // placement: the dynamics wave's hardware id | the environment wave's << 32
+            w = probe::hw_id() | ((unsigned long long)((PairP)lds_dyn)->box[9][0] << 32);
+        if ((threadIdx.x & 63) == 0 && ta.dbg) ta.dbg[gid >> 6] = w;
+    }
     if ((threadIdx.x & 63) == 0) {
         ta.done_mask[gid >> 6] = dmask;
         ta.wave_reward[gid >> 6] = rsum;
@@ -931,11 +907,14 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
             const double v = pool[(int64_t)(BSK_NF_BASE + k) * n_pool + slot];
             pom2 = fma(v, v, pom2);
         }
-        stf(ob + 0 * S2, bo, sqrt_nr(dot(ps, ps)));
-        stf(ob + 1 * S2, bo, sqrt_nr(dot(pw, pw)));
-        stf(ob + 2 * S2, bo, sqrt_nr(pom2) * ta.obs_cfg.inv_wheel_limit);
-        stf(ob + 3 * S2, bo, pool[(int64_t)(TAIL + BSK_T_CHARGE) * n_pool + slot] * ta.obs_cfg.charge_scale);
+        const double n0 = sqrt_nr(dot(ps, ps)), n1 = sqrt_nr(dot(pw, pw)), n2 = sqrt_nr(pom2) * ta.obs_cfg.inv_wheel_limit;
+        const double n3 = pool[(int64_t)(TAIL + BSK_T_CHARGE) * n_pool + slot] * ta.obs_cfg.charge_scale;
+        stf(ob + 0 * S2, bo, n0); stf(ob + 1 * S2, bo, n1); stf(ob + 2 * S2, bo, n2); stf(ob + 3 * S2, bo, n3);
         stf(ob + 4 * S2, bo, 1.0);
+        if (ta.obs_rm) {
+            double* __restrict__ rm = ta.obs_rm + (int64_t)i * 5;
+            rm[0] = n0; rm[1] = n1; rm[2] = n2; rm[3] = n3; rm[4] = 1.0;
+        }
         *(gptr<unsigned long long>)((gptr<char>)uniform_ptr(ta.cnt) + bo) = 0ull;
       }
     } else {
@@ -972,10 +951,26 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
         *(gptr<unsigned long long>)((gptr<char>)uniform_ptr(ta.cnt) + bo) = packed;
         stf(ob + 0 * S2, bo, o0); stf(ob + 1 * S2, bo, o1); stf(ob + 2 * S2, bo, o2); stf(ob + 3 * S2, bo, o3);
         stf(ob + 4 * S2, bo, o4);
+        if (ta.obs_rm) {       // optional row-major copy (N, 5): what a torch policy reshapes without a copy kernel
+            double* __restrict__ rm = ta.obs_rm + (int64_t)i * 5;
+            rm[0] = o0; rm[1] = o1; rm[2] = o2; rm[3] = o3; rm[4] = o4;
+        }
     }
 #undef FLD
     stf(uniform_ptr(ta.reward), bo, rew);
     ta.reason[i] = (unsigned char)why;
+    if (ta.ep_return) {
+        // Monitor-style episode statistics on the device (reference envs/leoPowerAttitudeEnvironment.py:130-135:
+        // 'r' = the episode's rewards including this step's, 'l' = env steps taken BEFORE this one)
+        ep_ret += rew;
+        if (why != 0) {
+            stf(uniform_ptr(ta.term_return), bo, ep_ret);
+            ta.term_len[i] = steps0;
+            if (n_pool > 0) ep_ret = 0.0;          // the device-side reset above started a new episode
+        }
+        stf(uniform_ptr(ta.ep_return), bo, ep_ret);
+        ta.done[i] = why != 0 ? 1 : 0;
+    }
 }
 
 // Deterministic batch scalars from the per-wave partials: one 256-thread workgroup, fixed order.
@@ -1000,7 +995,10 @@ __global__ __launch_bounds__(256) void stats_kernel(const double* __restrict__ w
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { *out_sum = sr[0]; *out_done = sd[0]; }
+    if (threadIdx.x == 0) {
+        if (out_done) { *out_sum = sr[0]; *out_done = sd[0]; }
+        else { out_sum[0] = sr[0]; out_sum[1] = (double)sd[0]; }   // {sum reward, #done} as two doubles: one all-reduce operand
+    }
 }
 
 // Scatter a compact IC block [nf][m] into the state slab at env indices idx[0..m) and zero their
@@ -1073,10 +1071,33 @@ __global__ void sample_pool_kernel(double* __restrict__ pool, int n_pool, int n_
     put(T + BSK_T_CHARGE, (8.0 + 12.0 * u[19]) * 3600.0);
 }
 
+// what a reset leaves in the output buffers of env i: the new episode's first observation (the vec env's convention:
+// |sigma_BN|, |omega|, |Omega| / limit in rad/s, charge / 3600 / power_max, 1), zero reward / reason / done / return
+__device__ __forceinline__ void init_outputs(const ResetOut& ro, const double* __restrict__ st, int64_t stride, int i) {
+    const V3 sg = mk(st[(int64_t)(BSK_F_SIGMA + 0) * stride + i], st[(int64_t)(BSK_F_SIGMA + 1) * stride + i], st[(int64_t)(BSK_F_SIGMA + 2) * stride + i]);
+    const V3 w = mk(st[(int64_t)(BSK_F_OMEGA + 0) * stride + i], st[(int64_t)(BSK_F_OMEGA + 1) * stride + i], st[(int64_t)(BSK_F_OMEGA + 2) * stride + i]);
+    double om2 = 0.0;
+    for (int k = 0; k < ro.n_rw; ++k) {
+        const double v = st[(int64_t)(BSK_NF_BASE + k) * stride + i];
+        om2 = fma(v, v, om2);
+    }
+    const double o[5] = {sqrt_nr(dot(sg, sg)), sqrt_nr(dot(w, w)), sqrt_nr(om2) * ro.inv_wheel_limit,
+                         st[(int64_t)(BSK_NF_BASE + ro.n_rw + BSK_T_CHARGE) * stride + i] * ro.charge_scale, 1.0};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        ro.obs[(int64_t)k * stride + i] = o[k];
+        if (ro.obs_rm) ro.obs_rm[(int64_t)i * 5 + k] = o[k];
+    }
+    ro.reward[i] = 0.0;
+    ro.reason[i] = 0;
+    if (ro.done) ro.done[i] = 0;
+    if (ro.ep_return) ro.ep_return[i] = 0.0;
+}
+
 // (re)start envs from the pool with the slot rule of the step kernel's auto-reset
 __global__ void reset_from_pool_kernel(double* __restrict__ st, int64_t stride, int nf, const double* __restrict__ pool,
                                        int n_pool, const unsigned char* __restrict__ mask, int n, int2* __restrict__ cnt,
-                                       int* __restrict__ episodes, unsigned env_base) {
+                                       int* __restrict__ episodes, unsigned env_base, const ResetOut ro) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || (mask && !mask[i])) return;
     const int ep = episodes[i];
@@ -1084,6 +1105,14 @@ __global__ void reset_from_pool_kernel(double* __restrict__ st, int64_t stride, 
     const unsigned slot = (((unsigned)i + env_base) * 2654435761u + (unsigned)ep * 40503u + 12345u) % (unsigned)n_pool;
     for (int f = 0; f < nf; ++f) st[f * stride + i] = pool[(int64_t)f * n_pool + slot];
     cnt[i] = make_int2(0, 0);
+    init_outputs(ro, st, stride, i);
+}
+
+// after a reset from host initial conditions: all n envs (idx == NULL) or the m listed ones
+__global__ void init_outputs_kernel(const double* __restrict__ st, int64_t stride, const int* __restrict__ idx, int m, const ResetOut ro) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    init_outputs(ro, st, stride, idx ? idx[t] : t);
 }
 
 hipError_t launch_sample_pool(double* pool, int n_pool, int n_rw, unsigned long long seed, double mu, hipStream_t s) {
@@ -1093,9 +1122,15 @@ hipError_t launch_sample_pool(double* pool, int n_pool, int n_rw, unsigned long 
 }
 
 hipError_t launch_reset_from_pool(double* st, int64_t stride, int nf, const double* pool, int n_pool, const unsigned char* mask,
-                                  int n, int2* cnt, int* episodes, unsigned env_base, hipStream_t s) {
+                                  int n, int2* cnt, int* episodes, unsigned env_base, const ResetOut& ro, hipStream_t s) {
     hipLaunchKernelGGL(reset_from_pool_kernel, dim3((n + 255) / 256), dim3(256), 0, s, st, stride, nf, pool, n_pool, mask, n, cnt,
-                       episodes, env_base);
+                       episodes, env_base, ro);
+    return hipGetLastError();
+}
+
+hipError_t launch_init_outputs(const double* st, int64_t stride, const int* idx, int m, const ResetOut& ro, hipStream_t s) {
+    if (m <= 0) return hipSuccess;
+    hipLaunchKernelGGL(init_outputs_kernel, dim3((m + 255) / 256), dim3(256), 0, s, st, stride, idx, m, ro);
     return hipGetLastError();
 }
 
@@ -1104,7 +1139,7 @@ static void fill_hot(const StepParams& p, HotCfg<NRW, DIAG>& h) {
     h.h = p.dt; h.h2 = 0.5 * p.dt; h.h3 = p.dt / 3.0; h.h6 = p.dt / 6.0;
     h.nmu = -p.mu; h.j2k = p.j2k;
     for (int i = 0; i < (DIAG ? 3 : 9); ++i) {
-        h.I[i] = DIAG ? p.inertia[4 * i] : p.inertia[i];
+        h.Dm[i] = DIAG ? p.dmat[4 * i] : p.dmat[i];
         h.Di[i] = DIAG ? p.dinv[4 * i] : p.dinv[i];
         h.W[i] = DIAG ? p.wmat[4 * i] : p.wmat[i];
     }
@@ -1134,7 +1169,7 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     a.cold = b.cold; a.st = b.st; a.cnt = b.cnt; a.act = b.act;
     a.stride = b.stride; a.n = b.n; a.substeps = b.substeps;
     a.nav_lag = p.nav_lag; a.fsw_lag = p.fsw_lag;
-    a.pair_shift = p.pair_shift; a.pad2_ = 0;
+    a.pair_shift = p.pair_shift; a.act_shift = b.act_shift; a.ep_return = b.ep_return;
     a.power = p.pc;
     a.extra = p.ex;
     a.tail.obs_cfg = p.obs; a.tail.st = b.st; a.tail.cnt = b.cnt; a.tail.obs = b.obs; a.tail.reward = b.reward;
@@ -1144,6 +1179,8 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     a.tail.n_pool = b.n_pool; a.tail.n_fields = b.n_fields;
     a.tail.fsw_lag = p.fsw_lag; a.tail.nav_lag = p.nav_lag;
     a.tail.env_base = b.env_base; a.tail.pad_ = 0;
+    a.tail.ep_return = b.ep_return; a.tail.term_return = b.term_return; a.tail.term_len = b.term_len; a.tail.done = b.done;
+    a.tail.obs_rm = b.obs_rm; a.tail.err = b.err; a.tail.dbg = b.dbg;
     if (SPLIT == 5) block = 256;
     if (SPLIT == 2) block = 128;      // pair form: dynamics wave + FSW / environment wave of the same 64 spacecraft
     if (SPLIT == 3) block = 192;      // three-wave form: rotational, FSW / environment and translational wave
@@ -1259,6 +1296,11 @@ const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat, int sh_form,
 hipError_t launch_stats(const double* wave_reward, const unsigned long long* done_mask, int n_waves, double* out_sum,
                         long long* out_done, hipStream_t s) {
     hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(256), 0, s, wave_reward, done_mask, n_waves, out_sum, out_done);
+    return hipGetLastError();
+}
+
+hipError_t launch_stats2(const double* wave_reward, const unsigned long long* done_mask, int n_waves, double* out2, hipStream_t s) {
+    hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(256), 0, s, wave_reward, done_mask, n_waves, out2, (long long*)nullptr);
     return hipGetLastError();
 }
 

@@ -32,6 +32,14 @@ struct TailArgs {
     int fsw_lag, nav_lag;
     unsigned env_base;             // global index of this handle's env 0 (sharded batches hash the GLOBAL index)
     int pad_;
+    // device-resident surface (BSK_FLAG_EPISODE_STATS / BSK_FLAG_OBS_ROWMAJOR; NULL: off)
+    double* ep_return;             // [stride] return of the running episode (the kernel adds this step's reward)
+    double* term_return;           // [stride] return / length of the episode that ended at this step (valid where done)
+    int* term_len;                 // [stride]
+    unsigned char* done;           // [stride] 0 / 1
+    double* obs_rm;                // [n][5] row-major copy of the observation
+    int* err;                      // device-visible error word of the handle (page-locked host memory; rarely written)
+    unsigned long long* dbg;       // [stride/64] one word per wave, written by probe builds only (bsk_probes.hpp)
 };
 
 // Passed by value to step_kernel (kernarg segment -> SGPRs).
@@ -46,7 +54,9 @@ struct StepArgs {
     int n;
     int substeps;
     int nav_lag, fsw_lag;   // both also in TailArgs (post-loop re-read); here for the FSW block inside the loop
-    int pair_shift, pad2_;  // pair form: the roles of a workgroup's two waves swap with bit `pair_shift` of its index
+    int pair_shift;         // pair form: the roles of a workgroup's two waves swap with bit `pair_shift` of its index
+    int act_shift;          // actions are int32 (1) or the low words of little-endian int64 (0): byte offset = 8 i >> act_shift
+    const double* ep_return;      // BSK_FLAG_EPISODE_STATS: the running episode's return, loaded with the state (NULL: off)
     PowerCfg power;               // read only by FEAT >= FEAT_POWER
     ExtraCfg extra;               // read only by FEAT_FULL
     TailArgs tail;
@@ -55,7 +65,7 @@ struct StepArgs {
 // Host-side, variant-independent description of the hot constants (built once per handle).
 struct StepParams {
     double dt, mu, j2k;
-    double inertia[9], dinv[9], wmat[9];   // wmat = sum Js g g^T
+    double inertia[9], dmat[9], dinv[9], wmat[9];   // dmat = I_sc - sum Js g g^T, dinv its inverse, wmat = sum Js g g^T
     double gs[BSK_MAX_RW][3], js[BSK_MAX_RW];
     double f_coulomb;
     int32_t fsw_every;
@@ -95,6 +105,26 @@ struct StepBuffers {
     int n_pool;
     int n_fields;
     unsigned env_base;
+    int act_shift;
+    double* ep_return;
+    double* term_return;
+    int* term_len;
+    unsigned char* done;
+    double* obs_rm;
+    int* err;
+    unsigned long long* dbg;
+};
+
+// what a reset leaves in the output buffers of the envs it restarts (init_outputs_kernel)
+struct ResetOut {
+    double* obs;                   // [5][stride]
+    double* obs_rm;                // [n][5] or NULL
+    double* reward;                // [stride]
+    unsigned char* reason;         // [stride]
+    unsigned char* done;           // [stride] or NULL
+    double* ep_return;             // [stride] or NULL
+    double inv_wheel_limit, charge_scale;
+    int n_rw;
 };
 
 hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams& p, const StepBuffers& b, int block,
@@ -104,7 +134,11 @@ bool pair_available(int grav, bool diag, int feat);
 bool tri_available(int grav, bool diag, int feat);
 hipError_t launch_sample_pool(double* pool, int n_pool, int n_rw, unsigned long long seed, double mu, hipStream_t s);
 hipError_t launch_reset_from_pool(double* st, int64_t stride, int nf, const double* pool, int n_pool, const unsigned char* mask,
-                                  int n, int2* cnt, int* episodes, unsigned env_base, hipStream_t s);
+                                  int n, int2* cnt, int* episodes, unsigned env_base, const ResetOut& ro, hipStream_t s);
+// first observation [|sigma_BN|, |omega|, |Omega|/limit, charge/3600/power_max, 1], zero reward / reason / done / episode
+// return of freshly reset envs: all n (idx == NULL) or the m listed ones
+hipError_t launch_init_outputs(const double* st, int64_t stride, const int* idx, int m, const ResetOut& ro, hipStream_t s);
+hipError_t launch_stats2(const double* wave_reward, const unsigned long long* done_mask, int n_waves, double* out2, hipStream_t s);
 hipError_t launch_stats(const double* wave_reward, const unsigned long long* done_mask, int n_waves, double* out_sum,
                         long long* out_done, hipStream_t s);
 hipError_t launch_scatter_reset(double* st, int64_t stride, int nf, const double* ic, const int* idx, int m, int2* cnt,

@@ -10,7 +10,8 @@ done flags are computed on the device by the step kernel.
 import numpy as np
 
 from .. import spaces
-from .._lib import FLAG_AUTO_RESET, FLAG_DESAT, FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY, GRAV_PM_J2, DONE_BATTERY, DONE_LENGTH, DONE_ORBIT, DONE_WHEELS
+from .._lib import (FLAG_AUTO_RESET, FLAG_DESAT, FLAG_DRAG, FLAG_EPISODE_STATS, FLAG_OBS_ROWMAJOR, FLAG_POWER, FLAG_SUN_THIRD_BODY, GRAV_PM_J2,
+                     DONE_BATTERY, DONE_LENGTH, DONE_ORBIT, DONE_WHEELS)
 from ..simulators.dynamics.config import default_config
 from ..simulators.dynamics.propagator import BatchedPropagator
 from ..simulators.initial_conditions.batch import sample_ic_batch
@@ -142,7 +143,9 @@ class LeoPowerAttVecEnv(_Base):
                 if desat and n_rw:
                     cfg.flags |= FLAG_DESAT
             if device_reset_pool:
-                cfg.flags |= FLAG_AUTO_RESET
+                # the device-resident configuration: the kernel restarts finished envs, keeps the episode statistics and
+                # writes the observation row-major as well (what step_tensors hands to an on-GPU policy)
+                cfg.flags |= FLAG_AUTO_RESET | FLAG_EPISODE_STATS | FLAG_OBS_ROWMAJOR
         self.cfg = cfg
         self.n_rw = int(cfg.n_rw)
         self.max_length = int(cfg.max_length)
@@ -205,8 +208,18 @@ class LeoPowerAttVecEnv(_Base):
         self.episode_lengths[:] = 0
         return self._initial_obs(self._ic).T.reshape(self.num_envs, 5, 1)
 
+    def _ic_from_pool(self):
+        """The running episodes' initial conditions after device-side resets nobody mirrored on the host (reset_tensors /
+        step_tensors): the pool slots the device picked (slot rule of include/bskgpu.h: bsk_set_ic_pool)."""
+        _, episodes = self.propagator.get_terminal_obs()
+        base = int(getattr(self.propagator, "env_base", 0))
+        cols = [pool_slot(base + i, int(episodes[i]) - 1, self._pool.shape[1]) for i in range(self.num_envs)]
+        return np.ascontiguousarray(self._pool[:, cols])
+
     def reset_init(self):
         """Replay the current initial conditions (reference reset_init, :202-216)."""
+        if self._ic is None:
+            self._ic = self._ic_from_pool()
         return self.reset(self._ic)
 
     def step_async(self, actions):
@@ -237,7 +250,8 @@ class LeoPowerAttVecEnv(_Base):
             term, episodes = self.propagator.get_terminal_obs()
             for i in idx:
                 # the new episode's initial conditions, for reset_init(): the slot rule of the device-side reset
-                self._ic[:, i] = self._pool[:, pool_slot(i, episodes[i] - 1, self._pool.shape[1])]
+                if self._ic is not None:       # (None: device-resident steps in between; rebuilt on demand, _ic_from_pool)
+                    self._ic[:, i] = self._pool[:, pool_slot(i, episodes[i] - 1, self._pool.shape[1])]
                 infos[i] = {
                     "episode": {"r": float(self.episode_returns[i]), "l": int(self.episode_lengths[i])},
                     "terminal_observation": term[:, i].reshape(5, 1).copy(),
@@ -279,66 +293,92 @@ class LeoPowerAttVecEnv(_Base):
             dev = torch.device("cuda", self.propagator.device)
             v = self.propagator.device_views()
             tv = {"device": dev, "stream": self.propagator.stream_ptr()}
-            for k in ("obs", "reward", "reason", "done_mask", "state", "terminal_obs", "episodes"):
+            for k in ("obs", "reward", "reason", "done_mask", "state", "terminal_obs", "episodes", "episode_return",
+                      "terminal_return", "terminal_length", "obs_rowmajor", "done"):
                 if k in v:
-                    tv[k] = torch.as_tensor(v[k], device=dev)
-            tv["obs_n51"] = tv["obs"].t().unsqueeze(-1)                  # (N,5,1) view of the SoA buffer
+                    tv[k] = torch.as_tensor(v[k], device=dev)                # ("done": a bool view of the kernel's 0 / 1 byte)
+            # (N,5,1): the row-major buffer when the kernel writes one (contiguous: a policy's reshape is free), else a
+            # transposed view of the SoA buffer
+            tv["obs_n51"] = tv["obs_rowmajor"].unsqueeze(-1) if "obs_rowmajor" in tv else tv["obs"].t().unsqueeze(-1)
             if "terminal_obs" in tv:
                 tv["terminal_obs_n51"] = tv["terminal_obs"].t().unsqueeze(-1)
             tv["ext"] = None
             self._tviews = tv
         return tv
 
-    def reset_tensors(self):
-        """``reset()`` for the device-resident loop: restarts every env from the device pool when the pool was drawn
-        on the GPU (no host data), else uploads fresh host-sampled initial conditions; returns the (N,5,1) device
-        tensor of first observations."""
+    def _order_streams(self, tv, before):
+        """Device-side ordering between the caller's current torch stream and the handle's stream (nothing when they are the
+        same stream): ``before`` = the handle's work waits for the caller's, else the caller's waits for the handle's."""
         import torch
-        ob = self.reset()
+        cur = torch.cuda.current_stream(tv["device"])
+        if cur.cuda_stream == tv["stream"]:
+            return
+        if tv["ext"] is None:
+            tv["ext"] = torch.cuda.ExternalStream(tv["stream"], device=tv["device"])
+        if before:
+            tv["ext"].wait_stream(cur)
+        else:
+            cur.wait_stream(tv["ext"])
+
+    def reset_tensors(self):
+        """``reset()`` for the device-resident loop -> the (N,5,1) device tensor of first observations, a zero-copy view of
+        the buffer the reset kernel itself wrote.  With the pool drawn on the GPU (``device_sampler``) nothing crosses PCIe
+        and nothing synchronises: one kernel on the handle's stream restarts every env from the pool.  Otherwise fresh
+        host-sampled initial conditions are uploaded (the one unavoidable copy) and the observation is again the kernel's.
+        Replaces reference envs/leoPowerAttitudeEnvironment.py:172-191 for an on-GPU training loop."""
         tv = self._torch_views()
-        return torch.as_tensor(ob, device=tv["device"])
+        if self.device_sampler and hasattr(self.propagator, "reset_from_pool_device"):
+            self._order_streams(tv, before=True)
+            self.propagator.reset_from_pool_device(None)
+            self._order_streams(tv, before=False)
+            self._ic = None                     # reset_init() rebuilds it from the pool's slot rule on demand
+            self._actions = None
+            self.episode_returns[:] = 0
+            self.episode_lengths[:] = 0
+        else:
+            self.reset()
+        return tv["obs_n51"]
 
     def step_tensors(self, actions):
-        """One env step with everything resident on the GPU: ``actions`` is an int32 device tensor (N,), the result
-        ``(obs (N,5,1), reward (N,), done (N,) bool, info)`` are device tensors — zero-copy views of the buffers the
-        step kernel writes (valid until the next step), ``done`` derived from the kernel's reason byte.  No host
-        synchronisation and no PCIe traffic: the launch is ordered after the producer of ``actions`` and before the
-        consumers of the outputs on the device (same stream when the env was created on the caller's stream, stream
-        waits otherwise).  Needs the device-side auto-reset (``device_reset_pool``) unless ``auto_reset=False``:
-        finished envs are restarted by the kernel itself; ``info`` holds device tensors ``reason`` (N,) uint8,
-        ``terminal_observation`` (N,5,1) (rows valid where ``done``) and ``episodes`` (N,) int32.
-        Host-side episode statistics (``episode_returns`` / ``episode_lengths``, ``reset_init``'s IC mirror) are not
-        updated by this path.  Fastest with policy and env on ONE non-default torch stream (``stream=s.cuda_stream``, loop
-        under ``torch.cuda.stream(s)``): torch's legacy default stream synchronises with every other stream of the process
-        (measured 76 against 41 us per step of a K = 1 loop; a ``torch.cuda.CUDAGraph`` capture of the step also works and
-        buys nothing on top, tools/exp/rl_graph.py).  Replaces reference envs/leoPowerAttitudeEnvironment.py:65-145 and
-        simulators/leoPowerAttitudeSimulator.py:598-619 for an on-GPU policy."""
+        """One env step with everything resident on the GPU: ``actions`` is an int32 or int64 device tensor (N,) - int64 is
+        what ``argmax`` returns, read in place - and the result ``(obs (N,5,1), reward (N,), done (N,) bool, info)`` are
+        device tensors: zero-copy views of the buffers the step kernel writes (valid until the next step).  This method
+        launches NO torch kernel of its own, does not synchronise and moves nothing over PCIe: the launch is ordered after
+        the producer of ``actions`` and before the consumers of the outputs on the device (same stream when the env was
+        created on the caller's stream, stream waits otherwise).  Needs the device-side auto-reset (``device_reset_pool``)
+        unless ``auto_reset=False``: finished envs are restarted by the kernel itself.  ``info`` holds device tensors:
+        ``reason`` (N,) uint8; ``terminal_observation`` (N,5,1), ``episode_r`` (N,) and ``episode_l`` (N,) int32 - rows valid
+        where ``done`` (the Monitor convention of reference envs/leoPowerAttitudeEnvironment.py:130-135, on the device);
+        ``episode_return`` (N,), the running episodes' returns; ``episodes`` (N,) int32, finished episodes per env.
+        The host-side mirrors (``episode_returns`` / ``episode_lengths``) are not updated by this path.
+        Fastest with policy and env on ONE non-default torch stream (``stream=s.cuda_stream``, loop under
+        ``torch.cuda.stream(s)``): torch's legacy default stream synchronises with every other stream of the process.
+        Replaces reference envs/leoPowerAttitudeEnvironment.py:65-145 and simulators/leoPowerAttitudeSimulator.py:598-619
+        for an on-GPU policy."""
         import torch
         if self.auto_reset and not self.device_reset:
             raise ValueError("step_tensors needs device_reset_pool > 0 (device-side auto-reset) or auto_reset=False")
         tv = self._torch_views()
-        if not (isinstance(actions, torch.Tensor) and actions.is_cuda and actions.dtype == torch.int32
+        if not (isinstance(actions, torch.Tensor) and actions.is_cuda and actions.dtype in (torch.int32, torch.int64)
                 and actions.is_contiguous() and actions.numel() == self.num_envs and actions.device == tv["device"]):
-            raise ValueError("actions must be a contiguous int32 tensor of %d entries on %s" % (self.num_envs, tv["device"]))
-        cur = torch.cuda.current_stream(tv["device"])
-        same = cur.cuda_stream == tv["stream"]
-        if not same:
-            if tv["ext"] is None:
-                tv["ext"] = torch.cuda.ExternalStream(tv["stream"], device=tv["device"])
-            tv["ext"].wait_stream(cur)                 # the kernel reads `actions` after their producer
+            raise ValueError("actions must be a contiguous int32 or int64 tensor of %d entries on %s" % (self.num_envs, tv["device"]))
+        self._order_streams(tv, before=True)       # the kernel reads `actions` after their producer
         # `actions` stays referenced until the next step replaces it: by then the caller's stream has been ordered after
         # the kernel that read it (wait below), so the caching allocator may hand the block out again.  (No
         # record_stream on the handle's stream: the allocator would record an event on it when the tensor dies, possibly
         # after close() has destroyed that stream.)
         self._dev_actions = actions
-        self.propagator.step_device(actions.data_ptr(), self.substeps)
-        if not same:
-            cur.wait_stream(tv["ext"])                 # consumers on the caller's stream run after the kernel
+        self.propagator.step_device(actions.data_ptr(), self.substeps, int64=actions.dtype == torch.int64)
+        self._order_streams(tv, before=False)      # consumers on the caller's stream run after the kernel
+        self._ic = None if self.device_reset else self._ic
         info = {"reason": tv["reason"]}
         if "terminal_obs_n51" in tv:
             info["terminal_observation"] = tv["terminal_obs_n51"]
             info["episodes"] = tv["episodes"]
-        return tv["obs_n51"], tv["reward"], tv["reason"].ne(0), info
+        if "terminal_return" in tv:
+            info["episode_r"], info["episode_l"], info["episode_return"] = tv["terminal_return"], tv["terminal_length"], tv["episode_return"]
+        done = tv["done"] if "done" in tv else tv["reason"].ne(0)
+        return tv["obs_n51"], tv["reward"], done, info
 
     def close(self):
         self._tviews = None            # torch views alias device buffers the propagator is about to free

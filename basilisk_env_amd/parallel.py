@@ -49,6 +49,20 @@ def local_obs_tensor(prop):
     return torch.from_numpy(np.ascontiguousarray(prop.get_obs()[0]))
 
 
+def release_to_handle(prop):
+    """The other half of the ordering: make the handle's stream wait for what torch's current stream has queued so far (the
+    copy of the padded rows, the collective that reads the zero-copy alias), so that the NEXT step kernel cannot overwrite
+    the observation buffer while it is still being read.  Device-side dependency, no host synchronisation."""
+    import torch
+
+    if hasattr(prop, "stream_ptr"):
+        dev = torch.device("cuda", getattr(prop, "device", torch.cuda.current_device()))
+        cur = torch.cuda.current_stream(dev)
+        hs = prop.stream_ptr()
+        if hs and cur.cuda_stream != hs:
+            torch.cuda.ExternalStream(hs, device=dev).wait_stream(cur)
+
+
 class ObsGatherer(object):
     """The exchange step, set up ONCE per (propagator, group): shard sizes are static (env-index ranges), so they are
     exchanged here and never again; ``gather`` / ``all_gather`` then run exactly one collective per call."""
@@ -65,6 +79,12 @@ class ObsGatherer(object):
         self.equal = len(set(self.sizes)) == 1
         self.n_local = n_local
 
+    def _release(self, local):
+        """Contract: a gather reads the library's observation buffer (or a copy queued on torch's stream); the handle's
+        stream is made to wait for those reads before its next step kernel may run (release_to_handle)."""
+        if local.is_cuda:
+            release_to_handle(self.prop)
+
     def _local(self):
         local = local_obs_tensor(self.prop)
         if local.is_cuda and self.cpu:
@@ -78,12 +98,14 @@ class ObsGatherer(object):
             # concatenation along dim 0 is the layout both RCCL and gloo accept; view as (world, 5, n)
             out = torch.empty((self.world * local.shape[0], self.n_local), dtype=local.dtype, device=local.device)
             dist.all_gather_into_tensor(out, local, group=self.group)
+            self._release(local)
             return out.view(self.world, local.shape[0], self.n_local)
         n_max = max(self.sizes)
         padded = torch.zeros((5, n_max), dtype=local.dtype, device=local.device)
         padded[:, :self.n_local] = local
         bufs = [torch.empty_like(padded) for _ in range(self.world)]
         dist.all_gather(bufs, padded, group=self.group)
+        self._release(local)
         return [b[:, :s] for b, s in zip(bufs, self.sizes)]
 
     def gather(self, dst=0):
@@ -92,6 +114,7 @@ class ObsGatherer(object):
         if self.equal:
             bufs = [torch.empty_like(local) for _ in range(self.world)] if self.rank == dst else None
             dist.gather(local, bufs, dst=dst, group=self.group)
+            self._release(local)
             return torch.stack(bufs) if self.rank == dst else None
         out = self.all_gather()
         return out if self.rank == dst else None
@@ -115,13 +138,17 @@ def gather_observations(prop, dist, dst=None, group=None):
 
 class DirectRcclGather(object):
     """One process per GPU, the direct leg: this rank's communicator comes from ``rccl.Comm.init_rank`` (unique id
-    broadcast once through ``dist``), the gather itself is grouped ncclSend / ncclRecv on the propagator handle's OWN
-    stream from the library's SoA rows into the root's ``[5][n_total]`` device buffer — no torch tensor, no staging
-    copy, no host synchronisation between the step kernel and the exchange."""
+    broadcast once through ``dist``), the gather itself is ONE group of ncclSend / ncclRecv on the propagator handle's OWN
+    stream from the library's buffers into the root's device buffers - observations ``[5][n_total]``, and with
+    ``rows=7`` (default) rewards ``[n_total]`` and done reasons ``u8[n_total]`` as well (what a
+    consumer on the root GPU needs to train on) - no torch tensor, no staging copy, no host synchronisation between the
+    step kernel and the exchange.  ``all_reduce_stats`` is the other collective of the path: two doubles per rank."""
 
-    def __init__(self, prop, dist, root=0, group=None):
+    def __init__(self, prop, dist, root=0, group=None, rows=7):
         from . import _hip, rccl
-        self.prop, self.root = prop, int(root)
+        if rows not in (5, 7):
+            raise ValueError("rows: 5 (observations) or 7 (+ reward, reason)")
+        self.prop, self.root, self.rows = prop, int(root), int(rows)
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         box = [rccl.unique_id() if self.rank == 0 else None]
@@ -129,29 +156,49 @@ class DirectRcclGather(object):
         sizes = [None] * self.world
         dist.all_gather_object(sizes, int(prop.n_envs), group=group)
         self.sizes = [int(x) for x in sizes]
-        self.n_total = sum(self.sizes)
+        n = self.n_total = sum(self.sizes)
         self.comm = rccl.Comm.init_rank(self.world, self.rank, box[0], prop.device)
-        self.out = _hip.DeviceBuffer(5 * self.n_total * 8, prop.device) if self.rank == self.root else None
+        self.out = _hip.DeviceBuffer(6 * n * 8 + n, prop.device) if self.rank == self.root else None     # obs | reward | reason
+        o = self.out.ptr if self.out is not None else 0
         v = prop.device_views()
-        self.src = v["obs"].__cuda_array_interface__["data"][0]
-        self.pitch = v["stride"] * 8
+        ptr = lambda k: v[k].__cuda_array_interface__["data"][0]
+        self.bufs = rccl.step_output_bufs(ptr("obs"), v["stride"] * 8, ptr("reward"), ptr("reason"), o, o + 5 * n * 8, o + 6 * n * 8)
+        if self.rows == 5:
+            self.bufs = self.bufs[:1]
+        self.bytes_over_fabric = rccl.gather_bytes(self.sizes, self.bufs, self.root)
         self.stream = prop.stream_ptr()
 
     def enqueue(self):
         """Queue one gather behind whatever the handle's stream holds (asynchronous)."""
         from . import rccl
-        out = self.out.ptr if self.out is not None else 0
         rccl.group_start()
-        rccl.enqueue_gather_rows(self.comm, self.stream, self.root, self.sizes, self.src, self.pitch, 5, out)
+        rccl.enqueue_gather(self.comm, self.stream, self.root, self.sizes, self.bufs)
         rccl.group_end()
-        rccl.copy_own_rows(self.comm, self.stream, self.root, self.sizes, self.src, self.pitch, 5, out)
+        rccl.copy_own(self.comm, self.stream, self.root, self.sizes, self.bufs)
 
-    def result_view(self):
-        """Root only: zero-copy view (5, n_total) of the gathered batch, env-index order."""
+    def all_reduce_stats(self):
+        """{sum of rewards, number of done envs} of the whole batch on every rank's GPU: the device-side partial of this rank
+        (bsk_get_batch_stats_device) all-reduced in place on the handle's stream.  -> device pointer of f64[2]."""
+        from . import rccl
+        p = self.prop.batch_stats_device()
+        rccl.all_reduce_sum_f64(self.comm, self.stream, p, p, 2)
+        return p
+
+    def _view(self, k, shape, typestr):
         from .simulators.dynamics.propagator import _DevArray
         if self.out is None:
             return None
-        return _DevArray(self.out.ptr, (5, self.n_total), "<f8", owner=self.prop, device=self.prop.device, stream=self.stream)
+        return _DevArray(self.bufs[k].out_ptr, shape, typestr, owner=self.prop, device=self.prop.device, stream=self.stream)
+
+    def result_view(self):
+        """Root only: zero-copy view (5, n_total) of the gathered observations, env-index order."""
+        return self._view(0, (5, self.n_total), "<f8")
+
+    def result_views(self):
+        """Root only: {"obs" (5, n_total), "reward" (n_total,), "reason" (n_total,) uint8}."""
+        if self.out is None or self.rows != 7:
+            return None if self.out is None else {"obs": self.result_view()}
+        return {"obs": self.result_view(), "reward": self._view(1, (self.n_total,), "<f8"), "reason": self._view(2, (self.n_total,), "|u1")}
 
     def close(self):
         self.comm.destroy()

@@ -19,6 +19,7 @@ import os
 from . import _hip, _lib
 
 ncclUint8, ncclInt32, ncclFloat64 = 1, 2, 8
+ncclSum = 0
 _RCCL = None
 
 
@@ -72,6 +73,7 @@ def load():
     lib.ncclSend.argtypes = [vp, sz, C.c_int, C.c_int, vp, vp]
     lib.ncclRecv.argtypes = [vp, sz, C.c_int, C.c_int, vp, vp]
     lib.ncclAllGather.argtypes = [vp, vp, sz, C.c_int, vp, vp]
+    lib.ncclAllReduce.argtypes = [vp, vp, sz, C.c_int, C.c_int, vp, vp]
     _RCCL = lib
     return lib
 
@@ -102,9 +104,9 @@ class Comm(object):
             raise ValueError("unique id must be 128 bytes")
         uid = _UniqueId()
         C.memmove(C.addressof(uid), uid_bytes, 128)
-        _hip.set_device(device)
         h = C.c_void_p()
-        _ck(lib.ncclCommInitRank(C.byref(h), int(world), uid, int(rank)), "ncclCommInitRank")
+        with _hip.device_guard(device):       # the communicator binds the device current at this call; the caller's stays
+            _ck(lib.ncclCommInitRank(C.byref(h), int(world), uid, int(rank)), "ncclCommInitRank")
         return cls(h.value, rank, world, device)
 
     @classmethod
@@ -141,12 +143,34 @@ def column_offsets(sizes):
     return offs, acc
 
 
-def enqueue_gather_rows(comm, stream, root, sizes, src_ptr, src_pitch_bytes, rows, out_ptr, itemsize=8, dtype=ncclFloat64):
-    """This rank's part of the direct gather of a ``[rows][n_r]`` shard per rank into the root's ``[rows][n_total]``
-    buffer (column offset of rank r = sum of the sizes before it).  MUST be called between group_start() and
-    group_end(), on every rank of the communicator (one process per rank: once; one process for all: once per Comm).
-    Non-root ranks send ``rows`` messages of ``sizes[rank]`` items, the root posts the matching receives and copies
-    its own shard device-to-device on the same stream after the group.  ``out_ptr`` is only read on the root."""
+class GatherBuf(object):
+    """One buffer of the gather: this rank's ``[rows][n_r]`` shard at ``src_ptr`` (row pitch ``src_pitch_bytes``) lands in
+    the root's ``[rows][n_total]`` buffer at ``out_ptr`` (only read on the root) at the rank's column offset."""
+
+    def __init__(self, src_ptr, src_pitch_bytes, rows, out_ptr, itemsize=8, dtype=ncclFloat64):
+        self.src_ptr, self.src_pitch_bytes, self.rows, self.out_ptr = int(src_ptr), int(src_pitch_bytes), int(rows), int(out_ptr or 0)
+        self.itemsize, self.dtype = int(itemsize), int(dtype)
+
+
+def step_output_bufs(obs_ptr, obs_pitch_bytes, reward_ptr, reason_ptr, out_obs, out_reward, out_reason):
+    """What a consumer on the root GPU needs from every shard to train on ("obs f64[5][N/8]
+    (+ reward, done mask)"): five observation rows, one reward row, one reason row (uint8; done = reason != 0) - seven
+    rows per rank, moved in ONE group."""
+    return [GatherBuf(obs_ptr, obs_pitch_bytes, 5, out_obs), GatherBuf(reward_ptr, 0, 1, out_reward),
+            GatherBuf(reason_ptr, 0, 1, out_reason, itemsize=1, dtype=ncclUint8)]
+
+
+def gather_bytes(sizes, bufs, root):
+    """Bytes that cross the fabric per gather (everything but the root's own shard)."""
+    return sum(int(n) for r, n in enumerate(sizes) if r != root) * sum(b.rows * b.itemsize for b in bufs)
+
+
+def enqueue_gather(comm, stream, root, sizes, bufs):
+    """This rank's part of the direct gather of several buffers (``GatherBuf``) in one group: column offset of rank r = sum
+    of the sizes before it.  MUST be called between group_start() and group_end(), on every rank of the communicator (one
+    process per rank: once; one process for all: once per Comm).  Non-root ranks send ``rows`` messages of ``sizes[rank]``
+    items per buffer, the root posts the matching receives (same order: messages between two ranks pair up in posting order)
+    and copies its own shard device-to-device on the same stream after the group (copy_own)."""
     lib = load()
     offs, n_total = column_offsets(sizes)
     vp = C.c_void_p
@@ -154,19 +178,38 @@ def enqueue_gather_rows(comm, stream, root, sizes, src_ptr, src_pitch_bytes, row
         for r in range(comm.world):
             if r == root or sizes[r] == 0:
                 continue
-            for f in range(rows):
-                _ck(lib.ncclRecv(vp(out_ptr + (f * n_total + offs[r]) * itemsize), int(sizes[r]), dtype, r, vp(comm.handle), vp(stream)),
-                    "ncclRecv")
+            for b in bufs:
+                for f in range(b.rows):
+                    _ck(lib.ncclRecv(vp(b.out_ptr + (f * n_total + offs[r]) * b.itemsize), int(sizes[r]), b.dtype, r, vp(comm.handle), vp(stream)),
+                        "ncclRecv")
     elif sizes[comm.rank]:
-        for f in range(rows):
-            _ck(lib.ncclSend(vp(src_ptr + f * src_pitch_bytes), int(sizes[comm.rank]), dtype, root, vp(comm.handle), vp(stream)), "ncclSend")
+        for b in bufs:
+            for f in range(b.rows):
+                _ck(lib.ncclSend(vp(b.src_ptr + f * b.src_pitch_bytes), int(sizes[comm.rank]), b.dtype, root, vp(comm.handle), vp(stream)), "ncclSend")
 
 
-def copy_own_rows(comm, stream, root, sizes, src_ptr, src_pitch_bytes, rows, out_ptr, itemsize=8):
-    """The root's own shard: one strided device-to-device copy on its stream (call after group_end())."""
+def copy_own(comm, stream, root, sizes, bufs):
+    """The root's own shard: one strided device-to-device copy per buffer on its stream (call after group_end())."""
     if comm.rank != root or not sizes[root]:
         return
     offs, n_total = column_offsets(sizes)
-    _hip.set_device(comm.device)
-    _hip.memcpy2d_async(out_ptr + offs[root] * itemsize, n_total * itemsize, src_ptr, src_pitch_bytes, int(sizes[root]) * itemsize, rows,
-                        _hip.hipMemcpyDeviceToDevice, stream)
+    with _hip.device_guard(comm.device):
+        for b in bufs:
+            _hip.memcpy2d_async(b.out_ptr + offs[root] * b.itemsize, n_total * b.itemsize, b.src_ptr, b.src_pitch_bytes or int(sizes[root]) * b.itemsize,
+                                int(sizes[root]) * b.itemsize, b.rows, _hip.hipMemcpyDeviceToDevice, stream)
+
+
+def enqueue_gather_rows(comm, stream, root, sizes, src_ptr, src_pitch_bytes, rows, out_ptr, itemsize=8, dtype=ncclFloat64):
+    """One buffer (the observation rows alone): see enqueue_gather."""
+    enqueue_gather(comm, stream, root, sizes, [GatherBuf(src_ptr, src_pitch_bytes, rows, out_ptr, itemsize, dtype)])
+
+
+def copy_own_rows(comm, stream, root, sizes, src_ptr, src_pitch_bytes, rows, out_ptr, itemsize=8):
+    copy_own(comm, stream, root, sizes, [GatherBuf(src_ptr, src_pitch_bytes, rows, out_ptr, itemsize)])
+
+
+def all_reduce_sum_f64(comm, stream, send_ptr, recv_ptr, count):
+    """ncclAllReduce(sum) of ``count`` doubles on ``stream`` (in place when the pointers are equal): the batch scalars
+    {sum of rewards, number of done envs} of a sharded step - two doubles per rank (bsk_get_batch_stats_device)."""
+    _ck(load().ncclAllReduce(C.c_void_p(send_ptr), C.c_void_p(recv_ptr), int(count), ncclFloat64, ncclSum, C.c_void_p(comm.handle), C.c_void_p(stream)),
+        "ncclAllReduce")

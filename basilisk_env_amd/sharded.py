@@ -162,13 +162,13 @@ class ShardedPropagator(object):
             v, st = p.device_views(), p.stream_ptr()
             pitch = v["stride"] * 8
             w = (hi - lo) * 8
-            _hip.set_device(p.device)
-            _hip.memcpy2d_async(h["ptr_f64"] + lo * 8, n * 8, v["obs"].__cuda_array_interface__["data"][0], pitch, w, 5,
-                                _hip.hipMemcpyDeviceToHost, st)
-            _hip.memcpy2d_async(h["ptr_f64"] + (5 * n + lo) * 8, n * 8, v["reward"].__cuda_array_interface__["data"][0], w, w, 1,
-                                _hip.hipMemcpyDeviceToHost, st)
-            _hip.memcpy2d_async(h["ptr_u8"] + lo, n, v["reason"].__cuda_array_interface__["data"][0], hi - lo, hi - lo, 1,
-                                _hip.hipMemcpyDeviceToHost, st)
+            with _hip.device_guard(p.device):      # (the calling thread's current device is the caller's business: restored)
+                _hip.memcpy2d_async(h["ptr_f64"] + lo * 8, n * 8, v["obs"].__cuda_array_interface__["data"][0], pitch, w, 5,
+                                    _hip.hipMemcpyDeviceToHost, st)
+                _hip.memcpy2d_async(h["ptr_f64"] + (5 * n + lo) * 8, n * 8, v["reward"].__cuda_array_interface__["data"][0], w, w, 1,
+                                    _hip.hipMemcpyDeviceToHost, st)
+                _hip.memcpy2d_async(h["ptr_u8"] + lo, n, v["reason"].__cuda_array_interface__["data"][0], hi - lo, hi - lo, 1,
+                                    _hip.hipMemcpyDeviceToHost, st)
             streams.append(st)
         for st in streams:
             _hip.stream_sync(st)
@@ -209,34 +209,60 @@ class ShardedPropagator(object):
         """Per shard: (lo, hi, device, views)."""
         return [(lo, hi, p.device, p.device_views()) for p, (lo, hi) in zip(self.shards, self.ranges)]
 
-    def gather_obs_device(self, root=0):
-        """Observation batch ``f64[5][n_total]`` on the root shard's GPU without touching the host: grouped
-        ncclSend / ncclRecv from every other device's SoA rows straight into the root's buffer (rccl.py), enqueued on
-        the handles' own streams.  Returns a zero-copy device view (valid until the next gather); the caller orders
-        its consumer after the root shard's stream (``shards[root].stream_ptr()``)."""
+    def gather_step_outputs_device(self, root=0):
+        """What a trainer on ONE GPU needs of the whole batch - observations ``f64[5][n_total]``, rewards ``f64[n_total]``,
+        done reasons ``u8[n_total]`` (done = reason != 0) - on the root shard's GPU without touching the host: ONE group of
+        ncclSend / ncclRecv (seven rows per rank) from every other device's buffers straight into the root's (rccl.py),
+        enqueued on the handles' own streams.  Returns zero-copy device views ``{"obs", "reward", "reason"}`` (valid until the
+        next gather); the caller orders its consumer after the root shard's stream (``shards[root].stream_ptr()``).
+        SURVEY.md section 8(e)."""
         from . import _hip, rccl
         from .simulators.dynamics.propagator import _DevArray
-        world = len(self.shards)
+        world, n = len(self.shards), self.n_envs
         if self._gather_buf is None:
-            self._gather_buf = _hip.DeviceBuffer(5 * self.n_envs * 8, self.shards[root].device)
+            self._gather_buf = _hip.DeviceBuffer(6 * n * 8 + n, self.shards[root].device)       # obs | reward | reason
             self._gather_root = root
         elif self._gather_root != root:
             raise ValueError("gather buffer lives on shard %d's device" % self._gather_root)
         if world > 1 and self._comms is None:
             self._comms = rccl.Comm.init_all(self.devices)
         out = self._gather_buf.ptr
-        srcs = []
+        out_obs, out_rew, out_why = out, out + 5 * n * 8, out + 6 * n * 8
+        bufs, streams = [], []
         for p in self.shards:
             v = p.device_views()
-            srcs.append((v["obs"].__cuda_array_interface__["data"][0], v["stride"] * 8, p.stream_ptr()))
+            ptr = lambda k: v[k].__cuda_array_interface__["data"][0]
+            bufs.append(rccl.step_output_bufs(ptr("obs"), v["stride"] * 8, ptr("reward"), ptr("reason"), out_obs, out_rew, out_why))
+            streams.append(p.stream_ptr())
         if world > 1:
             rccl.group_start()
             for r in range(world):
-                rccl.enqueue_gather_rows(self._comms[r], srcs[r][2], root, self.sizes, srcs[r][0], srcs[r][1], 5, out)
+                rccl.enqueue_gather(self._comms[r], streams[r], root, self.sizes, bufs[r])
             rccl.group_end()
         rroot = self._comms[root] if self._comms else rccl.Comm(None, root, world, self.shards[root].device)
-        rccl.copy_own_rows(rroot, srcs[root][2], root, self.sizes, srcs[root][0], srcs[root][1], 5, out)
-        return _DevArray(out, (5, self.n_envs), "<f8", owner=self.shards[root], device=self.shards[root].device, stream=srcs[root][2])
+        rccl.copy_own(rroot, streams[root], root, self.sizes, bufs[root])
+        kw = {"owner": self.shards[root], "device": self.shards[root].device, "stream": streams[root]}
+        return {"obs": _DevArray(out_obs, (5, n), "<f8", **kw), "reward": _DevArray(out_rew, (n,), "<f8", **kw),
+                "reason": _DevArray(out_why, (n,), "|u1", **kw), "bytes_over_fabric": rccl.gather_bytes(self.sizes, bufs[root], root)}
+
+    def gather_obs_device(self, root=0):
+        """The observation part of gather_step_outputs_device (rewards and reasons travel in the same group)."""
+        return self.gather_step_outputs_device(root)["obs"]
+
+    def all_reduce_stats_device(self):
+        """Batch scalars of the last step on EVERY shard's GPU: one ncclAllReduce of two doubles {sum of rewards, number of done
+        envs} on the handles' streams, operands produced on the device (bsk_get_batch_stats_device) - no host value involved.
+        -> list of device pointers (f64[2]), one per shard; a single shard needs no collective."""
+        from . import rccl
+        ptrs = [p.batch_stats_device() for p in self.shards]
+        if len(self.shards) > 1:
+            if self._comms is None:
+                self._comms = rccl.Comm.init_all(self.devices)
+            rccl.group_start()
+            for c, p, ptr in zip(self._comms, self.shards, ptrs):
+                rccl.all_reduce_sum_f64(c, p.stream_ptr(), ptr, ptr, 2)
+            rccl.group_end()
+        return ptrs
 
 
 def ShardedVecEnv(num_envs, devices=(0,), propagator_factory=None, **kw):

@@ -98,6 +98,9 @@ class BatchedPropagator(object):
 
     def __del__(self):
         try:
+            import sys
+            if sys.is_finalizing():      # interpreter teardown: the HIP runtime may be gone already, the OS reclaims the rest
+                return
             self.close()
         except Exception:
             pass
@@ -163,8 +166,10 @@ class BatchedPropagator(object):
         self._last_actions = a  # keep alive until the async H2D copy has been consumed
         check(self._lib.bsk_step(self._handle(), a.ctypes.data, int(substeps)))
 
-    def step_device(self, d_actions_ptr, substeps):
-        check(self._lib.bsk_step_device(self._handle(), C.c_void_p(int(d_actions_ptr)), int(substeps)))
+    def step_device(self, d_actions_ptr, substeps, int64=False):
+        """Actions already on the device: int32[n] (``int64=False``) or int64[n] (torch's argmax output, read in place)."""
+        fn = self._lib.bsk_step_device_i64 if int64 else self._lib.bsk_step_device
+        check(fn(self._handle(), C.c_void_p(int(d_actions_ptr)), int(substeps)))
 
     pinned_read_back = True     # get_obs(copy=False) exists
 
@@ -235,6 +240,17 @@ class BatchedPropagator(object):
         if pt.value:
             out["terminal_obs"] = _DevArray(pt.value, (5, n), "<f8", strides=(st.value * 8, 8), **kw)
             out["episodes"] = _DevArray(pe.value, (n,), "<i4", **kw)
+        # device-resident episode statistics / row-major observation (FLAG_EPISODE_STATS / FLAG_OBS_ROWMAJOR)
+        er, tr, tl, dn, rm = (C.c_void_p() for _ in range(5))
+        if hasattr(self._lib, "bsk_get_episode_device"):
+            check(self._lib.bsk_get_episode_device(self._handle(), C.byref(er), C.byref(tr), C.byref(tl), C.byref(dn), C.byref(rm)))
+        if er.value:
+            out["episode_return"] = _DevArray(er.value, (n,), "<f8", **kw)
+            out["terminal_return"] = _DevArray(tr.value, (n,), "<f8", **kw)
+            out["terminal_length"] = _DevArray(tl.value, (n,), "<i4", **kw)
+            out["done"] = _DevArray(dn.value, (n,), "|b1", **kw)
+        if rm.value:
+            out["obs_rowmajor"] = _DevArray(rm.value, (n, 5), "<f8", **kw)
         return out
 
     def get_ic_pool(self):
@@ -266,6 +282,18 @@ class BatchedPropagator(object):
             mp = mask.ctypes.data
         check(self._lib.bsk_reset_from_pool(self._handle(), mp))
 
+    def reset_from_pool_device(self, d_mask_ptr=None):
+        """The same with the mask (uint8[n], or None for every env) in DEVICE memory: enqueued on the handle's stream,
+        no host data, no copy, no synchronisation."""
+        check(self._lib.bsk_reset_from_pool_device(self._handle(), C.c_void_p(int(d_mask_ptr)) if d_mask_ptr else None))
+
+    def batch_stats_device(self):
+        """-> device pointer of f64[2] = {sum of rewards, number of done envs} of the last step, produced on the handle's
+        stream without synchronising (the operand of a sharded batch's one all-reduce)."""
+        p = C.c_void_p()
+        check(self._lib.bsk_get_batch_stats_device(self._handle(), C.byref(p)))
+        return p.value
+
     def get_terminal_obs(self):
         """-> terminal observations (5, N) (valid where the last step reported done), finished-episode
         counts (N,) int32."""
@@ -286,6 +314,19 @@ class BatchedPropagator(object):
         self.env_base = int(base)
 
     # ------------------------------------------------------------------ measurement
+    @staticmethod
+    def debug_counters():
+        """-> (host <-> device copies, stream synchronisations) the library has issued in this process so far."""
+        a, b = C.c_int64(), C.c_int64()
+        check(_lib.load().bsk_debug_counters(C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def debug_words(self):
+        """Probe builds (csrc/bsk_probes.hpp): the 64-bit word every wavefront of the last launch left -> uint64[ceil(n / 64)]."""
+        out = np.zeros((self.n_envs + 63) // 64, dtype=np.uint64)
+        check(self._lib.bsk_debug_words(self._handle(), out.ctypes.data))
+        return out
+
     def profile_begin(self, capacity, stride=1):
         """Arm dispatch-timestamp profiling of the step kernel for every ``stride``-th launch."""
         check(self._lib.bsk_profile_set_stride(self._handle(), int(stride)))

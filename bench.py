@@ -155,7 +155,7 @@ def kernel_time(prop, d_act_ptr, substeps, launches, stride=None):
     return mean_ms, n, {}
 
 
-def cpu_baseline(cfg, n_rw, substeps, budget_s=12.0, n=8192, sh=None):
+def cpu_baseline(cfg, n_rw, substeps, budget_s=12.0, n=8192, sh=None, single_s=0.0):
     """The CPU oracle (plain-C restatement, oracle/bsk_oracle.c) on the host cores of this box:
     OpenMP over spacecraft, bounded to ~budget_s.  A reported baseline, not the target.  ``sh``: harmonics degree
     (synthetic Kaula field) when the configuration's gravity model is GRAV_SH."""
@@ -182,9 +182,26 @@ def cpu_baseline(cfg, n_rw, substeps, budget_s=12.0, n=8192, sh=None):
         el = time.perf_counter() - t0
         if el > budget_s or done_steps >= 100000:
             break
-    return {"value": n * done_steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d envs x %d env-steps of %d RK4 sub-step(s), same physics/config, OpenMP over envs, %.1f s"
-                      % (n, done_steps, substeps, el)}
+    out = {"value": n * done_steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+           "sample": "%d envs x %d env-steps of %d RK4 sub-step(s), same physics/config, OpenMP over envs, %.1f s"
+                     % (n, done_steps, substeps, el)}
+    if single_s > 0:
+        # ... and on ONE core ("on all host cores ... and single-threaded"): the same library, one thread
+        n1 = max(1, n // max(cores, 1))
+        st1 = sample_ic_batch(n1, n_rw, seed=0)
+        s1, t1, a1 = np.zeros(n1, np.int32), np.zeros(n1, np.int32), np.zeros(n1, np.int32)
+        oracle.set_threads(1)
+        t0, k = time.perf_counter(), 0
+        while True:
+            oracle.step(cfg, st1, s1, t1, a1, substeps, omp=True, **kw)
+            k += 1
+            e1 = time.perf_counter() - t0
+            if e1 > single_s or k >= 100000:
+                break
+        oracle.set_threads(cores)
+        out["single_thread"] = {"value": n1 * k / e1, "unit": "env-steps/s", "cores": 1,
+                                "sample": "%d envs x %d env-steps, one thread, %.1f s" % (n1, k, e1)}
+    return out
 
 
 KERNEL_SOURCES = ("basilisk_env_amd/csrc/bsk_kernels.hip", "basilisk_env_amd/csrc/bsk_device.hpp",
@@ -364,10 +381,13 @@ def gather_legs(prop, dist, torch, world, n):
     g = ObsGatherer(prop, dist)
     local = local_obs_tensor(prop)
     host = torch.empty(tuple(local.shape), dtype=local.dtype, pin_memory=True)
-    out = {"shard_bytes": int(local.numel() * 8), "total_bytes": int(local.numel() * 8 * world),
+    shard = int(local.numel() * 8)
+    out = {"shard_bytes": shard, "total_bytes": shard * world,
            "gather_to_rank0_ms": clock(lambda: g.gather(0)),
            "all_gather_ms": clock(g.all_gather),
-           "direct_d2h_per_gpu_ms": clock(lambda: host.copy_(local_obs_tensor(prop), non_blocking=True))}
+           "direct_d2h_per_gpu_ms": clock(lambda: host.copy_(local_obs_tensor(prop), non_blocking=True)),
+           # bytes each leg moves per call: over the fabric into rank 0 / into every rank; over PCIe per GPU
+           "bytes": {"gather_to_rank0": shard * (world - 1), "all_gather": shard * (world - 1) * world, "direct_d2h_per_gpu": shard}}
     full = g.all_gather()
     assert tuple(full.shape) == (world, 5, n)
     out["_clock"] = clock
@@ -375,22 +395,48 @@ def gather_legs(prop, dist, torch, world, n):
 
 
 def direct_rccl_leg(prop, dist, torch, world, clock):
-    """The same gather through librccl directly (basilisk_env_amd/rccl.py): grouped ncclSend / ncclRecv from the library's
-    SoA rows into rank 0's [5][n_total] buffer on the propagator handle's own stream - no torch tensor, no staging copy.
-    Checked against the torch leg on rank 0."""
+    """The same gather through librccl directly (basilisk_env_amd/rccl.py): ONE group of ncclSend / ncclRecv from the library's
+    buffers into rank 0's on the propagator handle's own stream - no torch tensor, no staging copy.  Two forms side by side:
+    the five observation rows alone (what the torch legs move), and the seven rows a trainer on rank 0 needs (+ reward, done
+    reason: SURVEY.md section 8(e)); then the one all-reduce of the path, {sum of rewards, number of done envs} as two doubles
+    from device-side partials.  Checked against the torch leg / the host sums on rank 0."""
     from basilisk_env_amd.parallel import DirectRcclGather, ObsGatherer, concat_shards
-    d = DirectRcclGather(prop, dist, root=0)
-    try:
-        ms = clock(d.enqueue)
-        ref = ObsGatherer(prop, dist).gather(0)
-        ok = None
-        if dist.get_rank() == 0:
-            got = torch.as_tensor(d.result_view(), device="cuda")
-            ok = bool(torch.equal(got, concat_shards(ref)))
-        return {"direct_rccl_gather_to_rank0_ms": ms, "direct_rccl_matches_torch_gather": ok,
-                "direct_rccl_form": "grouped ncclSend/ncclRecv, 5 rows per rank straight into [5][n_total], handle stream"}
-    finally:
-        d.close()
+    out = {}
+    for rows in (5, 7):
+        d = DirectRcclGather(prop, dist, root=0, rows=rows)
+        try:
+            ms = clock(d.enqueue)
+            key = "direct_rccl_gather_to_rank0" if rows == 5 else "direct_rccl_gather7_to_rank0"
+            out[key + "_ms"] = ms
+            out.setdefault("bytes", {})[key] = d.bytes_over_fabric
+            if rows == 5:
+                ref = ObsGatherer(prop, dist).gather(0)
+                if dist.get_rank() == 0:
+                    got = torch.as_tensor(d.result_view(), device="cuda")
+                    out["direct_rccl_matches_torch_gather"] = bool(torch.equal(got, concat_shards(ref)))
+            else:
+                rsum, ndone = prop.batch_stats()
+                p = d.all_reduce_stats()
+                ms2 = clock(d.all_reduce_stats)
+                prop.sync()
+                tot = torch.zeros(2, dtype=torch.float64, device="cuda")
+                import ctypes
+                from basilisk_env_amd import _hip
+                _hip.check(_hip.runtime().hipMemcpyAsync(ctypes.c_void_p(tot.data_ptr()), ctypes.c_void_p(p), 16, _hip.hipMemcpyDeviceToDevice, ctypes.c_void_p(0)), "hipMemcpyAsync")
+                torch.cuda.synchronize()
+                want = torch.tensor([rsum, float(ndone)], dtype=torch.float64, device="cuda")
+                dist.all_reduce(want)
+                out["all_reduce_stats_ms"] = ms2
+                out["all_reduce_stats_matches_host_sums"] = bool(abs(float(tot[0]) - float(want[0])) < 1e-9 * max(1.0, abs(float(want[0]))) and float(tot[1]) == float(want[1]))
+                if dist.get_rank() == 0:
+                    v = d.result_views()
+                    rew = torch.as_tensor(v["reward"], device="cuda")
+                    why = torch.as_tensor(v["reason"], device="cuda")
+                    out["direct_rccl_gather7_shapes"] = [list(rew.shape), list(why.shape)]
+        finally:
+            d.close()
+    out["direct_rccl_form"] = "one group of ncclSend/ncclRecv per gather, rows straight into rank 0's buffers, handle stream; 7 = obs(5) + reward + reason"
+    return out
 
 
 def with_deadline(seconds, on_timeout, fn):
@@ -423,6 +469,8 @@ def profile_key(a, sh):
         return "%s_k%d" % (a.scenario, a.substeps)
     if a.envs == (1 << 22) and a.scenario == "bare" and a.substeps == 1:
         return "4m_k1"
+    if a.envs == 131072 and a.scenario == "bare" and a.substeps == 1:
+        return "131k_k1"
     return None
 
 
@@ -473,29 +521,30 @@ def rl_loop(torch, n, substeps, steps, warmup=10):
         ob = env.reset_tensors()
         g = torch.Generator(device="cuda").manual_seed(0)
         w = torch.randn(5, 3, dtype=torch.float64, device="cuda", generator=g)
-        ret = torch.zeros(n, dtype=torch.float64, device="cuda")
 
         def one(ob):
-            act = (ob.reshape(n, 5) @ w).argmax(dim=1).to(torch.int32)
-            ob2, rew, done, _ = env.step_tensors(act)
-            ret.add_(rew)
-            return ob2
+            act = (ob.reshape(n, 5) @ w).argmax(dim=1)          # int64, read in place by the step kernel; (N,5) is a view
+            ob2, rew, done, info = env.step_tensors(act)        # no torch kernel in here; returns accumulate in the step kernel
+            return ob2, info
 
+        info = None
         for _ in range(warmup):
-            ob = one(ob)
+            ob, info = one(ob)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            ob = one(ob)
+            ob, info = one(ob)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        ret = info["episode_return"]
     d_act = torch.zeros(n, dtype=torch.int32, device="cuda")
     km, _, _ = kernel_time(env.propagator, d_act.data_ptr(), substeps, 16 if substeps > 1 else 64)
     assert bool(torch.isfinite(ret).all())
     env.close()
     return {"env_steps_per_s": n * steps / el, "ms_per_step": el / steps * 1e3, "kernel_ms": km,
             "kernel_env_steps_per_s": n / (km * 1e-3), "loop_over_kernel_rate": (n * steps / el) / (n / (km * 1e-3)),
-            "steps": steps, "policy": "obs(N,5) @ W(5,3) -> argmax -> int32, torch on the env's (non-default) stream",
+            "steps": steps, "torch_kernels_per_step": 2,
+            "policy": "obs(N,5) @ W(5,3) -> argmax (int64, consumed in place), torch on the env's (non-default) stream; episode returns / lengths / done byte kept by the step kernel",
             "env": "LeoPowerAttVecEnv.step_tensors, full reference scenario, J2 + 4 wheels, device IC pool 4096 (Philox), device-side auto-reset"}
 
 
@@ -682,6 +731,23 @@ def main():
         extra["large_n"] = {"envs": nl, "env_steps_per_s": nl * 50 / el3, "roofline": roof3}
         big.close()
         del d_act_big
+        # BASELINE configs[3], the per-GPU half: 131 072 envs per GPU (1 048 576 on 8), config-3 physics, K = 1 - driver-timed on
+        # one card while no 8-GPU node is at hand (the exchange legs need the launcher: `gather`)
+        n3 = 131072
+        p3 = BatchedPropagator(cfg, n3, device=local)
+        p3.reset(sample_ic_batch(n3, n_rw, seed=1000))
+        d_act3 = torch.zeros(n3, dtype=torch.int32, device="cuda")
+        el4 = timed_run(p3, d_act3.data_ptr(), 1, 2000, 100, barrier, sync)
+        km4, nl4, kst4 = kernel_time(p3, d_act3.data_ptr(), 1, 48)
+        tb4, ts4 = pmc_traffic(n3, 1)
+        roof4 = hbm_roofline(n3, km4 * 1e-3, p3.kernel_info(), tb4, ts4, nl4)
+        roof4.update(kst4)
+        settle_roofline(roof4, "131k_k1", km4 * 1e3, el4 / 2000 * 1e6, BYTES_PER_ENV_STEP * n3, HBM_PEAK_GBS, fp)
+        roof4["frac_of_copy_ceiling"] = roof4["achieved"] / HBM_COPY_CEILING_GBS
+        extra["config3_per_gpu"] = {"workload": "BASELINE configs[3], one GPU's share: %d envs, J2 + 4 wheels, K = 1" % n3, "envs": n3,
+                                    "env_steps_per_s": n3 * 2000 / el4, "ms_per_step": el4 / 2000 * 1e3, "roofline": roof4}
+        p3.close()
+        del d_act3
         # what this device sustains on a pure fp64 FMA stream today (its clocks under a dense fp64 load): the rooflines
         # above stay priced on the nominal 78.6 TFLOP/s; this is printed beside them
         try:
@@ -783,14 +849,14 @@ def main():
         if sh:
             out["cpu_baseline"] = cpu_baseline(cfg, n_rw, a.substeps, budget_s=10.0, n=256, sh=70)
         else:
-            out["cpu_baseline"] = cpu_baseline(cfg, n_rw, a.substeps, budget_s=10.0 if default_line else 12.0)
+            out["cpu_baseline"] = cpu_baseline(cfg, n_rw, a.substeps, budget_s=8.0 if default_line else 12.0, single_s=3.0)
         if "k1800" in extra:
             extra["k1800"]["cpu_baseline"] = cpu_baseline(cfg, n_rw, 1800, budget_s=6.0, n=512)
         for sc in ("power", "full"):
             if "%s_k1800" % sc in extra:
                 c2 = cfg.copy()
                 c2.flags |= scenario_flags(sc)
-                extra["%s_k1800" % sc]["cpu_baseline"] = cpu_baseline(c2, n_rw, 1800, budget_s=5.0, n=256)
+                extra["%s_k1800" % sc]["cpu_baseline"] = cpu_baseline(c2, n_rw, 1800, budget_s=4.0, n=256, single_s=2.0 if sc == "full" else 0.0)
         if "sh70" in extra:
             c5 = default_config(n_rw=n_rw, gravity_model=GRAV_SH)
             c5.sh_degree = 70
@@ -802,9 +868,11 @@ def main():
             out["gather"]["direct_rccl"] = "timeout after 90 s: leg abandoned"
             if rank == 0:
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(3)      # the line is out, but a collective deadlocked: the launcher must see a failure (never a re-exec)
         try:
-            out["gather"].update(with_deadline(90.0, give_up, lambda: direct_rccl_leg(prop, dist, torch, world, clock)))
+            leg = with_deadline(90.0, give_up, lambda: direct_rccl_leg(prop, dist, torch, world, clock))
+            out["gather"].setdefault("bytes", {}).update(leg.pop("bytes", {}))
+            out["gather"].update(leg)
         except Exception as e:
             out["gather"]["direct_rccl_error"] = repr(e)
     prop.close()

@@ -48,7 +48,13 @@ enum { BSK_GRAV_PM = 0, BSK_GRAV_PM_J2 = 1, BSK_GRAV_SH = 2 };
 #define BSK_FLAG_DESAT 0x4u          /* action 2 fires the thruster octet (…Simulator.py:574-588) */
 #define BSK_FLAG_DRAG 0x8u           /* exponential atmosphere + facet drag (…Simulator.py:265-284) */
 #define BSK_FLAG_AUTO_RESET 0x10u    /* device-side masked auto-reset from a staged IC pool */
-#define BSK_FLAG_LDS_SCRATCH 0x20u   /* bare propagator only: stage the RK4 accumulator (15 doubles per spacecraft) in
+#define BSK_FLAG_EPISODE_STATS 0x40u /* device-resident episode statistics (the Monitor convention of envs/leoPowerAttitudeEnvironment.py:130-135
+                                        without the host): running return per env, return / length of the episode that just ended,
+                                        a 0 / 1 done byte; bsk_get_episode_device.  16 B more HBM traffic per env-step */
+#define BSK_FLAG_OBS_ROWMAJOR 0x80u  /* the step kernel also writes the observation row-major, f64[n_envs][5] (what the reference's
+                                        (5,1) observation stacks to, envs/leoPowerAttitudeEnvironment.py:43-45): a policy on the GPU
+                                        reshapes it without a copy kernel.  40 B more per env-step */
+#define BSK_FLAG_LDS_SCRATCH 0x20u   /* bare propagator only: stage the RK4 accumulator (12 doubles per spacecraft) in
                                         LDS between the stages instead of VGPRs: 3 waves per SIMD instead of 2.
                                         Same results bit for bit; timings in DESIGN.md §4 */
 
@@ -194,6 +200,9 @@ int bsk_reset(bsk_handle* h, const uint8_t* mask, const double* ic);
 int bsk_step(bsk_handle* h, const int32_t* actions, int substeps);
 /* Same, actions already resident in device memory (no PCIe traffic on the step path). */
 int bsk_step_device(bsk_handle* h, const int32_t* d_actions, int substeps);
+/* Same, actions as int64 in device memory (what torch's argmax returns: no conversion kernel between policy and step);
+ * the kernel reads the low word of each little-endian element. */
+int bsk_step_device_i64(bsk_handle* h, const int64_t* d_actions, int substeps);
 
 /* Host copies of the last step's outputs (synchronises the stream).  Any pointer may be NULL.
  * obs: f64[5][n_envs] = [|sigma_BR|, |omega_BN_B|, |Omega|/wheel_limit, charge/3600/power_max,
@@ -221,6 +230,17 @@ int bsk_get_obs_device(bsk_handle* h, double** d_obs, double** d_reward, uint64_
  * bsk_get_terminal_obs_device: device pointers of the terminal observations f64[5][stride] and the per-env
  * finished-episode counts int32[stride] of the device-side auto-reset (NULL until a pool is staged).
  * bsk_get_state_device: the state slab f64[n_fields][stride] itself (read-only for the caller between steps). */
+/* bsk_get_episode_device (BSK_FLAG_EPISODE_STATS / BSK_FLAG_OBS_ROWMAJOR; pointers are NULL where the flag is off):
+ *   ep_return   f64[stride]  return of the running episode, this step's reward included; 0 where a device-side reset fired
+ *   term_return f64[stride], term_len int32[stride]: 'r' and 'l' of info['episode'] for the envs whose done byte is set at this
+ *               step ('l' = env steps taken before this one, as the reference counts: ...Environment.py:133)
+ *   done        u8[stride]   0 / 1 (a torch.bool view needs no kernel)
+ *   obs_rowmajor f64[n_envs][5]
+ * Every reset entry point (bsk_reset, bsk_reset_from_pool*, the step kernel's own auto-reset) leaves the NEW episode's first
+ * observation [|sigma_BN|, |omega|, |Omega|/limit, charge/3600/power_max, 1] in the observation buffers and zero in reward, reason,
+ * done and ep_return of the envs it restarts, so that a device-resident loop never has to compute or upload a reset observation. */
+int bsk_get_episode_device(bsk_handle* h, double** d_ep_return, double** d_term_return, int32_t** d_term_len, uint8_t** d_done,
+                           double** d_obs_rowmajor);
 int bsk_get_stream(bsk_handle* h, void** stream);
 int bsk_get_terminal_obs_device(bsk_handle* h, double** d_term_obs, int32_t** d_episodes);
 int bsk_get_state_device(bsk_handle* h, double** d_state, int64_t* stride);
@@ -228,6 +248,9 @@ int bsk_get_state_device(bsk_handle* h, double** d_state, int64_t* stride);
 /* Batch scalars produced with wavefront reductions: sum of rewards and number of done envs
  * of the last step (synchronises). */
 int bsk_get_batch_stats(bsk_handle* h, double* reward_sum, int64_t* n_done);
+/* The same two scalars left ON the device as f64[2] = {sum of rewards, number of done envs}, enqueued on the handle's stream
+ * without synchronising: the operand of the one all-reduce a sharded batch needs. */
+int bsk_get_batch_stats_device(bsk_handle* h, double** d_stats2);
 
 /* Full state read-back / injection, host SoA [n_fields][n_envs] (parity tests, reset_init). */
 int bsk_n_fields(const bsk_handle* h);
@@ -256,6 +279,8 @@ int bsk_set_ic_pool(bsk_handle* h, int n_pool, const double* ic_pool);
  * or the masked envs from the pool with the slot rule above, without any host data. */
 int bsk_sample_ic_pool(bsk_handle* h, int n_pool, uint64_t seed);
 int bsk_reset_from_pool(bsk_handle* h, const uint8_t* mask);
+/* Same with the mask (or NULL) in DEVICE memory, asynchronous on the handle's stream: no host data, no copy, no synchronisation. */
+int bsk_reset_from_pool_device(bsk_handle* h, const uint8_t* d_mask);
 /* Host copy of the staged pool, SoA [n_fields][n_pool] (n_pool as staged; the caller sizes the buffer):
  * lets the host replay a device-side reset (reset_init, leoPowerAttitudeEnvironment.py:202-216). */
 int bsk_get_ic_pool(bsk_handle* h, double* ic_pool);
@@ -272,7 +297,17 @@ int bsk_set_env_base(bsk_handle* h, int64_t env_base);
  * sun_r0 + sun_v * t is evaluated at the start of an env step (default 0). */
 int bsk_set_sim_time(bsk_handle* h, double t_seconds);
 
+/* Synchronises the handle's stream.  Like every synchronising entry point (bsk_get_obs*, bsk_get_state, bsk_get_batch_stats,
+ * bsk_get_terminal_obs) it then checks the handle's device error word and returns BSK_EHIP when a kernel raised it: the
+ * three-wave form's barrier-free exchange gives up after 2^20 polls instead of hanging, and says so here. */
 int bsk_sync(bsk_handle* h);
+
+/* Process-wide counts of the host <-> device copies and stream synchronisations this library has issued (tests assert that the
+ * device-resident entry points issue none).  Either pointer may be NULL. */
+int bsk_debug_counters(int64_t* n_copies, int64_t* n_syncs);
+/* Probe builds only (csrc/bsk_probes.hpp; all zeros from the product library): the word every wavefront of the last launch left
+ * in the handle's debug buffer, uint64[ceil(n_envs / 64)].  Synchronises. */
+int bsk_debug_words(bsk_handle* h, uint64_t* words);
 
 /* Per-launch timing of the step kernel with hipEvents recorded on the handle's stream around
  * each launch.  begin() arms it (capacity launches); end() synchronises and reports the mean

@@ -41,7 +41,8 @@ def test_step_tensors_is_bit_identical_to_host_path(n, own_stream):
     host, dev = _twin_envs(n, own_stream)
     ob_h = host.reset()
     ob_d = dev.reset_tensors()
-    assert ob_d.is_cuda and tuple(ob_d.shape) == (n, 5, 1) and np.array_equal(ob_d.cpu().numpy(), ob_h)
+    # (the host path computes the reset observation with numpy, the device path reads the reset kernel's own: one ulp apart at most)
+    assert ob_d.is_cuda and tuple(ob_d.shape) == (n, 5, 1) and np.allclose(ob_d.cpu().numpy(), ob_h, rtol=4e-16, atol=0)
     rng = np.random.default_rng(3)
     n_done = 0
     for step in range(8):
@@ -75,13 +76,112 @@ def test_step_tensors_argument_checks():
     env.close()
     env = LeoPowerAttVecEnv(64, n_rw=3, gravity_model=GRAV_PM, step_duration=1.0, power=False, auto_reset=False)
     env.reset()
-    for bad in (torch.zeros(64, dtype=torch.int64, device="cuda"), torch.zeros(63, dtype=torch.int32, device="cuda"),
-                torch.zeros(64, dtype=torch.int32), np.zeros(64, np.int32)):
+    for bad in (torch.zeros(64, dtype=torch.int16, device="cuda"), torch.zeros(63, dtype=torch.int32, device="cuda"),
+                torch.zeros(64, dtype=torch.int32), np.zeros(64, np.int32), torch.zeros(128, dtype=torch.int64, device="cuda")[::2]):
         with pytest.raises(ValueError):
             env.step_tensors(bad)
     ob, rew, done, info = env.step_tensors(torch.ones(64, dtype=torch.int32, device="cuda"))
     assert "terminal_observation" not in info and not bool(done.any())
     env.close()
+
+
+@pytest.mark.parametrize("n", [64, 200])
+def test_device_episode_statistics_equal_the_host_paths(n):
+    """Row f4's bookkeeping on the device: info['episode'] = {'r', 'l'} of the host path (the Monitor convention of the
+    reference, envs/leoPowerAttitudeEnvironment.py:130-135) against the kernel's term_return / term_len, and the running
+    returns, bit for bit through more than n device-side resets; int32 and int64 action tensors alternate."""
+    import torch
+    host, dev = _twin_envs(n, own_stream=False)
+    host.reset()
+    dev.reset_tensors()
+    rng = np.random.default_rng(11)
+    n_done = 0
+    for step in range(9):
+        a = rng.integers(0, 3, n)
+        oh, rh, dh, ih = host.step(a)
+        at = torch.as_tensor(a.astype(np.int64 if step % 2 else np.int32), device="cuda")
+        od, rd, dd, info = dev.step_tensors(at)
+        assert np.array_equal(rd.cpu().numpy(), rh) and np.array_equal(dd.cpu().numpy(), dh)
+        er, el = info["episode_r"].cpu().numpy(), info["episode_l"].cpu().numpy()
+        for i in np.flatnonzero(dh):
+            assert er[i] == ih[i]["episode"]["r"] and int(el[i]) == ih[i]["episode"]["l"]
+        assert np.array_equal(info["episode_return"].cpu().numpy(), host.episode_returns)
+        n_done += int(dh.sum())
+    assert n_done >= n
+    host.close()
+    dev.close()
+
+
+def test_step_tensors_outputs_are_the_kernels_own_buffers():
+    """step_tensors launches no torch kernel of its own: observation = the row-major buffer the kernel writes (contiguous, a
+    policy's reshape is a view), done = a bool view of the kernel's 0 / 1 byte, everything aliases library memory."""
+    import torch
+    n = 300
+    host, dev = _twin_envs(n, own_stream=False)
+    dev.reset_tensors()
+    v = dev.propagator.device_views()
+    ptr = lambda k: v[k].__cuda_array_interface__["data"][0]
+    od, rd, dd, info = dev.step_tensors(torch.zeros(n, dtype=torch.int64, device="cuda"))
+    assert od.is_contiguous() and od.data_ptr() == ptr("obs_rowmajor") and od.reshape(n, 5).data_ptr() == od.data_ptr()
+    assert dd.dtype == torch.bool and dd.data_ptr() == ptr("done") and rd.data_ptr() == ptr("reward")
+    assert info["episode_r"].data_ptr() == ptr("terminal_return") and info["episode_l"].dtype == torch.int32
+    soa = torch.as_tensor(v["obs"], device="cuda")
+    assert torch.equal(od.reshape(n, 5), soa.t())           # the two layouts hold the same numbers
+    assert torch.equal(dd, info["reason"].ne(0))
+    host.close()
+    dev.close()
+
+
+def test_reset_tensors_and_the_loop_move_nothing_over_pcie():
+    """With the pool drawn on the GPU, reset_tensors + step_tensors issue NO host <-> device copy and NO stream
+    synchronisation (the library counts its own: bsk_debug_counters), and the reset observation is the reset kernel's
+    own output - equal to what the host path computes from the same pool."""
+    import torch
+    n = 500
+    kw = dict(n_rw=4, step_duration=1.0, seed=5, device_reset_pool=64, device_sampler=True)
+    env = LeoPowerAttVecEnv(n, stream=torch.cuda.current_stream().cuda_stream, **kw)
+    twin = LeoPowerAttVecEnv(n, **kw)
+    ob_host = twin.reset()
+    torch.cuda.synchronize()
+    c0 = BatchedPropagator.debug_counters()
+    ob = env.reset_tensors()
+    for _ in range(5):
+        ob, rew, done, info = env.step_tensors((ob.reshape(n, 5)[:, :3]).argmax(dim=1))      # int64 actions, in place
+    c1 = BatchedPropagator.debug_counters()
+    assert c1 == c0, (c0, c1)
+    ob0 = env.reset_tensors()
+    assert ob0.data_ptr() == env._torch_views()["obs_rowmajor"].data_ptr()
+    torch.cuda.synchronize()
+    # second device-side reset of `env` = second episode's pool slots; the twin's first reset used the first ones: replay
+    env2 = LeoPowerAttVecEnv(n, stream=torch.cuda.current_stream().cuda_stream, **kw)
+    assert np.allclose(env2.reset_tensors().cpu().numpy(), ob_host, rtol=4e-16, atol=0)
+    assert np.array_equal(env2.reset_init(), ob_host)                   # the IC mirror is rebuilt from the slot rule
+    for e in (env, twin, env2):
+        e.close()
+
+
+def test_host_resets_leave_the_first_observation_in_the_device_buffers():
+    """bsk_reset (all / masked) writes the new episode's first observation and zeroes reward / reason for the envs it restarts."""
+    n = 150
+    cfg = default_config(4, GRAV_PM_J2)
+    p = BatchedPropagator(cfg, n)
+    ic = sample_ic_batch(n, 4, seed=3)
+    p.reset(ic)
+    env = LeoPowerAttVecEnv.__new__(LeoPowerAttVecEnv)
+    env.n_rw, env.wheel_limit, env.power_max = 4, cfg.wheel_limit, cfg.power_max
+    want = env._initial_obs(ic)
+    obs, rew, done, why = p.get_obs()
+    assert np.allclose(obs, want, rtol=1e-15, atol=0) and not rew.any() and not why.any()
+    p.step(np.zeros(n, np.int32), 4)
+    stepped = p.get_obs()[0]
+    mask = (np.arange(n) % 4 == 1).astype(np.uint8)
+    ic2 = sample_ic_batch(n, 4, seed=4)
+    p.reset(ic2, mask)
+    obs2, rew2, _, _ = p.get_obs()
+    m = mask.astype(bool)
+    assert np.allclose(obs2[:, m], env._initial_obs(ic2)[:, m], rtol=1e-15, atol=0) and np.array_equal(obs2[:, ~m], stepped[:, ~m])
+    assert not rew2[m].any() and rew2[~m].any()
+    p.close()
 
 
 def test_on_device_policy_loop_runs_without_host_sync():

@@ -159,3 +159,49 @@ def test_three_wave_form_with_device_side_reset_and_default_selection():
     big.step(np.zeros(16384 + 64, np.int32), 20)
     assert "tri" not in big.kernel_info()["name"]
     big.close()
+
+
+def test_exchange_timeout_raises_the_handles_error_word():
+    """The barrier-free exchange gives up after 2^20 polls instead of hanging - and must SAY so: a probe library whose
+    translational wave never publishes (csrc/bsk_probes.hpp: BSK_PROBE_TRI_NOPUBLISH, built by `make probes` /
+    __graft_entry__.build()) makes the next synchronising call fail with BSK_EHIP and a message, not hand NaN observations
+    to the caller as if nothing had happened.  Run in a child process: the library of this process is the product's."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "basilisk_env_amd", "variants", "probe_tri_nopublish.so")
+    if not os.path.exists(lib):
+        pytest.skip("probe library not built (make -C basilisk_env_amd/csrc probes)")
+    script = r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from basilisk_env_amd._lib import BskError, FLAG_DESAT, FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY, GRAV_PM_J2
+from basilisk_env_amd.simulators.dynamics import BatchedPropagator, default_config
+from basilisk_env_amd.simulators.initial_conditions.batch import sample_ic_batch
+cfg = default_config(4, GRAV_PM_J2)
+cfg.flags |= FLAG_POWER | FLAG_SUN_THIRD_BODY | FLAG_DRAG | FLAG_DESAT
+p = BatchedPropagator(cfg, 64)
+p.reset(sample_ic_batch(64, 4, seed=1))
+p.step(np.zeros(64, np.int32), 20)
+assert "tri" in p.kernel_info()["name"]
+try:
+    p.get_obs()
+    print("NO ERROR")
+except BskError as e:
+    print("CODE", e.code, "three-wave" in str(e))
+p.sync()                       # the word is cleared once reported
+print("SYNC OK")
+try:
+    p.step(np.zeros(64, np.int32), 20)
+    p.sync()
+    print("NO ERROR")
+except BskError as e:
+    print("CODE", e.code)
+p.close()
+''' % root
+    r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, BSKGPU_LIB=lib, BSKGPU_TRI="1", BSKGPU_PAIR="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = r.stdout.split("\n")
+    assert out[0] == "CODE -4 True" and out[1] == "SYNC OK" and out[2] == "CODE -4", r.stdout

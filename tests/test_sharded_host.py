@@ -93,50 +93,115 @@ def test_too_few_envs_or_no_devices():
         ShardedPropagator(cfg, 4, devices=[], propagator_factory=OraclePropagator)
 
 
+class _FakeHip(object):
+    """Stands in for the few _hip calls the multi-GPU host layer makes: records the current device and the copies."""
+
+    def __init__(self, monkeypatch, _hip, start_device=5):
+        self.dev, self.sets, self.copies = start_device, [], []
+        monkeypatch.setattr(_hip, "current_device", lambda: self.dev)
+        monkeypatch.setattr(_hip, "set_device", self._set)
+        monkeypatch.setattr(_hip, "memcpy2d_async", lambda *a: self.copies.append((self.dev,) + a))
+
+    def _set(self, d):
+        self.dev = int(d)
+        self.sets.append(int(d))
+
+
 def test_direct_gather_address_arithmetic(monkeypatch):
-    """rccl.enqueue_gather_rows / copy_own_rows post exactly the messages that land shard r's row f at
-    out[f][offset_r : offset_r + n_r]: played back against numpy buffers with a fake librccl."""
+    """rccl.enqueue_gather / copy_own post exactly the messages that land shard r's rows at out[f][offset_r : offset_r + n_r]
+    of every buffer - observations (5 rows, padded pitch), rewards (1 row), done reasons (1 row of uint8): the seven-row
+    group of SURVEY.md section 8(e) - played back against numpy buffers with a fake librccl."""
+    import ctypes
+
     from basilisk_env_amd import _hip, rccl
 
-    sizes, rows = [3, 4, 2], 5
+    sizes = [3, 4, 2]
     n_total = sum(sizes)
-    shards = [np.arange(rows * 8, dtype=np.float64).reshape(rows, 8) + 100 * r for r in range(3)]   # pitch 8 > n_r
-    out = np.zeros((rows, n_total))
+    obs = [np.arange(5 * 8, dtype=np.float64).reshape(5, 8) + 100 * r for r in range(3)]      # pitch 8 > n_r
+    rew = [np.arange(8, dtype=np.float64) * 0.5 + 10 * r for r in range(3)]
+    why = [(np.arange(8) + 3 * r).astype(np.uint8) for r in range(3)]
+    out_obs, out_rew, out_why = np.zeros((5, n_total)), np.zeros(n_total), np.zeros(n_total, np.uint8)
     sends, recvs = {}, []
 
     class FakeLib(object):
         def ncclSend(self, ptr, count, dtype, peer, comm, stream):
-            sends.setdefault((comm.value, peer), []).append((ptr.value, count))
+            sends.setdefault((comm.value, peer), []).append((ptr.value, count, dtype))
             return 0
 
         def ncclRecv(self, ptr, count, dtype, peer, comm, stream):
-            recvs.append((ptr.value, count, peer))
+            recvs.append((ptr.value, count, dtype, peer))
             return 0
 
     monkeypatch.setattr(rccl, "load", lambda: FakeLib())
-    copies = []
-    monkeypatch.setattr(_hip, "set_device", lambda d: None)
-    monkeypatch.setattr(_hip, "memcpy2d_async", lambda *a: copies.append(a))
+    hip = _FakeHip(monkeypatch, _hip)
     root = 1
     for r in range(3):
         comm = rccl.Comm(1000 + r, r, 3, r)
-        rccl.enqueue_gather_rows(comm, 7, root, sizes, shards[r].ctypes.data, 8 * 8, rows, out.ctypes.data)
-        rccl.copy_own_rows(comm, 7, root, sizes, shards[r].ctypes.data, 8 * 8, rows, out.ctypes.data)
-    # play the messages: the k-th recv from peer p pairs with the k-th send of p to the root
-    import ctypes
+        bufs = rccl.step_output_bufs(obs[r].ctypes.data, 8 * 8, rew[r].ctypes.data, why[r].ctypes.data,
+                                     out_obs.ctypes.data, out_rew.ctypes.data, out_why.ctypes.data)
+        assert [b.rows for b in bufs] == [5, 1, 1] and rccl.gather_bytes(sizes, bufs, root) == (3 + 2) * 49
+        rccl.enqueue_gather(comm, 7, root, sizes, bufs)
+        rccl.copy_own(comm, 7, root, sizes, bufs)
+    # play the messages: the k-th recv from peer p pairs with the k-th send of p to the root (types and counts agree)
     taken = {}
-    for ptr, count, peer in recvs:
+    for ptr, count, dtype, peer in recvs:
         k = taken.get(peer, 0)
-        sptr, scount = sends[(1000 + peer, root)][k]
+        sptr, scount, sdtype = sends[(1000 + peer, root)][k]
         taken[peer] = k + 1
-        assert scount == count == sizes[peer]
-        ctypes.memmove(ptr, sptr, count * 8)
-    assert len(copies) == 1
-    dst, dpitch, src, spitch, width, height, kind, stream = copies[0]
-    for f in range(height):
-        ctypes.memmove(dst + f * dpitch, src + f * spitch, width)
-    want = np.concatenate([s[:, :n] for s, n in zip(shards, sizes)], axis=1)
-    assert np.array_equal(out, want) and kind == _hip.hipMemcpyDeviceToDevice
+        assert scount == count == sizes[peer] and sdtype == dtype
+        ctypes.memmove(ptr, sptr, count * (1 if dtype == rccl.ncclUint8 else 8))
+    assert all(taken[p] == len(sends[(1000 + p, root)]) == 7 for p in (0, 2))       # seven rows per rank, one group
+    assert len(hip.copies) == 3                                                      # the root's own shard, one copy per buffer
+    for dev, dst, dpitch, src, spitch, width, height, kind, stream in hip.copies:
+        assert dev == root and kind == _hip.hipMemcpyDeviceToDevice                 # issued with the root's device current
+        for f in range(height):
+            ctypes.memmove(dst + f * dpitch, src + f * spitch, width)
+    assert hip.dev == 5 and hip.sets == [root, 5]                                    # ... and the caller's device restored
+    assert np.array_equal(out_obs, np.concatenate([s_[:, :n] for s_, n in zip(obs, sizes)], axis=1))
+    assert np.array_equal(out_rew, np.concatenate([s_[:n] for s_, n in zip(rew, sizes)]))
+    assert np.array_equal(out_why, np.concatenate([s_[:n] for s_, n in zip(why, sizes)]))
+    # the single-buffer wrappers (observations only) post the first five rows of the same pattern
+    sends.clear(); recvs.clear()
+    rccl.enqueue_gather_rows(rccl.Comm(1000, 0, 3, 0), 7, root, sizes, obs[0].ctypes.data, 64, 5, out_obs.ctypes.data)
+    assert len(sends[(1000, root)]) == 5 and not recvs
+
+
+def test_python_hip_calls_leave_the_current_device_alone(monkeypatch):
+    """the ctypes HIP layer must not change the calling thread's current device behind a torch policy's back.
+    device_guard restores it; DeviceBuffer, Comm.init_rank and the sharded read-back / own-shard copies all go through it."""
+    from basilisk_env_amd import _hip, rccl
+
+    hip = _FakeHip(monkeypatch, _hip, start_device=2)
+    with _hip.device_guard(2):
+        assert hip.dev == 2
+    assert hip.sets == []                                   # already current: no call at all
+    with pytest.raises(RuntimeError):
+        with _hip.device_guard(6):
+            assert hip.dev == 6
+            raise RuntimeError("boom")
+    assert hip.dev == 2 and hip.sets == [6, 2]              # restored on the error path too
+
+    class RT(object):
+        def hipMalloc(self, pp, n):
+            assert hip.dev == 4
+            return 0
+
+        def hipFree(self, p):
+            return 0
+
+    monkeypatch.setattr(_hip, "runtime", lambda: RT())
+    buf = _hip.DeviceBuffer(64, 4)
+    assert hip.dev == 2 and buf.device == 4
+    buf.ptr = None
+
+    class Lib(object):
+        def ncclCommInitRank(self, ph, world, uid, rank):
+            assert hip.dev == 3
+            return 0
+
+    monkeypatch.setattr(rccl, "load", lambda: Lib())
+    c = rccl.Comm.init_rank(2, 1, b"\0" * 128, 3)
+    assert hip.dev == 2 and c.device == 3
 
 
 def test_dlpack_capsule_roundtrip_on_host_memory():

@@ -9,7 +9,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 cfg = default_config(4, GRAV_PM_J2); cfg.flags |= FLAG_POWER | FLAG_SUN_THIRD_BODY | FLAG_DRAG | FLAG_DESAT
 p = BatchedPropagator(cfg, n); p.reset(sample_ic_batch(n, 4, seed=0))
 p.step(np.zeros(n, np.int32), 200); p.sync()
-m = torch.as_tensor(p.device_views()["done_mask"], device="cuda").cpu().numpy().astype(np.uint64)
+m = p.debug_words()
 d, f = (m & np.uint64(0xFFFFFFFF)).astype(np.int64), (m >> np.uint64(32)).astype(np.int64)
 def key(h): return ((h >> 16) & 15, (h >> 13) & 7, (h >> 12) & 1, (h >> 8) & 15, (h >> 4) & 3)   # xcc, se, sh, cu, simd
 occ = collections.defaultdict(list)

@@ -10,7 +10,7 @@ cfg = default_config(4, GRAV_PM_J2); cfg.flags |= FLAG_POWER | FLAG_SUN_THIRD_BO
 p = BatchedPropagator(cfg, n); p.reset(sample_ic_batch(n, 4, seed=0))
 for _ in range(3):
     p.step(np.zeros(n, np.int32), 600); p.sync()
-m = torch.as_tensor(p.device_views()["done_mask"], device="cuda").cpu().numpy().astype(np.uint64)
+m = p.debug_words()
 dur, hid = (m & np.uint64(0xFFFFFFFF)).astype(np.int64), (m >> np.uint64(32)).astype(np.int64)
 print("envs", n, "D-wave durations [kcycles] percentiles 0/25/50/75/90/100:", np.percentile(dur, [0, 25, 50, 75, 90, 100]).astype(int))
 simd, cu, xcc, se = (hid >> 4) & 3, (hid >> 8) & 15, (hid >> 16) & 15, (hid >> 13) & 7

@@ -11,6 +11,6 @@ cfg = default_config(4, GRAV_PM_J2); cfg.flags |= FLAG_POWER | FLAG_SUN_THIRD_BO
 p = BatchedPropagator(cfg, n); p.reset(sample_ic_batch(n, 4, seed=0))
 for _ in range(3):
     p.step(np.zeros(n, np.int32), K); p.sync()
-m = torch.as_tensor(p.device_views()["done_mask"], device="cuda").cpu().numpy().astype(np.uint64)
+m = p.debug_words()
 wb = (m & np.uint64(0x1FFFFF)).astype(np.float64) * 16; wa = ((m >> np.uint64(21)) & np.uint64(0x1FFFFF)).astype(np.float64) * 16; ch = ((m >> np.uint64(42)) & np.uint64(0x1FFFFF)).astype(np.float64) * 16
 print("envs", n, "per launch of", K, "ticks, mean / max over waves [kcycles]: D waits at B %.0f / %.0f, at A %.0f / %.0f; F chain total %.0f / %.0f" % (wb.mean() / 1e3, wb.max() / 1e3, wa.mean() / 1e3, wa.max() / 1e3, ch.mean() / 1e3, ch.max() / 1e3))

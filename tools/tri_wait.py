@@ -18,6 +18,6 @@ for _ in range(3):
     p.step(np.zeros(n, np.int32), K); p.sync()
     wall = time.perf_counter() - t0
 print("wall of the last launch %.3f ms (%.0f ns per tick)" % (wall * 1e3, wall / K * 1e9))
-arr = torch.as_tensor(p.device_views()["done_mask"], device="cuda").cpu().numpy().astype(np.uint64)
+arr = p.debug_words()
 miss, spin, cyc = (arr & np.uint64(0xFFFF)).astype(float), ((arr >> np.uint64(16)) & np.uint64(0xFFFF)).astype(float), (arr >> np.uint64(32)).astype(float) * 64
 print("%-14s envs %d K %d: consumes early %.0f (of %d), re-reads %.0f, kcycles re-reading %.0f (mean over waves; max %.0f)" % (sys.argv[3] if len(sys.argv) > 3 else "", n, K, miss.mean(), 4 * K, spin.mean(), cyc.mean() / 1e3, cyc.max() / 1e3))
