@@ -430,6 +430,9 @@ struct bsk_handle {
     double* d_stats2 = nullptr;   // {sum of rewards, number of done envs} of the last step, as two doubles (all-reduce operand)
     // error word the kernels can raise (page-locked host memory, device-visible): checked by every synchronising entry point
     int* h_err = nullptr;
+    // bare levels: no spacecraft of the batch / of the reset pool started its episode with an empty battery (bsk_launch.hpp:
+    // StepArgs::static_charge).  Known after a reset of the whole batch; withdrawn by bsk_set_state until the next one.
+    bool charge_pos = false, pool_charge_pos = false;
     // pair form of the step kernel (bsk_device.hpp: PairLds): used for launches of >= pair_min_substeps sub-steps of batches
     // of <= pair_max_envs spacecraft where it is built (power / full-scenario levels, point mass or J2, diagonal hub).  Measured
     // (profiles/r03/pair_form.txt): -13 % per env step up to one pair per CU (16 384 spacecraft), level with the single-wave
@@ -532,6 +535,7 @@ int do_step(bsk_handle* h, const void* d_actions, int substeps, int act_shift) {
     b.cnt = h->d_cnt;
     b.act = (const int*)d_actions;
     b.act_shift = act_shift;
+    b.static_charge = (h->sp.feat == bsk::FEAT_BARE || h->sp.feat == bsk::FEAT_LDSS) && h->charge_pos && (h->n_pool == 0 || h->pool_charge_pos) ? 1 : 0;
     b.ep_return = h->d_ep_return; b.term_return = h->d_term_return; b.term_len = h->d_term_len; b.done = h->d_done;
     b.obs_rm = h->d_obs_rm; b.err = h->h_err; b.dbg = h->d_dbg;
     b.obs = h->d_obs;
@@ -846,7 +850,10 @@ int bsk_reset(bsk_handle* h, const uint8_t* mask, const double* ic) {
     if (!h || !ic) return fail(BSK_EINVAL, "handle/ic is NULL");
     DeviceGuard guard(h->device);
     const size_t row = (size_t)h->n * sizeof(double);
+    const double* ic_charge = ic + (size_t)(BSK_NF_BASE + h->cfg.n_rw + BSK_T_CHARGE) * h->n;
     if (!mask) {
+        h->charge_pos = true;
+        for (int i = 0; i < h->n; ++i) h->charge_pos = h->charge_pos && ic_charge[i] > 0.0;
         HIP_COPY(hipMemcpy2DAsync(h->d_state, (size_t)h->stride * sizeof(double), ic, row, row, h->nf,
                                  hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipMemsetAsync(h->d_cnt, 0, (size_t)h->stride * sizeof(int2), h->stream));
@@ -856,7 +863,7 @@ int bsk_reset(bsk_handle* h, const uint8_t* mask, const double* ic) {
     }
     std::vector<int> idx;
     for (int i = 0; i < h->n; ++i)
-        if (mask[i]) idx.push_back(i);
+        if (mask[i]) { idx.push_back(i); h->charge_pos = h->charge_pos && ic_charge[i] > 0.0; }
     const size_t m = idx.size();
     if (m == 0) return BSK_OK;
     std::vector<double> compact(m * h->nf);
@@ -981,6 +988,7 @@ int bsk_get_state(bsk_handle* h, double* state) {
 int bsk_set_state(bsk_handle* h, const double* state) {
     if (!h || !state) return fail(BSK_EINVAL, "handle/state is NULL");
     DeviceGuard guard(h->device);
+    h->charge_pos = false;       // (the observation buffers no longer describe this state: the kernel reads the charge again)
     const size_t row = (size_t)h->n * sizeof(double);
     HIP_COPY(hipMemcpy2DAsync(h->d_state, (size_t)h->stride * sizeof(double), state, row, row, h->nf, hipMemcpyHostToDevice, h->stream));
     HIP_SYNC(hipStreamSynchronize(h->stream));
@@ -1024,6 +1032,8 @@ int bsk_set_ic_pool(bsk_handle* h, int n_pool, const double* ic_pool) {
     if (rc) return rc;
     HIP_COPY(hipMemcpy(h->d_pool, ic_pool, (size_t)h->nf * n_pool * sizeof(double), hipMemcpyHostToDevice));
     h->n_pool = n_pool;
+    h->pool_charge_pos = true;
+    for (int k = 0; k < n_pool; ++k) h->pool_charge_pos = h->pool_charge_pos && ic_pool[(size_t)(BSK_NF_BASE + h->cfg.n_rw + BSK_T_CHARGE) * n_pool + k] > 0.0;
     return BSK_OK;
 }
 
@@ -1053,6 +1063,7 @@ int bsk_sample_ic_pool(bsk_handle* h, int n_pool, uint64_t seed) {
     HIP_TRY(bsk::launch_sample_pool(h->d_pool, n_pool, h->cfg.n_rw, (unsigned long long)seed, h->cfg.mu, h->stream));
     HIP_SYNC(hipStreamSynchronize(h->stream));
     h->n_pool = n_pool;
+    h->pool_charge_pos = true;       // the sampler draws U(8, 20) W h
     return BSK_OK;
 }
 
@@ -1068,6 +1079,7 @@ int bsk_reset_from_pool(bsk_handle* h, const uint8_t* mask) {
     }
     HIP_TRY(bsk::launch_reset_from_pool(h->d_state, h->stride, h->nf, h->d_pool, h->n_pool, d_mask, h->n, h->d_cnt,
                                         h->d_episodes, h->env_base, reset_out(h), h->stream));
+    h->charge_pos = (mask ? h->charge_pos : true) && h->pool_charge_pos;
     HIP_SYNC(hipStreamSynchronize(h->stream));
     return BSK_OK;
 }
@@ -1078,6 +1090,7 @@ int bsk_reset_from_pool_device(bsk_handle* h, const uint8_t* d_mask) {
     DeviceGuard guard(h->device);
     HIP_TRY(bsk::launch_reset_from_pool(h->d_state, h->stride, h->nf, h->d_pool, h->n_pool, d_mask, h->n, h->d_cnt,
                                         h->d_episodes, h->env_base, reset_out(h), h->stream));
+    h->charge_pos = (d_mask ? h->charge_pos : true) && h->pool_charge_pos;
     return BSK_OK;       // asynchronous on the handle's stream: no host data, no copy, no synchronisation
 }
 

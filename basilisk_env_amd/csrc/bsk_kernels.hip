@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
     constexpr int TAIL = BSK_NF_BASE + NRW;
     const V3 lext = mk(ldf(FLD(TAIL + BSK_T_LEXT + 0), bo), ldf(FLD(TAIL + BSK_T_LEXT + 1), bo),
                        ldf(FLD(TAIL + BSK_T_LEXT + 2), bo));
-    double charge = ldf(FLD(TAIL + BSK_T_CHARGE), bo);
+    double charge = 1.0;     // (bare levels with StepArgs::static_charge: never read - any non-zero value)
+    if (FEAT >= FEAT_POWER || BSK_UNLIKELY(a.static_charge == 0)) charge = ldf(FLD(TAIL + BSK_T_CHARGE), bo);
     const int2 cnt = *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(a.cnt) + bo);  // {steps | phase << 20, ticks}
     // (int32 actions, or the low words of int64 ones - torch's argmax output - read in place: a.act_shift)
     const int action = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(a.act) + (bo >> a.act_shift));
@@ -843,7 +844,8 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
 #pragma unroll
     for (int k = 0; k < NRW; ++k) om2 = fma(x.Om[k], x.Om[k], om2);
     const double o2 = sqrt_nr(om2) * ta.obs_cfg.inv_wheel_limit;
-    const double o3 = charge * ta.obs_cfg.charge_scale;
+    const bool static_o3 = FEAT < FEAT_POWER && ta.static_charge != 0;     // obs[3] already sits in the buffers (wave-uniform)
+    double o3 = charge * ta.obs_cfg.charge_scale;
     const double o4 = shadow;
 
     // reward and termination
@@ -851,7 +853,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
     double rew = (action == 0) ? ta.obs_cfg.reward_mult * rcp_nr(fma(o0, o0, 1.0)) : 0.0;
     if (steps0 >= ta.obs_cfg.max_length) why |= BSK_DONE_LENGTH;
     if (o2 > 1.0) { why |= BSK_DONE_WHEELS; rew -= ta.obs_cfg.failure_penalty; }
-    if (o3 == 0.0) { why |= BSK_DONE_BATTERY; rew -= ta.obs_cfg.failure_penalty; }
+    if (!static_o3 && o3 == 0.0) { why |= BSK_DONE_BATTERY; rew -= ta.obs_cfg.failure_penalty; }
     if (dot(x.r, x.r) < ta.obs_cfg.r_min2) why |= BSK_DONE_ORBIT;
 
     if constexpr (SPLIT == 5) {
@@ -889,6 +891,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
         // Device-side auto-reset (rare, divergent): reload this env from the staged IC pool, keep the
         // finished episode's observation as terminal observation, report the new episode's first one.
         gptr<double> tob = uniform_ptr(ta.term_obs);
+        if (static_o3) o3 = *(gptr<double>)((gptr<char>)(ob + 3 * S2) + bo);      // (rare path: the finished episode's constant obs[3])
         stf(tob + 0 * S2, bo, o0); stf(tob + 1 * S2, bo, o1); stf(tob + 2 * S2, bo, o2); stf(tob + 3 * S2, bo, o3);
         stf(tob + 4 * S2, bo, o4);
         const int ep = ta.episodes[i];
@@ -949,11 +952,13 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
         const unsigned long long packed = (unsigned long long)(unsigned)(min(steps0 + 1, 0xFFFFF) | (phase << 20)) |
                                           ((unsigned long long)(unsigned)(cnt.y + ta.substeps) << 32);
         *(gptr<unsigned long long>)((gptr<char>)uniform_ptr(ta.cnt) + bo) = packed;
-        stf(ob + 0 * S2, bo, o0); stf(ob + 1 * S2, bo, o1); stf(ob + 2 * S2, bo, o2); stf(ob + 3 * S2, bo, o3);
+        stf(ob + 0 * S2, bo, o0); stf(ob + 1 * S2, bo, o1); stf(ob + 2 * S2, bo, o2);
+        if (!static_o3) stf(ob + 3 * S2, bo, o3);
         stf(ob + 4 * S2, bo, o4);
         if (ta.obs_rm) {       // optional row-major copy (N, 5): what a torch policy reshapes without a copy kernel
             double* __restrict__ rm = ta.obs_rm + (int64_t)i * 5;
-            rm[0] = o0; rm[1] = o1; rm[2] = o2; rm[3] = o3; rm[4] = o4;
+            rm[0] = o0; rm[1] = o1; rm[2] = o2; rm[4] = o4;
+            if (!static_o3) rm[3] = o3;
         }
     }
 #undef FLD
@@ -1170,6 +1175,7 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     a.stride = b.stride; a.n = b.n; a.substeps = b.substeps;
     a.nav_lag = p.nav_lag; a.fsw_lag = p.fsw_lag;
     a.pair_shift = p.pair_shift; a.act_shift = b.act_shift; a.ep_return = b.ep_return;
+    a.static_charge = b.static_charge; a.pad2_ = 0;
     a.power = p.pc;
     a.extra = p.ex;
     a.tail.obs_cfg = p.obs; a.tail.st = b.st; a.tail.cnt = b.cnt; a.tail.obs = b.obs; a.tail.reward = b.reward;
@@ -1178,7 +1184,7 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     a.tail.pool = b.pool; a.tail.term_obs = b.term_obs; a.tail.episodes = b.episodes;
     a.tail.n_pool = b.n_pool; a.tail.n_fields = b.n_fields;
     a.tail.fsw_lag = p.fsw_lag; a.tail.nav_lag = p.nav_lag;
-    a.tail.env_base = b.env_base; a.tail.pad_ = 0;
+    a.tail.env_base = b.env_base; a.tail.static_charge = b.static_charge;
     a.tail.ep_return = b.ep_return; a.tail.term_return = b.term_return; a.tail.term_len = b.term_len; a.tail.done = b.done;
     a.tail.obs_rm = b.obs_rm; a.tail.err = b.err; a.tail.dbg = b.dbg;
     if (SPLIT == 5) block = 256;

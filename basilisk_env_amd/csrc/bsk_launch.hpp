@@ -31,7 +31,7 @@ struct TailArgs {
     int n_fields;
     int fsw_lag, nav_lag;
     unsigned env_base;             // global index of this handle's env 0 (sharded batches hash the GLOBAL index)
-    int pad_;
+    int static_charge;             // bare levels: obs[3] is a reset-time constant in the buffers and no battery is empty (StepArgs)
     // device-resident surface (BSK_FLAG_EPISODE_STATS / BSK_FLAG_OBS_ROWMAJOR; NULL: off)
     double* ep_return;             // [stride] return of the running episode (the kernel adds this step's reward)
     double* term_return;           // [stride] return / length of the episode that ended at this step (valid where done)
@@ -56,6 +56,11 @@ struct StepArgs {
     int nav_lag, fsw_lag;   // both also in TailArgs (post-loop re-read); here for the FSW block inside the loop
     int pair_shift;         // pair form: the roles of a workgroup's two waves swap with bit `pair_shift` of its index
     int act_shift;          // actions are int32 (1) or the low words of little-endian int64 (0): byte offset = 8 i >> act_shift
+    // Bare levels (no power system): the battery charge never changes, so obs[3] = charge / 3600 / power_max is whatever the last
+    // reset left in the observation buffers (every reset entry point writes it) and "battery empty" is a property of the initial
+    // conditions.  When the host knows that no spacecraft of the batch (nor of the reset pool) started with an empty battery, the
+    // kernel neither loads the charge nor stores obs[3]: 16 of the 407 bytes a K = 1 step moves per spacecraft.  0: as before.
+    int static_charge, pad2_;
     const double* ep_return;      // BSK_FLAG_EPISODE_STATS: the running episode's return, loaded with the state (NULL: off)
     PowerCfg power;               // read only by FEAT >= FEAT_POWER
     ExtraCfg extra;               // read only by FEAT_FULL
@@ -106,6 +111,7 @@ struct StepBuffers {
     int n_fields;
     unsigned env_base;
     int act_shift;
+    int static_charge;
     double* ep_return;
     double* term_return;
     int* term_len;

@@ -2,7 +2,7 @@
 # The round's bench lines, run AFTER profiles/rNN/ holds this tree's kernel_trace.json / isa_mix.json / summary_latest.json,
 # so that every line carries the committed rocprofv3 figures beside its own stamps.  Usage: tools/bench_lines.sh TAG
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r03}
+TAG=${1:-r04}
 O=$R/gpurun_out/${TAG}_lines
 mkdir -p $O
 cd $R

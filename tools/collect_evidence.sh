@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copy what tools/round.sh, tools/isa_mix.sh and tools/bench_lines.sh merged back under gpurun_out/ into profiles/TAG (tracked).
 # Usage (this container, repo root): tools/collect_evidence.sh r03
-TAG=${1:-r03}
+TAG=${1:-r04}
 S=gpurun_out/$TAG; D=profiles/$TAG
 mkdir -p $D
 cp $S/kernel_trace.json $S/summary_latest.json $D/ 2>/dev/null

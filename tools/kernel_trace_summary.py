@@ -20,7 +20,7 @@ import re
 import sys
 
 RAMP_MS = 25.0
-KEYS = {"kt_65k": "65k_k1", "kt_4m": "4m_k1", "kt_k1800": "bare_k1800", "kt_power_k1800": "power_k1800",
+KEYS = {"kt_65k": "65k_k1", "kt_4m": "4m_k1", "kt_131k": "131k_k1", "kt_k1800": "bare_k1800", "kt_power_k1800": "power_k1800",
         "kt_full_k1800": "full_k1800", "kt_sh": "sh70"}
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

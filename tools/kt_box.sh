@@ -4,7 +4,7 @@
 # Usage (one gpurun call per box): tools/kt_box.sh TAG IDX      -> gpurun_out/TAG/kt_65k_bIDX/, ab_65k_bIDX_plain.json
 # afterwards, in this container: python tools/kernel_trace_summary.py gpurun_out/TAG gpurun_out/TAG > gpurun_out/TAG/kernel_trace.json
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r03}; IDX=${2:-2}
+TAG=${1:-r04}; IDX=${2:-2}
 O=$R/gpurun_out/$TAG; mkdir -p $O
 B="python3 $R/bench.py --no-cpu-baseline --no-extra"
 cd /tmp && export TMPDIR=/tmp

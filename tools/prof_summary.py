@@ -27,7 +27,7 @@ for sub in sorted(os.listdir(d)):
 # HBM traffic per launch for the bench workloads: FETCH_SIZE is doubled (gfx950 reports 1/2 of a
 # coalesced streaming read: MI355X_MICROARCH.md §HBM; calibrated on this kernel, profiles/r01/README.md)
 traffic = {}
-for tag, envs in (("65k", 65536), ("4m", 4194304)):
+for tag, envs in (("65k", 65536), ("131k", 131072), ("4m", 4194304)):
     f, w = out.get("fetch_" + tag), out.get("write_" + tag)
     if f and w:
         fk = f["counters_mean_per_dispatch"]["FETCH_SIZE"]

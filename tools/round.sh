@@ -2,7 +2,7 @@
 # One GPU-box pass of the round's evidence: GPU tests, bench lines, the 2-rank rehearsal of the self-launch path on
 # one card, kernel traces and counter passes.  Usage: tools/round.sh TAG   (outputs under gpurun_out/TAG/)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r03}
+TAG=${1:-r04}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
@@ -28,6 +28,10 @@ prof kt_4m --kernel-trace --stats --output-format csv -d $O/kt_4m -- $BL
 prof fetch_4m --pmc FETCH_SIZE --output-format csv -d $O/fetch_4m -- $BL
 prof write_4m --pmc WRITE_SIZE --output-format csv -d $O/write_4m -- $BL
 prof sq_4m --pmc $SQ --output-format csv -d $O/sq_4m -- $BL
+B3="$B --envs 131072 --steps 20000 --warmup 2000"       # BASELINE configs[3], one GPU's share
+prof kt_131k --kernel-trace --stats --output-format csv -d $O/kt_131k -- $B3
+prof fetch_131k --pmc FETCH_SIZE --output-format csv -d $O/fetch_131k -- $B --envs 131072 --steps 50
+prof write_131k --pmc WRITE_SIZE --output-format csv -d $O/write_131k -- $B --envs 131072 --steps 50
 BK="$B --substeps 1800 --steps 20 --warmup 10"
 prof kt_k1800 --kernel-trace --stats --output-format csv -d $O/kt_k1800 -- $BK
 prof sq_k1800 --pmc $SQ --output-format csv -d $O/sq_k1800 -- $BK
@@ -43,7 +47,9 @@ cd $R
 python3 tools/prof_summary.py $O > $O/summary_latest.json 2>/dev/null && echo summary ok
 python3 tools/kernel_trace_summary.py $O $O > $O/kernel_trace.json && echo kernel_trace ok
 # A/B: the same commands without the profiler (their own stamped pass), beside the traces above
-for ab in "65k:--steps 40000 --warmup 4000" "full_k1800:--scenario full --substeps 1800 --steps 20 --warmup 10" "power_k1800:--scenario power --substeps 1800 --steps 20 --warmup 10" "k1800:--substeps 1800 --steps 20 --warmup 10" "sh:--gravity sh --steps 1000 --warmup 300" "4m:--envs 4194304 --steps 20 --warmup 3"; do
+# the device-resident loop under the copy tracer: reset_tensors + step_tensors must show NO memory copy (row f4)
+prof memcopy_rl --kernel-trace --memory-copy-trace --output-format csv -d $O/memcopy_rl -- python3 $R/tools/exp/rl_nocopy.py
+for ab in "131k:--envs 131072 --steps 20000 --warmup 2000" "65k:--steps 40000 --warmup 4000" "full_k1800:--scenario full --substeps 1800 --steps 20 --warmup 10" "power_k1800:--scenario power --substeps 1800 --steps 20 --warmup 10" "k1800:--substeps 1800 --steps 20 --warmup 10" "sh:--gravity sh --steps 1000 --warmup 300" "4m:--envs 4194304 --steps 20 --warmup 3"; do
   python bench.py --no-cpu-baseline --no-extra ${ab#*:} > $O/ab_${ab%%:*}_plain.json 2>> $O/bench.err
 done
 python3 tools/latency.py > $O/latency.json 2>> $O/bench.err && echo latency ok
