@@ -8,6 +8,29 @@ cp $S/kernel_trace.json $S/summary_latest.json $D/ 2>/dev/null
 cp $S/kt_*_dispatches.csv $S/kt_*_kernel_stats.csv $D/ 2>/dev/null
 cp $S/ab_*_plain.json $D/ 2>/dev/null
 [ -f $S/latency.json ] && cp $S/latency.json $D/latency_box.json
+# the device-resident loop under rocprofv3 --kernel-trace --memory-copy-trace (tools/exp/rl_nocopy.py): kernels per name, copies
+if [ -d $S/memcopy_rl ]; then
+  python3 - $S/memcopy_rl $S/memcopy_rl.log > $D/memcopy_rl.txt <<'PY'
+import csv, glob, sys, collections, re
+d, log = sys.argv[1], sys.argv[2]
+kt = glob.glob(d + "/*/*_kernel_trace.csv"); mc = glob.glob(d + "/*/*memory_copy*.csv")
+print("rocprofv3 --kernel-trace --memory-copy-trace -- python3 tools/exp/rl_nocopy.py   (65 536 envs, full scenario, K = 1, 200 steps after reset_tensors)")
+print("memory-copy records: %d file(s)%s" % (len(mc), "" if mc else "  -> none: no hipMemcpy* reached the copy engines or the tracer in the whole run"))
+for f in mc:
+    rows = list(csv.DictReader(open(f))); print("  ", f.split("/")[-1], len(rows), "records", collections.Counter(r.get("Direction", r.get("Kind", "?")) for r in rows))
+c = collections.Counter()
+for f in kt:
+    for r in csv.DictReader(open(f)):
+        n = r["Kernel_Name"]; n = re.sub(r"<.*", "", n); n = n[:60]
+        c[n] += 1
+print("kernels dispatched (name prefix: count):")
+for n, k in c.most_common():
+    print("  %6d  %s" % (k, n))
+for line in open(log):
+    if "library copies" in line:
+        print(line.strip())
+PY
+fi
 [ -f gpurun_out/isa_$TAG/isa_mix.json ] && cp gpurun_out/isa_$TAG/isa_mix.json $D/
 [ -d gpurun_out/${TAG}_lines ] && cp gpurun_out/${TAG}_lines/bench_*.json $D/ 2>/dev/null
 python3 - $D <<'PY'
