@@ -359,6 +359,8 @@ int build_params(const bsk_config& c, bsk::StepParams& p, bsk::ColdCfg& k, bool&
     k.kt[32 + bsk::KC_REQIH] = c.req * p.ex.inv_scale_height;
     k.kt[32 + bsk::KC_RSKIP] = p.ex.rho_skip;
     k.kt[32 + bsk::KC_LOG2E] = 1.4426950408889634074;
+    k.kt[32 + bsk::KC_I6] = 1.0 / 6.0; k.kt[32 + bsk::KC_I24] = 1.0 / 24.0; k.kt[32 + bsk::KC_I120] = 1.0 / 120.0;   // Atmo::advance
+    k.kt[32 + bsk::KC_I720] = 1.0 / 720.0;
     {   // row E: rho0 / k!, k = 0..13 (bsk_device.hpp: atmosphere_density), -ln2 split in two parts
         long double f = 1.0L;
         for (int i = 0; i < 14; ++i) {

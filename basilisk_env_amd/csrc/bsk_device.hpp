@@ -167,7 +167,7 @@ struct ColdCfg {
 // entries of the broadcast table (ColdCfg::kt): row A, row B, row C
 enum { KA_G = 0, KA_JS = 12 };                                 // wheel spin axes g[i][k] at 3 i + k, Js_i
 enum { KB_IJS = 0, KB_FAC = 4, KB_FAD = 10 };                  // 1/Js_i, facet half sums / differences (6 + 6)
-enum { KC_IMASS = 0, KC_NB = 1, KC_KFLUX = 4, KC_RHO0 = 5, KC_NIH = 6, KC_REQIH = 7, KC_RSKIP = 8, KC_LOG2E = 9 };   // 1/m, panel normal, ...
+enum { KC_IMASS = 0, KC_NB = 1, KC_KFLUX = 4, KC_RHO0 = 5, KC_NIH = 6, KC_REQIH = 7, KC_RSKIP = 8, KC_LOG2E = 9, KC_I6 = 10, KC_I24 = 11, KC_I120 = 12, KC_I720 = 13 };   // 1/m, panel normal, ...
 enum { KD_JG = 0, KD_HIJS = 12 };                              // row D: Js_i g[i][k] at 3 i + k, dt / Js_i
 enum { KE_POLY = 0, KE_NLN2HI = 14, KE_NLN2LO = 15 };          // row E: rho0 / k!, k = 0..13 (atmosphere_density); -ln2 in two parts
 
@@ -558,6 +558,8 @@ struct TriXch {
 // extra instruction, no latency, 6 registers.  A DPP operand is read from ANOTHER lane's register, so every lane
 // of the wave must be active where these are used: the full-scenario kernels keep the RK4 loop's trip count and
 // the drag / thruster switches wave-uniform.  asm volatile keeps the compiler from sinking one into a branch.
+// HAZARD: a DPP read wants two wait states after a VALU write of its source and the compiler does not pad inline asm - the
+// build does (csrc/dpp_nops.py between the device compiler and the assembler), tools/dpp_hazard.py checks what ships.
 struct KTab {
     double a, b, c, e;
 };
@@ -576,6 +578,13 @@ template <int K>
 __device__ __forceinline__ double fmac_k_neg(double acc, double tab, double x) {    // acc - tab[K] * x
     asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tab), "v"(x), "n"(K));
     return acc;
+}
+// max(x, 0) of a value that came out of one of the asm statements above: the compiler cannot see that it is no signalling
+// NaN and canonicalises it first (v_max x, x) when asked for fmax
+__device__ __forceinline__ double max0(double x) {
+    double r;
+    asm("v_max_f64 %0, %1, 0" : "=v"(r) : "v"(x));
+    return r;
 }
 template <int K>
 __device__ __forceinline__ double mul_k(double tab, double x) { return fmac_k<K>(0.0, tab, x); }   // tab[K] * x
@@ -596,24 +605,67 @@ __device__ __forceinline__ double get_k(double tab) {                           
 // 81 VALU instructions less, 23 scalar ones more, 3.7 % instead of 9 % faster).  So: seven first-degree pairs c_2j + c_2j+1 r,
 // each a broadcast move + a broadcast FMA, combined by Horner's rule in r^2 - 28 instructions, no scalar ones, no constants
 // in registers.  Moves first, FMAs after: no DPP instruction directly behind the one that wrote its accumulator.
-__device__ __forceinline__ double atmosphere_density(const KTab& kt, double rm) {
-    const double x = fmac_k<KC_NIH>(get_k<KC_REQIH>(kt.c), kt.c, rm);        // Re/H - |r|/H
+__device__ __forceinline__ double atmosphere_exponent(const KTab& kt, double rm) {      // Re/H - |r|/H
+    return fmac_k<KC_NIH>(get_k<KC_REQIH>(kt.c), kt.c, rm);
+}
+__device__ __forceinline__ double atmosphere_exp(const KTab& kt, double x) {             // rho0 e^x
     const double n = __builtin_rint(mul_k<KC_LOG2E>(kt.c, x));
-    double r = fmac_k<KE_NLN2HI>(x, kt.e, n);
-    double t0 = get_k<KE_POLY + 0>(kt.e), t1 = get_k<KE_POLY + 2>(kt.e), t2 = get_k<KE_POLY + 4>(kt.e), t3 = get_k<KE_POLY + 6>(kt.e);
-    r = fmac_k<KE_NLN2LO>(r, kt.e, n);
-    double t4 = get_k<KE_POLY + 8>(kt.e), t5 = get_k<KE_POLY + 10>(kt.e), t6 = get_k<KE_POLY + 12>(kt.e);
+    const double te = kt.e;
+    double r = fmac_k<KE_NLN2HI>(x, te, n);
+    double t0 = get_k<KE_POLY + 0>(te), t1 = get_k<KE_POLY + 2>(te), t2 = get_k<KE_POLY + 4>(te), t3 = get_k<KE_POLY + 6>(te);
+    r = fmac_k<KE_NLN2LO>(r, te, n);
+    double t4 = get_k<KE_POLY + 8>(te), t5 = get_k<KE_POLY + 10>(te), t6 = get_k<KE_POLY + 12>(te);
     const double r2 = r * r;
-    t0 = fmac_k<KE_POLY + 1>(t0, kt.e, r); t1 = fmac_k<KE_POLY + 3>(t1, kt.e, r); t2 = fmac_k<KE_POLY + 5>(t2, kt.e, r);
-    t3 = fmac_k<KE_POLY + 7>(t3, kt.e, r); t4 = fmac_k<KE_POLY + 9>(t4, kt.e, r); t5 = fmac_k<KE_POLY + 11>(t5, kt.e, r);
-    t6 = fmac_k<KE_POLY + 13>(t6, kt.e, r);
+    t0 = fmac_k<KE_POLY + 1>(t0, te, r); t1 = fmac_k<KE_POLY + 3>(t1, te, r); t2 = fmac_k<KE_POLY + 5>(t2, te, r);
+    t3 = fmac_k<KE_POLY + 7>(t3, te, r); t4 = fmac_k<KE_POLY + 9>(t4, te, r); t5 = fmac_k<KE_POLY + 11>(t5, te, r);
+    t6 = fmac_k<KE_POLY + 13>(t6, te, r);
     double p = fma(t6, r2, t5);
     p = fma(p, r2, t4);
     p = fma(p, r2, t3);
     p = fma(p, r2, t2);
     p = fma(p, r2, t1);
     p = fma(p, r2, t0);
-    const double rho = ldexp(p, (int)n);
+    return ldexp(p, (int)n);
+}
+// The density ALONG a trajectory.  Between two dyn ticks |r| moves by metres and the exponent by d = -(|r'| - |r|) / H: up to
+// 5e-3 on the reference's orbits (radial velocity up to 380 m/s, H = 8 km, dt = 0.1 s).  rho' = rho e^d with the degree-6
+// Taylor polynomial of e^d (truncation d^7 / 5040 < 5e-17 for |d| <= 2^-6, i.e. 125 m of radial motion per tick) - ten
+// instructions instead of the thirty-five of the full evaluation.  The exponents telescope exactly (x' - x of neighbouring
+// doubles is exact), so what accumulates is the rounding of one polynomial and one product per tick (2e-16 each); every
+// chunk of <= PEN_CHUNK ticks starts from a full evaluation (anchor), and a lane whose exponent jumps by more than 2^-6
+// takes the full evaluation for that tick (per lane: the others keep their increments, so a lane's result does not depend
+// on its neighbours in the wave).  The conditioning of the exponential itself - an ulp of |r| is 1e-13 of rho - is three
+// orders above either.  All three forms of the scenario kernel anchor at the same ticks and advance with the same
+// operations: bit-identical.
+struct Atmo {
+    double x, rho;             // the exponent of the last evaluation, the un-clamped density there
+    __device__ __forceinline__ double clamped(const KTab& kt) const { return rho >= get_k<KC_RSKIP>(kt.c) ? rho : 0.0; }   // 0 below the skip density
+    __device__ __forceinline__ double anchor(const KTab& kt, double rm) {
+        x = atmosphere_exponent(kt, rm);
+        rho = atmosphere_exp(kt, x);
+        return clamped(kt);
+    }
+    __device__ __forceinline__ double advance(const KTab& kt, double rm) {
+        const double xn = atmosphere_exponent(kt, rm);
+        const double d = xn - x;
+        x = xn;
+        const double d2 = d * d;
+        double a = fmac_k<KC_I120>(get_k<KC_I24>(kt.c), kt.c, d);          // 1/24 + d/120 + d^2/720
+        double b = fmac_k<KC_I6>(0.5, kt.c, d);                             // 1/2 + d/6
+        a = fmac_k<KC_I720>(a, kt.c, d2);
+        b = fma(d2, a, b);
+        const double pn = rho * fma(d2, b, d + 1.0);
+        const bool far = !(d2 <= 0x1p-12);                                   // |d| > 2^-6 or NaN
+        if (BSK_UNLIKELY(__builtin_amdgcn_ballot_w64(far) != 0)) {
+            const double full = atmosphere_exp(kt, xn);
+            rho = far ? full : pn;
+        } else rho = pn;
+        return clamped(kt);
+    }
+};
+// exponentialAtmosphere at one position (no history)
+__device__ __forceinline__ double atmosphere_density(const KTab& kt, double rm) {
+    const double rho = atmosphere_exp(kt, atmosphere_exponent(kt, rm));
     return rho >= get_k<KC_RSKIP>(kt.c) ? rho : 0.0;
 }
 
@@ -762,7 +814,7 @@ __device__ __forceinline__ void power_eval(const PowerCfg& pc, const SunGeom& g,
     const V3 dB = d + rot.ka * t2 - rot.kb * t1;
     const double id3 = id * id * id;
     if constexpr (LDSK) {     // panel normal and flux constant from the broadcast table (row C)
-        const double proj = fmax(fmac_k<KC_NB>(fmac_k<KC_NB + 1>(mul_k<KC_NB + 2>(tc, dB.z), tc, dB.y), tc, dB.x), 0.0);
+        const double proj = max0(fmac_k<KC_NB>(fmac_k<KC_NB + 1>(mul_k<KC_NB + 2>(tc, dB.z), tc, dB.y), tc, dB.x));
         gain = mul_k<KC_KFLUX>(tc, id3) * proj;
     } else {
         const double proj = fmax(fma(pc.nB[0], dB.x, fma(pc.nB[1], dB.y, pc.nB[2] * dB.z)), 0.0);
@@ -820,16 +872,27 @@ __device__ __forceinline__ void power_flush(const PowerCfg& pc, LdsP L, int m, i
 #pragma unroll
         for (int k = 0; k < PEN_SLOTS; ++k) sk[k] = L->s[k][lane];
     }
-    // Replay: the energy increments p_k h in parallel, then only the clamped sums are a dependent chain (three
-    // operations per tick; one wave per SIMD pays every dependent instruction's full latency).  charge + (p h) with
-    // p h rounded first is what the non-fused reference arithmetic does.
+    // Replay: the panel powers p_k in parallel, then only the clamped sums are a dependent chain (three operations per tick;
+    // one wave per SIMD pays every dependent instruction's full latency).  charge' = clamp(fma(p, h, charge)): ONE rounding
+    // per tick, written as an explicit fma - under -ffp-contract=fast the compiler fused `charge + p * h` in some shapes of
+    // this loop and not in others, and the wave-split forms' replay (bsk_kernels.hip: env_ticks) must give the same bits.
+    // (The reference's simpleBattery rounds p h first: <= 1 ulp of the charge per tick apart, 1e-16 relative.)
 #pragma unroll
-    for (int k = 0; k < PEN_SLOTS; ++k) dq[k] = fma(dq[k], sk[k], draw) * h;
+    for (int k = 0; k < PEN_SLOTS; ++k) dq[k] = fma(dq[k], sk[k], draw);
+    // `m` is the same in every lane (the chunk lengths it sums are wave-uniform, the flush is decided by a ballot): as a
+    // scalar, the full record - the usual flush - replays without a predicate per slot (three operations instead of eight)
+    const int mu = __builtin_amdgcn_readfirstlane(m);
+    if (BSK_LIKELY(mu == PEN_SLOTS)) {
 #pragma unroll
-    for (int k = 0; k < PEN_SLOTS; ++k) {
-        if (k < m) {
-            shadow = sk[k];
-            charge = fmin(fmax(charge + dq[k], 0.0), cap);
+        for (int k = 0; k < PEN_SLOTS; ++k) charge = fmin(fmax(fma(dq[k], h, charge), 0.0), cap);
+        shadow = sk[PEN_SLOTS - 1];
+    } else {
+#pragma unroll
+        for (int k = 0; k < PEN_SLOTS; ++k) {
+            if (k < mu) {
+                shadow = sk[k];
+                charge = fmin(fmax(fma(dq[k], h, charge), 0.0), cap);
+            }
         }
     }
 }
@@ -1659,26 +1722,38 @@ struct Guid {
     V3 sigma_BR, omega_BR_B, omega_RN_B, domega_RN_B;
 };
 
+// hillPoint: the orbit frame's attitude, rate and acceleration from (r, v).
+// ZNAV: a navigation message nobody has written yet may be among the lanes (all zeros: the FSW tick at t = 0 with
+// bsk_config.nav_lag) - hillPoint's unit vectors normalise to zero, the zero DCM maps to the zero MRP and its radius guard
+// zeroes the rates.  That instantiation carries 34 selects the chain of every other tick does without.
+template <bool ZNAV>
+__device__ __forceinline__ void hill_point(V3 r, V3 v, V3& sRN, V3& wRN_N, V3& dwRN_N) {
+    bool znav = false;
+    if constexpr (ZNAV) znav = dot(r, r) == 0.0;
+    const V3 xr = znav ? mk(1, 0, 0) : r, xv = znav ? mk(0, 1, 0) : v;   // keeps the arithmetic finite
+    double ir = rsqrt_nr(dot(xr, xr));
+    V3 h = cross(xr, xv);
+    double h2 = dot(h, h), ih = rsqrt_nr(h2), hm = h2 * ih;
+    V3 e_r = ir * xr, e_h = ih * h, e_t = cross(e_h, e_r);
+    double C[9] = {e_r.x, e_r.y, e_r.z, e_t.x, e_t.y, e_t.z, e_h.x, e_h.y, e_h.z};
+    sRN = c2mrp(C);
+    double dfdt = hm * ir * ir;
+    double ddfdt2 = -2.0 * dot(xv, e_r) * ir * dfdt;
+    wRN_N = dfdt * e_h;
+    dwRN_N = ddfdt2 * e_h;
+    if (znav) { sRN = mk(0, 0, 0); wRN_N = mk(0, 0, 0); dwRN_N = mk(0, 0, 0); }
+}
+
 // hillPoint | inertial3D  ->  attTrackingError
 template <int NRW>
 __device__ __forceinline__ Guid guidance(const double* __restrict__ sigma_R0N, const State<NRW>& x, int action) {
     V3 sRN, wRN_N, dwRN_N;
-    // a navigation message nobody has written yet (all zeros: the FSW tick at t = 0 with bsk_config.nav_lag): hillPoint's
-    // unit vectors normalise to zero, the zero DCM maps to the zero MRP and its radius guard zeroes the rates
-    const bool znav = dot(x.r, x.r) == 0.0;
+    // some lane of the wave holds the unwritten message (one ballot per FSW tick; a flag handed down from the tick loop
+    // would occupy a scalar register pair across it)
+    const bool maybe_znav = __builtin_amdgcn_ballot_w64(dot(x.r, x.r) == 0.0) != 0;
     if (action == 0) {
-        const V3 xr = znav ? mk(1, 0, 0) : x.r, xv = znav ? mk(0, 1, 0) : x.v;   // keeps the arithmetic finite
-        double ir = rsqrt_nr(dot(xr, xr));
-        V3 h = cross(xr, xv);
-        double h2 = dot(h, h), ih = rsqrt_nr(h2), hm = h2 * ih;
-        V3 e_r = ir * xr, e_h = ih * h, e_t = cross(e_h, e_r);
-        double C[9] = {e_r.x, e_r.y, e_r.z, e_t.x, e_t.y, e_t.z, e_h.x, e_h.y, e_h.z};
-        sRN = c2mrp(C);
-        double dfdt = hm * ir * ir;
-        double ddfdt2 = -2.0 * dot(xv, e_r) * ir * dfdt;
-        wRN_N = dfdt * e_h;
-        dwRN_N = ddfdt2 * e_h;
-        if (znav) { sRN = mk(0, 0, 0); wRN_N = mk(0, 0, 0); dwRN_N = mk(0, 0, 0); }
+        if (BSK_UNLIKELY(maybe_znav)) hill_point<true>(x.r, x.v, sRN, wRN_N, dwRN_N);
+        else hill_point<false>(x.r, x.v, sRN, wRN_N, dwRN_N);
     } else {
         sRN = mk(sigma_R0N[0], sigma_R0N[1], sigma_R0N[2]);
         wRN_N = mk(0, 0, 0);

@@ -32,6 +32,21 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // a wave-uniform condition as an integer in a scalar register
 __device__ __forceinline__ int uni(bool b) { return __builtin_amdgcn_readfirstlane(b ? 1 : 0); }
+// a wave-uniform double as a scalar value of its own: a kernel argument that arrived in a 16-dword scalar load is otherwise
+// kept - and, when scalar registers run out, spilled and reloaded - as part of that whole tuple
+__device__ __forceinline__ double own_scalar(double x) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// ... "some lane of the wave": compare + s_cmp_lg_u64 + s_cselect_b32 (through uni() the compiler materialises the ballot as
+// a lane value and reads it back: seven instructions)
+__device__ __forceinline__ int uni_any(bool lane_cond) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(lane_cond);
+    int r;
+    asm volatile("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(m) : "scc");
+    return r;
+}
 
 __device__ __forceinline__ int wave_min_uniform(int v) {
     // every lane holds the same value unless a masked reset staggered the FSW phases inside this wave: one ballot
@@ -188,6 +203,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
     // what the previous tick's EnvTask knows about this tick's initial state (bsk_device.hpp: Pre): here of the loaded state
     Pre pre{0.0, 0.0, MrpRot{0.0, 0.0}};
     if constexpr (FULL && !PAIR) { pre.r2 = dot(x.r, x.r); pre.rot = mrp_rot(x.s); }
+    Atmo atm{0.0, 0.0};   // exponentialAtmosphere along the trajectory (bsk_device.hpp): anchored per chunk of ticks, advanced per tick
     bool first_fsw = true;
     bool drag_cfg = false;
     if constexpr (FULL) drag_cfg = a.extra.base_density != 0.0;
@@ -346,7 +362,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
             for (int k = 0; k < PAIR_CHUNK; ++k) {
                 if (k < mm) {
                     shadow = sk[k];
-                    charge = fmin(fmax(charge + fma(gk[k], sk[k], draw) * c.h, 0.0), cap);
+                    charge = fmin(fmax(fma(fma(gk[k], sk[k], draw), c.h, charge), 0.0), cap);   // (the arithmetic of power_flush)
                 }
             }
         };
@@ -406,11 +422,16 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
                 constexpr bool ROT = PART == PART_ROT;
                 TriXch<PART> xc{TX, lane, 0, 0, false};
                 // exponentialAtmosphere at a position (the arithmetic of the single-wave tick loop), 0 below the skip density
+                // (anchored where the single-wave loop anchors: the launch's first tick, every chunk's first tick - whose
+                // density the last step of the chunk before it asks for)
+                bool atm_anchor = true;
                 auto density = [&](V3 r) __attribute__((always_inline)) {
                     double rho = 0.0;
                     if (drag_cfg) {
                         const double r2 = dot(r, r);
-                        rho = atmosphere_density(kt, r2 * rsqrt_nr(r2));
+                        const double rm = r2 * rsqrt_nr(r2);
+                        if (atm_anchor) rho = atm.anchor(kt, rm);
+                        else rho = atm.advance(kt, rm);
                     }
                     return rho;
                 };
@@ -463,6 +484,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
                         }
                         const double tt = (double)tick * c.h;
                         double rho_next = 0.0;
+                        atm_anchor = t == m - 1;
 #define BSK_TRI_STEP(THR, DRAGM) rk4_step_part<GRAV, NRW, DIAG, FEAT, SPLIT, THR, DRAGM, PART>(c, wv, x, lext, tt, ev, xc, v1, tq, Tw, pw, tqj, density, rho_next)
                         if (BSK_LIKELY(!ev.thr_on)) {
                             if (BSK_LIKELY(ev.drag_on)) BSK_TRI_STEP(false, 1);
@@ -532,12 +554,15 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
                 if constexpr (FULL) {
                     if (ev.sun_on) third_body_anchor(ev.s3, mk(PL->sun[0][lane], PL->sun[1][lane], PL->sun[2][lane]), a.extra.mu_sun, x.r);
                 }
+                if constexpr (FULL) {
+                    if (drag_cfg) { const double r2 = dot(x.r, x.r); atm.anchor(kt, r2 * rsqrt_nr(r2)); }
+                }
                 for (int t = 0; t < m; ++t, ++tick) {
                     const V3 lx = mk(PL->lext[0][lane], PL->lext[1][lane], PL->lext[2][lane]);   // (parked in LDS)
                     if constexpr (FULL) {
                         if (drag_cfg) {
                             const double r2 = dot(x.r, x.r);
-                            ev.rho = atmosphere_density(kt, r2 * rsqrt_nr(r2));
+                            ev.rho = atm.advance(kt, r2 * rsqrt_nr(r2));
                             ev.drag_on = __builtin_amdgcn_ballot_w64(ev.rho != 0.0) != 0;
                         }
                         if (desat) {
@@ -632,7 +657,16 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
         }
     } else {
     int np = 0;   // power system: ticks recorded since the last flush (per lane)
+    PowerCfg pc_loop_cfg;   // power level (panel constants as scalar operands): the four the tick reads, as scalars of their own
+    if constexpr (POWER && !FULL) {
+        pc_loop_cfg = a.power;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pc_loop_cfg.nB[k] = own_scalar(a.power.nB[k]);
+        pc_loop_cfg.kflux = own_scalar(a.power.kflux);
+    }
+    const probe::Stamp pc_loop = probe::stamp<probe::CHUNK != 0>();
     while (j < substeps_eff) {
+        const probe::Stamp pc_head = probe::stamp<probe::CHUNK == 1>();
         int m = substeps_eff - j;
         bool fsw_here = false;                         // this lane's FSW chain ran at the head of this chunk
         if constexpr (NRW > 0) {
@@ -649,7 +683,9 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
                         for (int k = 0; k < NRW; ++k) nav.Om[k] = 0.0;
                     }
                 }
+                const probe::Stamp pc_fsw = probe::stamp<probe::CHUNK == 3>();
                 fsw_tick(nav, tick + ((navlag && !z0) ? 1 : 0));
+                probe::since<probe::CHUNK == 3>(dbg_chain, pc_fsw);
                 fsw_here = true;
                 if (!navlag) latch();
                 else dist = fsw_every;                 // latched inside the chunk, after its first RK4 step
@@ -674,14 +710,19 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
         }
         if constexpr (POWER) {
             // the tick record is flushed (queue drained cooperatively, battery replayed) when some lane's would overflow
+            const probe::Stamp pc_flush = probe::stamp<probe::CHUNK == 4>();
             if (__builtin_amdgcn_ballot_w64(np + m > PEN_SLOTS) != 0) {
                 power_flush(a.power, L, np, lane, c.h, charge, shadow);
                 np = 0;
             }
+            probe::since<probe::CHUNK == 4>(dbg_chain, pc_flush);
         }
         j += m;
         if constexpr (FULL) {
+            const probe::Stamp pc_anchor = probe::stamp<probe::CHUNK == 5>();
             if (ev.sun_on) third_body_anchor(ev.s3, sg.sun, a.extra.mu_sun, x.r);   // exact at the chunk's first position
+            if (drag_cfg_u) atm.anchor(kt, pre.r2 * rsqrt_nr(pre.r2));             // ... and the density's full evaluation
+            probe::since<probe::CHUNK == 5>(dbg_chain, pc_anchor);
         }
         // ---- the chunk's ticks.  A tick = head (what decides which instantiation of the step runs: the atmosphere's density,
         // the burst test) + body (RK4 step, EnvTask).  Three instantiations at the full-scenario levels: with drag (nearly
@@ -695,11 +736,11 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
             if constexpr (FULL) {
                 pre.ir = rsqrt_nr(pre.r2);                   // 1 / |r|: the atmosphere below, the first stage's gravity
                 if (drag_cfg_u) {   // exponentialAtmosphere, refreshed once per dyn tick
-                    ev.rho = atmosphere_density(kt, pre.r2 * pre.ir);
-                    drag_now = uni(__builtin_amdgcn_ballot_w64(ev.rho != 0.0) != 0);   // any lane of the wave inside the atmosphere
+                    ev.rho = atm.advance(kt, pre.r2 * pre.ir);
+                    drag_now = uni_any(ev.rho != 0.0);   // any lane of the wave inside the atmosphere
                 }
                 // some thruster of some lane still inside its burst
-                if (BSK_UNLIKELY(burst_any)) thr_now = uni(__builtin_amdgcn_ballot_w64(ev.thr_max > 0 && 2 * (tick - thr_t0) <= ev.thr_max) != 0);
+                if (BSK_UNLIKELY(burst_any)) thr_now = uni_any(ev.thr_max > 0 && 2 * (tick - thr_t0) <= ev.thr_max);
             }
         };
         auto tick_body = [&](auto THR_, auto DM_) __attribute__((always_inline)) {
@@ -713,7 +754,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
             }
             if constexpr (FULL) rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT, THR, DM>(c, wv, x, u, lext, (double)tick * c.h, ev, accp, &pre, &q2);
             else rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT, false>(c, wv, x, u, lext, (double)tick * c.h, ev, accp);
-            if constexpr (POWER) power_tick<FULL>(a.power, sg, x.r, x.s, L, np + t, lane, kt.c, FULL ? &pre : nullptr, FULL ? &q2 : nullptr);
+            if constexpr (POWER) power_tick<FULL>(FULL ? a.power : pc_loop_cfg, sg, x.r, x.s, L, np + t, lane, kt.c, FULL ? &pre : nullptr, FULL ? &q2 : nullptr);
             ++t;
             ++tick;
         };
@@ -729,12 +770,14 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
         auto burst_pending = [&]() __attribute__((always_inline)) {
             int any = 0;
             if constexpr (FULL) {
-                if (desat) any = uni(__builtin_amdgcn_ballot_w64(ev.thr_max > 0 && 2 * (tick - thr_t0) <= ev.thr_max) != 0);
+                if (desat) any = uni_any(ev.thr_max > 0 && 2 * (tick - thr_t0) <= ev.thr_max);
                 if (!any) thr_now = 0;
             }
             return any;
         };
         burst_any = burst_pending();
+        probe::since<probe::CHUNK == 1>(dbg_chain, pc_head);
+        const probe::Stamp pc_first = probe::stamp<probe::CHUNK == 2>();
         // The chunk's first tick runs alone when an FSW tick opened the chunk under the reference's task priorities: after it
         // the dynamics task's effectors latch the new commands (idempotent moves, a no-op for lanes without a new message).
         // No other tick latches anything.
@@ -753,6 +796,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
                 burst_any = burst_pending();
             }
         }
+        probe::since<probe::CHUNK == 2>(dbg_chain, pc_first);
         // The rest of the chunk as RUNS of ticks of one instantiation, two ticks per trip of the run's loop.  A loop whose body
         // is one tick cannot produce the step's results in the registers its header expects (the old state is read until the
         // last stage: ~30 register moves per tick); a loop that picks the instantiation per tick merges three alternative
@@ -806,6 +850,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
     if constexpr (POWER) {
         if (__builtin_amdgcn_ballot_w64(np > 0) != 0) power_flush(a.power, L, np, lane, c.h, charge, shadow);
     }
+    if constexpr (probe::CHUNK != 0) dbg_waitA = probe::elapsed(pc_loop);
     }   // !PAIR
 
     // Re-read the post-loop arguments from the kernarg segment through an opaque pointer: the
@@ -873,6 +918,8 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
             w = ((probe::elapsed(t_kernel) >> 10) & 0xFFFFFFFFull) | (probe::hw_id() << 32);
         if constexpr (PAIR && probe::PAIR_HWID)         // placement: the dynamics wave's hardware id | the environment wave's << 32
             w = probe::hw_id() | ((unsigned long long)((PairP)lds_dyn)->box[9][0] << 32);
+        if constexpr (!PAIR && probe::CHUNK != 0)       // single-wave form: cycles / 16 of the probed part of every chunk | of the whole tick loop << 32
+            w = ((dbg_chain >> 4) & 0xFFFFFFFFull) | (((dbg_waitA >> 4) & 0xFFFFFFFFull) << 32);
         if ((threadIdx.x & 63) == 0 && ta.dbg) ta.dbg[gid >> 6] = w;
     }
     if ((threadIdx.x & 63) == 0) {

@@ -8,6 +8,9 @@
 //     BSK_PROBE_PAIR_TIME     residency of every wave: cycles and hardware id                                            (tools/pair_time.py)
 //     BSK_PROBE_PAIR_HWID     which SIMD hosts which wave of a pair                                                      (tools/pair_place.py)
 //     BSK_PROBE_TRI_XCHG=1|2  the three-wave exchange: early consumes, re-reads, cycles re-reading (rotational / translational wave; tools/tri_wait.py)
+//     BSK_PROBE_CHUNK=1..5    single-wave form: cycles of one part of every chunk of ticks beside the whole loop's (1: the chunk's head up to its
+//                             first tick - FSW chain, flush, anchors; 2: the lone first tick + latch; 3: the FSW chain alone; 4: the power
+//                             system's flush; 5: the third-body and density anchors; tools/chunk_probe.py)
 //     BSK_PROBE_TRI_NOPUBLISH fault injection: the translational wave never publishes, so that its partner's poll times out
 //                             (tests/test_gpu_tri.py: the handle's error word -> BSK_EHIP)
 // A probe writes ONE 64-bit word per wave into the handle's debug buffer (bsk_debug_words), never into a result buffer.
@@ -17,7 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #if !defined(BSK_PROBES) || !BSK_PROBES
-#if defined(BSK_PROBE_PAIR_WAIT) || defined(BSK_PROBE_PAIR_TIME) || defined(BSK_PROBE_PAIR_HWID) || defined(BSK_PROBE_TRI_XCHG) || defined(BSK_PROBE_TRI_NOPUBLISH)
+#if defined(BSK_PROBE_PAIR_WAIT) || defined(BSK_PROBE_PAIR_TIME) || defined(BSK_PROBE_PAIR_HWID) || defined(BSK_PROBE_TRI_XCHG) || defined(BSK_PROBE_TRI_NOPUBLISH) || defined(BSK_PROBE_CHUNK)
 #error "a BSK_PROBE_* selector without -DBSK_PROBES=1: probes never ride along in a product build"
 #endif
 #endif
@@ -46,6 +49,11 @@ constexpr int TRI_XCHG = BSK_PROBE_TRI_XCHG;
 #else
 constexpr int TRI_XCHG = 0;
 #endif
+#ifdef BSK_PROBE_CHUNK
+constexpr int CHUNK = BSK_PROBE_CHUNK;
+#else
+constexpr int CHUNK = 0;
+#endif
 #ifdef BSK_PROBE_TRI_NOPUBLISH
 constexpr bool TRI_NOPUBLISH = true;
 #else
@@ -53,10 +61,10 @@ constexpr bool TRI_NOPUBLISH = false;
 #endif
 #else
 constexpr bool PAIR_WAIT = false, PAIR_TIME = false, PAIR_HWID = false, TRI_NOPUBLISH = false;
-constexpr int TRI_XCHG = 0;
+constexpr int TRI_XCHG = 0, CHUNK = 0;
 #endif
-constexpr bool ANY = PAIR_WAIT || PAIR_TIME || PAIR_HWID || TRI_XCHG != 0;     // probes that emit a word per wave
-static_assert((int)PAIR_WAIT + (int)PAIR_TIME + (int)PAIR_HWID + (int)(TRI_XCHG != 0) + (int)TRI_NOPUBLISH <= 1, "one probe per library");
+constexpr bool ANY = PAIR_WAIT || PAIR_TIME || PAIR_HWID || TRI_XCHG != 0 || CHUNK != 0;     // probes that emit a word per wave
+static_assert((int)PAIR_WAIT + (int)PAIR_TIME + (int)PAIR_HWID + (int)(TRI_XCHG != 0) + (int)TRI_NOPUBLISH + (int)(CHUNK != 0) <= 1, "one probe per library");
 
 typedef unsigned long long Stamp;
 // the cycle counter when probe ON is built in, 0 (and no instruction) otherwise

@@ -205,7 +205,7 @@ def cpu_baseline(cfg, n_rw, substeps, budget_s=12.0, n=8192, sh=None, single_s=0
 
 
 KERNEL_SOURCES = ("basilisk_env_amd/csrc/bsk_kernels.hip", "basilisk_env_amd/csrc/bsk_device.hpp",
-                  "basilisk_env_amd/csrc/bsk_launch.hpp")
+                  "basilisk_env_amd/csrc/bsk_launch.hpp", "basilisk_env_amd/csrc/bsk_probes.hpp", "basilisk_env_amd/csrc/dpp_nops.py")
 
 
 def kernel_fingerprint():
@@ -537,13 +537,26 @@ def rl_loop(torch, n, substeps, steps, warmup=10):
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         ret = info["episode_return"]
+        # the policy's two torch kernels alone, same stream, same shapes: what the loop costs without the env in it
+        for _ in range(warmup):
+            (ob.reshape(n, 5) @ w).argmax(dim=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            (ob.reshape(n, 5) @ w).argmax(dim=1)
+        torch.cuda.synchronize()
+        el_policy = time.perf_counter() - t0
     d_act = torch.zeros(n, dtype=torch.int32, device="cuda")
     km, _, _ = kernel_time(env.propagator, d_act.data_ptr(), substeps, 16 if substeps > 1 else 64)
     assert bool(torch.isfinite(ret).all())
     env.close()
     return {"env_steps_per_s": n * steps / el, "ms_per_step": el / steps * 1e3, "kernel_ms": km,
             "kernel_env_steps_per_s": n / (km * 1e-3), "loop_over_kernel_rate": (n * steps / el) / (n / (km * 1e-3)),
-            "steps": steps, "torch_kernels_per_step": 2,
+            "steps": steps, "torch_kernels_per_step": 2, "policy_only_ms_per_step": el_policy / steps * 1e3,
+            "env_share_over_kernel": ((el - el_policy) / steps * 1e3) / km,
+            "note": "loop time minus the policy's own two kernels, over the step kernel's time: what the env adds per step beyond its "
+                    "kernel (1.0 = nothing); the loop captured in a HIP graph runs at the eager loop's rate (tools/exp/rl_graph.py, "
+                    "tests/test_gpu_device_surface.py): it is bound by the three dependent kernels, not by launches",
             "policy": "obs(N,5) @ W(5,3) -> argmax (int64, consumed in place), torch on the env's (non-default) stream; episode returns / lengths / done byte kept by the step kernel",
             "env": "LeoPowerAttVecEnv.step_tensors, full reference scenario, J2 + 4 wheels, device IC pool 4096 (Philox), device-side auto-reset"}
 

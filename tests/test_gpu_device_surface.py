@@ -201,6 +201,61 @@ def test_on_device_policy_loop_runs_without_host_sync():
     env.close()
 
 
+def test_step_tensors_loop_is_hip_graph_capturable():
+    """The device-resident loop - policy kernels + step kernel + device-side auto-reset - captured in a HIP graph and replayed
+    gives exactly what the eager loop gives: step_tensors launches on the capturing stream and issues nothing a capture
+    forbids (no copy, no synchronisation, no allocation)."""
+    import torch
+    n, U, reps = 1000, 5, 8
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        def make():
+            probe = LeoPowerAttVecEnv(n, n_rw=4, step_duration=1.0, seed=3, device_reset_pool=128, device_sampler=True)
+            cfg = probe.cfg
+            probe.close()
+            cfg.max_length = 7                 # episodes end - and restart on the device - inside the replayed graphs
+            env = LeoPowerAttVecEnv(n, cfg=cfg, step_duration=1.0, seed=3, device_reset_pool=128, device_sampler=True, stream=side.cuda_stream)
+            env.reset_tensors()
+            return env
+        g = torch.Generator(device="cuda").manual_seed(0)
+        w = torch.randn(5, 3, dtype=torch.float64, device="cuda", generator=g)
+        act = torch.zeros(n, dtype=torch.int64, device="cuda")
+        logits = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+
+        def one(env):
+            torch.matmul(env._torch_views()["obs_n51"].reshape(n, 5), w, out=logits)
+            torch.argmax(logits, dim=1, out=act)
+            return env.step_tensors(act)
+
+        env = make()
+        for _ in range(U * (reps + 1)):
+            ob, rew, done, info = one(env)
+        torch.cuda.synchronize()
+        want = [t.clone() for t in (ob, rew, info["episode_return"], info["episodes"])]
+        env.close()
+
+        env = make()
+        for _ in range(U):                     # warm-up: torch's lazy initialisation must not happen inside the capture
+            one(env)
+        torch.cuda.synchronize()
+        c0 = env.propagator.debug_counters()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            for _ in range(U):
+                ob, rew, done, info = one(env)
+        for _ in range(reps - 1):              # (the capture itself executed nothing)
+            graph.replay()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert env.propagator.debug_counters() == c0
+        got = [ob, rew, info["episode_return"], info["episodes"]]
+        assert int(info["episodes"].sum()) > 0
+        for a, b in zip(want, got):
+            assert torch.equal(a, b)
+        del graph
+        env.close()
+
+
 def test_device_views_dlpack_and_cuda_array_interface_alias_the_buffers():
     import torch
     n = 200

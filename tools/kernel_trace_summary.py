@@ -98,7 +98,7 @@ def main():
             with open(os.path.join(outdir, rec["csv"]), "w") as f:
                 f.write("dispatch,start_offset_us,duration_ns\n")
                 for i, (s, dd) in enumerate(dur):
-                    f.write("%d,%.1f,%d\n" % (i, s / 1e3, dd))
+                    f.write("%d,%.3f,%d\n" % (i, s / 1e3, dd))
             st = sorted(glob.glob(os.path.join(p, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
             if st:
                 with open(st[-1]) as src, open(os.path.join(outdir, rec["stats_csv"]), "w") as dst:
