@@ -1,4 +1,6 @@
 """GPU: full-scenario kernel (power + Sun third body + drag) against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -52,6 +54,64 @@ def test_full_scenario_matches_oracle(n_rw, grav, flags, scale):
         oracle.step(cfg, st1, s1, t1, np.ones(n, np.int32), 138)
         assert np.abs(st1[3:6] - st2[3:6]).max() > 1e-6
     prop.close()
+
+
+def _forced(cfg, n, **env):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return BatchedPropagator(cfg, n)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def test_density_increment_and_its_guard_match_oracle_in_every_form():
+    """The kernels advance the density along the trajectory (rho' = rho e^d, degree-6 polynomial, a full evaluation per chunk
+    of ticks and for any lane whose exponent jumps by more than 2^-6: bsk_device.hpp Atmo).  With 1 s dyn ticks and a 20 km
+    scale height the reference's orbits (radial velocity up to 380 m/s) put lanes on BOTH sides of the guard inside the same
+    waves; the oracle evaluates libm's exp every tick.  All three forms of the kernel must agree bit for bit."""
+    n, n_rw = 300, 4
+    cfg = default_config(n_rw, GRAV_PM_J2)
+    cfg.flags |= FLAG_POWER | FLAG_SUN_THIRD_BODY | FLAG_DRAG
+    cfg.dt = 1.0
+    cfg.base_density, cfg.scale_height = 1e-4, 20e3            # 1e-15 kg/m^3 at 500 km, 6e-8 at the lowest perigees (150 km)
+    ic = sample_ic_batch(n, n_rw, seed=123)
+    r, v = ic[0:3], ic[3:6]
+    d = np.abs((r * v).sum(axis=0) / np.linalg.norm(r, axis=0)) * cfg.dt / cfg.scale_height
+    assert (d > 2.0 ** -6).sum() > 10 and (d < 2.0 ** -6).sum() > 100      # both paths are taken
+    props = [_forced(cfg, n, BSKGPU_PAIR="0", BSKGPU_TRI="0"), _forced(cfg, n, BSKGPU_PAIR="1", BSKGPU_TRI="0"),
+             _forced(cfg, n, BSKGPU_PAIR="0", BSKGPU_TRI="1")]
+    for p in props:
+        p.reset(ic)
+    st = ic.copy()
+    steps, ticks = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    rng = np.random.default_rng(9)
+    for k in (7, 60, 23):
+        act = rng.integers(0, 2, n).astype(np.int32)
+        oracle.step(cfg, st, steps, ticks, act, k)
+        states = []
+        for p in props:
+            p.step(act, k)
+            states.append(p.get_state())
+        errs = max_group_err(states[0], st, n_rw)
+        assert max(errs.values()) < 1e-11, errs
+        assert np.array_equal(states[0], states[1]) and np.array_equal(states[0], states[2])
+        assert len({p.kernel_info()["name"] for p in props}) == 3, [p.kernel_info()["name"] for p in props]   # (the form of the last launch)
+    # the drag acted, and strongly somewhere: the lowest perigee lost speed against a drag-free twin
+    cfg2 = default_config(n_rw, GRAV_PM_J2)
+    cfg2.flags |= FLAG_POWER | FLAG_SUN_THIRD_BODY
+    cfg2.dt = 1.0
+    st2 = ic.copy()
+    oracle.step(cfg2, st2, np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32), 90)
+    st1 = ic.copy()
+    oracle.step(cfg, st1, np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32), 90)
+    assert np.abs(st1[3:6] - st2[3:6]).max() > 1e-3
+    for p in props:
+        p.close()
 
 
 def test_full_scenario_matches_golden(golden):
