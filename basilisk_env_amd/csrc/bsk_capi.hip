@@ -400,7 +400,6 @@ struct bsk_handle {
     double* d_reward = nullptr;
     unsigned long long* d_done_mask = nullptr;
     unsigned char* d_reason = nullptr;
-    double* d_wave_reward = nullptr;
     double* d_stat_sum = nullptr;
     long long* d_stat_done = nullptr;
     // masked-reset staging
@@ -430,6 +429,8 @@ struct bsk_handle {
     double* d_obs_rm = nullptr;
     unsigned long long* d_dbg = nullptr;   // one word per wave for probe builds (bsk_probes.hpp)
     double* d_stats2 = nullptr;   // {sum of rewards, number of done envs} of the last step, as two doubles (all-reduce operand)
+    bool stats_fresh = false;     // d_stat_sum / d_stat_done / d_stats2 hold the LAST STEP's batch scalars (snapshot_stats)
+    bool stepped = false;         // some step has run since the handle was created
     // error word the kernels can raise (page-locked host memory, device-visible): checked by every synchronising entry point
     int* h_err = nullptr;
     // bare levels: no spacecraft of the batch / of the reset pool started its episode with an empty battery (bsk_launch.hpp:
@@ -513,6 +514,16 @@ bsk::ResetOut reset_out(const bsk_handle* h) {
     return ro;
 }
 
+// The batch scalars of the last step (sum of rewards, number of done envs) are formed from the reward buffer and the done
+// ballots by a kernel of their own, once, when somebody asks - or just before a reset entry point overwrites the restarted
+// envs' rewards with zeros (the vec env auto-resets BEFORE a training loop reads the step's statistics).
+static int snapshot_stats(bsk_handle* h) {
+    if (h->stats_fresh) return BSK_OK;
+    HIP_TRY(bsk::launch_stats(h->d_reward, h->n, h->d_done_mask, (h->n + 63) / 64, h->d_stat_sum, h->d_stat_done, h->d_stats2, h->stream));
+    h->stats_fresh = true;
+    return BSK_OK;
+}
+
 // After a stream synchronisation: has a kernel raised the handle's error word?  (bsk_device.hpp: BSK_DEVERR_*)
 int check_device_error(bsk_handle* h) {
     if (!h->h_err) return BSK_OK;
@@ -544,7 +555,6 @@ int do_step(bsk_handle* h, const void* d_actions, int substeps, int act_shift) {
     b.reward = h->d_reward;
     b.done_mask = h->d_done_mask;
     b.reason = h->d_reason;
-    b.wave_reward = h->d_wave_reward;
     b.stride = h->stride;
     b.n = h->n;
     b.substeps = substeps;
@@ -581,6 +591,8 @@ int do_step(bsk_handle* h, const void* d_actions, int substeps, int act_shift) {
     h->last_pair = h->sp.pair != 0;
     h->last_tri = h->sp.tri != 0;
     HIP_TRY(bsk::launch_step(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp.feat, h->sp, b, h->block, h->stream, e0, e1));
+    h->stats_fresh = false;
+    h->stepped = true;
     return BSK_OK;
 }
 
@@ -762,7 +774,6 @@ int bsk_create(const bsk_config* cfg, int n_envs, int device_id, void* stream, b
     if (e == hipSuccess) e = alloc((void**)&h->d_reward, (size_t)S * sizeof(double));
     if (e == hipSuccess) e = alloc((void**)&h->d_done_mask, (size_t)(S / 64) * sizeof(unsigned long long));
     if (e == hipSuccess) e = alloc((void**)&h->d_reason, (size_t)S);
-    if (e == hipSuccess) e = alloc((void**)&h->d_wave_reward, (size_t)(S / 64) * sizeof(double));
     if (e == hipSuccess) e = alloc((void**)&h->d_stat_sum, sizeof(double));
     if (e == hipSuccess) e = alloc((void**)&h->d_stat_done, sizeof(long long));
     if (e == hipSuccess) e = alloc((void**)&h->d_stats2, 2 * sizeof(double));
@@ -798,7 +809,7 @@ void bsk_destroy(bsk_handle* h) {
     for (hipEvent_t ev : h->ev_warm)
         if (ev) (void)hipEventDestroy(ev);
     void* bufs[] = {h->d_state, h->d_cnt, h->d_act, h->d_obs, h->d_reward, h->d_done_mask, h->d_reason,
-                    h->d_wave_reward, h->d_stat_sum, h->d_stat_done, h->d_ic_stage, h->d_idx_stage, h->d_mask_stage, h->d_cold, h->d_sh_tab, h->d_sh_tab4, h->d_pool, h->d_term_obs, h->d_episodes,
+                    h->d_stat_sum, h->d_stat_done, h->d_ic_stage, h->d_idx_stage, h->d_mask_stage, h->d_cold, h->d_sh_tab, h->d_sh_tab4, h->d_pool, h->d_term_obs, h->d_episodes,
                     h->d_ep_return, h->d_term_return, h->d_term_len, h->d_done, h->d_obs_rm, h->d_stats2, h->d_dbg};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
@@ -851,6 +862,7 @@ int bsk_n_fields(const bsk_handle* h) { return h ? h->nf : BSK_EINVAL; }
 int bsk_reset(bsk_handle* h, const uint8_t* mask, const double* ic) {
     if (!h || !ic) return fail(BSK_EINVAL, "handle/ic is NULL");
     DeviceGuard guard(h->device);
+    if (h->stepped) { int rc = snapshot_stats(h); if (rc) return rc; }   // the last step's batch scalars, before its rewards are overwritten
     const size_t row = (size_t)h->n * sizeof(double);
     const double* ic_charge = ic + (size_t)(BSK_NF_BASE + h->cfg.n_rw + BSK_T_CHARGE) * h->n;
     if (!mask) {
@@ -966,8 +978,7 @@ int bsk_get_state_device(bsk_handle* h, double** d_state, int64_t* stride) {
 int bsk_get_batch_stats(bsk_handle* h, double* reward_sum, int64_t* n_done) {
     if (!h) return fail(BSK_EINVAL, "handle is NULL");
     DeviceGuard guard(h->device);
-    const int n_waves = (h->n + 63) / 64;
-    HIP_TRY(bsk::launch_stats(h->d_wave_reward, h->d_done_mask, n_waves, h->d_stat_sum, h->d_stat_done, h->stream));
+    { int rc = snapshot_stats(h); if (rc) return rc; }
     double s = 0;
     long long d = 0;
     HIP_COPY(hipMemcpyAsync(&s, h->d_stat_sum, sizeof s, hipMemcpyDeviceToHost, h->stream));
@@ -1073,6 +1084,7 @@ int bsk_reset_from_pool(bsk_handle* h, const uint8_t* mask) {
     if (!h) return fail(BSK_EINVAL, "handle is NULL");
     if (h->n_pool == 0) return fail(BSK_EINVAL, "no IC pool staged (bsk_set_ic_pool / bsk_sample_ic_pool)");
     DeviceGuard guard(h->device);
+    if (h->stepped) { int rc = snapshot_stats(h); if (rc) return rc; }   // the last step's batch scalars, before its rewards are overwritten
     unsigned char* d_mask = nullptr;
     if (mask) {
         if (!h->d_mask_stage) HIP_TRY(hipMalloc(&h->d_mask_stage, (size_t)h->stride));   // kept for the handle's lifetime
@@ -1090,6 +1102,7 @@ int bsk_reset_from_pool_device(bsk_handle* h, const uint8_t* d_mask) {
     if (!h) return fail(BSK_EINVAL, "handle is NULL");
     if (h->n_pool == 0) return fail(BSK_EINVAL, "no IC pool staged (bsk_set_ic_pool / bsk_sample_ic_pool)");
     DeviceGuard guard(h->device);
+    if (h->stepped) { int rc = snapshot_stats(h); if (rc) return rc; }   // the last step's batch scalars, before its rewards are overwritten
     HIP_TRY(bsk::launch_reset_from_pool(h->d_state, h->stride, h->nf, h->d_pool, h->n_pool, d_mask, h->n, h->d_cnt,
                                         h->d_episodes, h->env_base, reset_out(h), h->stream));
     h->charge_pos = (d_mask ? h->charge_pos : true) && h->pool_charge_pos;
@@ -1110,7 +1123,7 @@ int bsk_get_episode_device(bsk_handle* h, double** d_ep_return, double** d_term_
 int bsk_get_batch_stats_device(bsk_handle* h, double** d_stats2) {
     if (!h || !d_stats2) return fail(BSK_EINVAL, "handle/d_stats2 is NULL");
     DeviceGuard guard(h->device);
-    HIP_TRY(bsk::launch_stats2(h->d_wave_reward, h->d_done_mask, (h->n + 63) / 64, h->d_stats2, h->stream));
+    { int rc = snapshot_stats(h); if (rc) return rc; }
     *d_stats2 = h->d_stats2;
     return BSK_OK;       // asynchronous: the two doubles are valid once the handle's stream has reached this point
 }

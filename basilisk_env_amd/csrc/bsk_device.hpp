@@ -105,7 +105,12 @@ __device__ __forceinline__ gptr<T> uniform_ptr(T* p) {
 __device__ __forceinline__ double ldf(const double* __restrict__ base, uint32_t boff) {
     return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + boff);
 }
+// (stores: the zero-extension of the offset has to be visible in the store's own basic block for the saddr form to be
+// selected; left to itself it is computed once at the top of the kernel, every store then adds a 64-bit register pair to
+// its base - one VALU instruction per store - and takes the vaddr form.  The empty asm makes each use's offset a value of
+// its own.)
 __device__ __forceinline__ void stf(gptr<double> base, uint32_t boff, double v) {
+    asm("" : "+v"(boff));
     *(gptr<double>)((gptr<char>)base + boff) = v;
 }
 

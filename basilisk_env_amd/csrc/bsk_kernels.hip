@@ -6,9 +6,9 @@
 //   SPLIT form of the harmonics evaluation (bsk_device.hpp: 1 scalar stream, 4 / 5 DPP broadcast with one / two waves)
 //   HBM layout: structure-of-arrays fp64, field f of env i at st[f*stride + i]; a wave reads 512
 //   contiguous bytes per field (global_load_dwordx2 per lane, fully coalesced), state lives in
-//   VGPRs for all `substeps` RK4 steps, and is written back once.  Reward / done are reduced per
-//   wavefront: __ballot gives the 64-bit done mask (one store per wave), a shuffle tree gives
-//   the wave's reward sum (one store per wave) — no atomics, bitwise reproducible.
+//   VGPRs for all `substeps` RK4 steps, and is written back once.  The done flags are reduced per
+//   wavefront (__ballot: one 64-bit mask, one store per wave); the batch's reward sum is formed by stats_kernel
+//   from the reward buffer when somebody asks for it — no atomics, bitwise reproducible.
 // sample_pool_kernel / reset_from_pool_kernel: on-device IC sampler and reset (row f4).
 // stats_kernel: deterministic batch scalars.  scatter_reset_kernel: masked reset from host ICs.
 //
@@ -906,7 +906,6 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
     }
     // wavefront reductions (every lane of the wave participates; tail lanes contribute nothing)
     const unsigned long long dmask = __ballot(valid2 && why != 0);
-    const double rsum = wave_sum(valid2 ? rew : 0.0);
     if constexpr (probe::ANY) {
         // probe builds (bsk_probes.hpp): one 64-bit word per wave in the handle's debug buffer - never in the done mask
         unsigned long long w = 0ull;
@@ -924,7 +923,6 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
     }
     if ((threadIdx.x & 63) == 0) {
         ta.done_mask[gid >> 6] = dmask;
-        ta.wave_reward[gid >> 6] = rsum;
     }
 
     // Tail lanes shadow env n-1 and computed bit-identical results from identical inputs, so their
@@ -1025,19 +1023,28 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
     }
 }
 
-// Deterministic batch scalars from the per-wave partials: one 256-thread workgroup, fixed order.
-__global__ __launch_bounds__(256) void stats_kernel(const double* __restrict__ wave_reward,
+// Deterministic batch scalars, one 256-thread workgroup, fixed order: sum of the last step's rewards and number of finished
+// envs.  The step kernel used to leave a per-wave reward sum for this (a six-stage butterfly through the LDS crossbar in every
+// launch's epilogue - a third of a microsecond on the critical path of a 6.5 us launch, for a number asked for once per
+// rollout); now this kernel forms the same sums from the reward buffer itself: wave w of the step kernel = rewards
+// [64 w, 64 w + 64), the same xor butterfly, then - as before - thread t of 256 adds the waves w = t (mod 256) in ascending
+// order and a halving tree joins the 256 partials.  Same operations in the same order: the same bits.
+__global__ __launch_bounds__(256) void stats_kernel(const double* __restrict__ reward, int n,
                                                     const unsigned long long* __restrict__ done_mask, int n_waves,
-                                                    double* out_sum, long long* out_done) {
+                                                    double* out_sum, long long* out_done, double* out2) {
     __shared__ double sr[256];
     __shared__ long long sd[256];
-    double r = 0.0;
-    long long d = 0;
-    for (int w = threadIdx.x; w < n_waves; w += 256) {
-        r += wave_reward[w];
-        d += __popcll(done_mask[w]);
+    const int lane = (int)(threadIdx.x & 63u), hw = (int)(threadIdx.x >> 6);
+    sr[threadIdx.x] = 0.0;
+    __syncthreads();
+    // hardware wave k takes the step kernel's waves w = k (mod 4): their slots w mod 256 are disjoint from the other waves'
+    for (int w = hw; w < n_waves; w += 4) {
+        const int i = 64 * w + lane;
+        const double ws = wave_sum(i < n ? reward[i] : 0.0);
+        if (lane == 0) sr[w & 255] += ws;
     }
-    sr[threadIdx.x] = r;
+    long long d = 0;
+    for (int w = threadIdx.x; w < n_waves; w += 256) d += __popcll(done_mask[w]);
     sd[threadIdx.x] = d;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
@@ -1048,8 +1055,9 @@ __global__ __launch_bounds__(256) void stats_kernel(const double* __restrict__ w
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        if (out_done) { *out_sum = sr[0]; *out_done = sd[0]; }
-        else { out_sum[0] = sr[0]; out_sum[1] = (double)sd[0]; }   // {sum reward, #done} as two doubles: one all-reduce operand
+        *out_sum = sr[0];
+        *out_done = sd[0];
+        out2[0] = sr[0]; out2[1] = (double)sd[0];   // {sum reward, #done} as two doubles: one all-reduce operand
     }
 }
 
@@ -1226,7 +1234,7 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     a.power = p.pc;
     a.extra = p.ex;
     a.tail.obs_cfg = p.obs; a.tail.st = b.st; a.tail.cnt = b.cnt; a.tail.obs = b.obs; a.tail.reward = b.reward;
-    a.tail.done_mask = b.done_mask; a.tail.reason = b.reason; a.tail.wave_reward = b.wave_reward;
+    a.tail.done_mask = b.done_mask; a.tail.reason = b.reason;
     a.tail.stride = b.stride; a.tail.n = b.n; a.tail.substeps = b.substeps;
     a.tail.pool = b.pool; a.tail.term_obs = b.term_obs; a.tail.episodes = b.episodes;
     a.tail.n_pool = b.n_pool; a.tail.n_fields = b.n_fields;
@@ -1346,14 +1354,9 @@ const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat, int sh_form,
     return nullptr;
 }
 
-hipError_t launch_stats(const double* wave_reward, const unsigned long long* done_mask, int n_waves, double* out_sum,
-                        long long* out_done, hipStream_t s) {
-    hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(256), 0, s, wave_reward, done_mask, n_waves, out_sum, out_done);
-    return hipGetLastError();
-}
-
-hipError_t launch_stats2(const double* wave_reward, const unsigned long long* done_mask, int n_waves, double* out2, hipStream_t s) {
-    hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(256), 0, s, wave_reward, done_mask, n_waves, out2, (long long*)nullptr);
+hipError_t launch_stats(const double* reward, int n, const unsigned long long* done_mask, int n_waves, double* out_sum,
+                        long long* out_done, double* out2, hipStream_t s) {
+    hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(256), 0, s, reward, n, done_mask, n_waves, out_sum, out_done, out2);
     return hipGetLastError();
 }
 

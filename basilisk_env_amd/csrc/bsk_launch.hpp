@@ -19,7 +19,6 @@ struct TailArgs {
     double* reward;                // [stride]
     unsigned long long* done_mask; // [stride/64], one 64-bit ballot per wavefront
     unsigned char* reason;         // [stride]
-    double* wave_reward;           // [stride/64]
     int64_t stride;
     int n;
     int substeps;
@@ -100,7 +99,6 @@ struct StepBuffers {
     double* reward;
     unsigned long long* done_mask;
     unsigned char* reason;
-    double* wave_reward;
     int64_t stride;
     int n;
     int substeps;
@@ -144,9 +142,8 @@ hipError_t launch_reset_from_pool(double* st, int64_t stride, int nf, const doub
 // first observation [|sigma_BN|, |omega|, |Omega|/limit, charge/3600/power_max, 1], zero reward / reason / done / episode
 // return of freshly reset envs: all n (idx == NULL) or the m listed ones
 hipError_t launch_init_outputs(const double* st, int64_t stride, const int* idx, int m, const ResetOut& ro, hipStream_t s);
-hipError_t launch_stats2(const double* wave_reward, const unsigned long long* done_mask, int n_waves, double* out2, hipStream_t s);
-hipError_t launch_stats(const double* wave_reward, const unsigned long long* done_mask, int n_waves, double* out_sum,
-                        long long* out_done, hipStream_t s);
+hipError_t launch_stats(const double* reward, int n, const unsigned long long* done_mask, int n_waves, double* out_sum,
+                        long long* out_done, double* out2, hipStream_t s);
 hipError_t launch_scatter_reset(double* st, int64_t stride, int nf, const double* ic, const int* idx, int m, int2* cnt,
                                 hipStream_t s);
 

@@ -245,8 +245,10 @@ int bsk_get_stream(bsk_handle* h, void** stream);
 int bsk_get_terminal_obs_device(bsk_handle* h, double** d_term_obs, int32_t** d_episodes);
 int bsk_get_state_device(bsk_handle* h, double** d_state, int64_t* stride);
 
-/* Batch scalars produced with wavefront reductions: sum of rewards and number of done envs
- * of the last step (synchronises). */
+/* Batch scalars of the LAST STEP: sum of its rewards and number of done envs, formed in a fixed order (bitwise
+ * reproducible) from the reward buffer and the per-wave done ballots by a small kernel of their own - once, when first asked
+ * for, or just before a reset entry point zeroes the restarted envs' rewards; the step kernel's epilogue carries no reward
+ * reduction.  (Synchronises.) */
 int bsk_get_batch_stats(bsk_handle* h, double* reward_sum, int64_t* n_done);
 /* The same two scalars left ON the device as f64[2] = {sum of rewards, number of done envs}, enqueued on the handle's stream
  * without synchronising: the operand of the one all-reduce a sharded batch needs. */

@@ -201,6 +201,42 @@ def test_on_device_policy_loop_runs_without_host_sync():
     env.close()
 
 
+def test_batch_stats_are_the_last_steps_whatever_was_reset_since():
+    """bsk_get_batch_stats* = sum of rewards and number of finished envs of the LAST STEP.  They are formed from the reward
+    buffer by a kernel of their own (the step kernel's epilogue carries no reward reduction), so every reset entry point
+    takes the snapshot before it zeroes the restarted envs' rewards: the vec env auto-resets before a loop reads them."""
+    n = 777
+    cfg = default_config(4, GRAV_PM_J2)
+    cfg.max_length = 2
+    cfg.flags |= FLAG_AUTO_RESET          # (a pool may be staged; with max_length reached the kernel itself restarts envs too)
+    p = BatchedPropagator(cfg, n)
+    ic = sample_ic_batch(n, 4, seed=11)
+    p.reset(ic)
+    p.set_ic_pool(sample_ic_batch(64, 4, seed=12))
+    rng = np.random.default_rng(2)
+    assert p.batch_stats() == (0.0, 0)                       # before any step
+    for _ in range(3):
+        p.step(rng.integers(0, 3, n).astype(np.int32), 4)
+    obs, rew, done, why = p.get_obs()
+    want_s, want_d = float(rew.sum()), int((why != 0).sum())
+    assert want_d == n and want_s != 0.0                     # (max_length reached: every env finished in the last step)
+    mask = (rng.random(n) < 0.5).astype(np.uint8)
+    p.reset(sample_ic_batch(n, 4, seed=13), mask)            # host ICs, masked: zeroes those envs' rewards
+    assert np.all(p.get_obs()[1][mask.astype(bool)] == 0.0)
+    s1, d1 = p.batch_stats()
+    assert abs(s1 - want_s) < 1e-12 * n and d1 == want_d
+    p.reset_from_pool(mask)                                  # pool, masked
+    p.reset_from_pool_device(0)                              # pool, all, asynchronous
+    p.reset(ic)                                              # everything
+    assert np.all(p.get_obs()[1] == 0.0)
+    assert p.batch_stats() == (s1, d1)                       # still the last step's, bit for bit
+    p.step(np.zeros(n, np.int32), 1)
+    obs, rew, done, why = p.get_obs()
+    s2, d2 = p.batch_stats()
+    assert abs(s2 - float(rew.sum())) < 1e-12 * n and d2 == int((why != 0).sum()) and (s2, d2) != (s1, d1)
+    p.close()
+
+
 def test_step_tensors_loop_is_hip_graph_capturable():
     """The device-resident loop - policy kernels + step kernel + device-side auto-reset - captured in a HIP graph and replayed
     gives exactly what the eager loop gives: step_tensors launches on the capturing stream and issues nothing a capture
