@@ -237,6 +237,43 @@ def test_batch_stats_are_the_last_steps_whatever_was_reset_since():
     p.close()
 
 
+def _stats_order(rew):
+    """bsk_get_batch_stats' reward sum, operation for operation (stats_kernel): per 64 envs an xor butterfly, wave w into slot
+    w mod 256 in ascending order, then a halving tree over the 256 slots."""
+    n = len(rew)
+    nw = (n + 63) // 64
+    v = np.zeros(nw * 64)
+    v[:n] = rew
+    v = v.reshape(nw, 64)
+    idx = np.arange(64)
+    for off in (32, 16, 8, 4, 2, 1):
+        v = v + v[:, idx ^ off]
+    ws = v[:, 0]
+    slots = np.zeros(256)
+    for w in range(nw):
+        slots[w & 255] += ws[w]
+    off = 128
+    while off:
+        slots[:off] += slots[off:2 * off]
+        off >>= 1
+    return float(slots[0])
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 20000])
+def test_batch_stats_reward_sum_has_a_fixed_order(n):
+    """Bitwise reproducible: the sum is the documented tree, whatever the batch size."""
+    cfg = default_config(4, GRAV_PM_J2)
+    p = BatchedPropagator(cfg, n)
+    p.reset(sample_ic_batch(n, 4, seed=21))
+    rng = np.random.default_rng(3)
+    for k in (1, 3):
+        p.step(rng.integers(0, 3, n).astype(np.int32), k)
+        s, d = p.batch_stats()
+        obs, rew, done, why = p.get_obs()
+        assert s == _stats_order(rew) and d == int((why != 0).sum())
+    p.close()
+
+
 def test_step_tensors_loop_is_hip_graph_capturable():
     """The device-resident loop - policy kernels + step kernel + device-side auto-reset - captured in a HIP graph and replayed
     gives exactly what the eager loop gives: step_tensors launches on the capturing stream and issues nothing a capture
