@@ -25,14 +25,17 @@ def _tool():
 def test_no_dpp_hazard_in_the_built_library():
     assert os.path.exists(LIB), "build the library first (__graft_entry__.build())"
     d = _tool()
-    total, bad = 0, []
+    total, bad, tbad = 0, [], []
     with tempfile.TemporaryDirectory() as tmp:
         for text in d.disassemble(LIB, tmp):
-            n, b = d.check(d.parse(text))
+            funcs = d.parse(text)
+            n, b = d.check(funcs)
             total += n
             bad += b
+            tbad += d.check_trans(funcs)       # (the other hazard an inline-asm consumer could hide: a transcendental's result read at once)
     assert total > 1000, "the scenario kernels' DPP instructions were not found: %d" % total
     assert not bad, "%d DPP hazards, first: %s" % (len(bad), bad[0])
+    assert not tbad, "%d transcendental forwarding hazards, first: %s" % (len(tbad), tbad[0])
 
 
 def test_the_padding_pass_finds_and_fixes_a_planted_hazard():

@@ -133,19 +133,50 @@ def check(funcs):
     return n_dpp, bad
 
 
+TRANS = re.compile(r"v_(rcp|rsq|sqrt|exp|log|sin|cos)(_iflag|_clamp|_legacy)?_f(16|32|64)")
+
+
+def check_trans(funcs):
+    """gfx940+ forwarding hazard: a VALU instruction must not read a transcendental's result in the very next issue slot
+    (one wait state).  The compiler pads its own instructions; an inline-asm consumer it would not see.  Checked for EVERY
+    VALU consumer (fall-through only: a branch in between is a wait state)."""
+    bad = []
+    for name, ins in funcs.items():
+        for i in range(1, len(ins)):
+            a0, op0, ops0, _ = ins[i - 1]
+            a1, op1, ops1, _ = ins[i]
+            if not TRANS.match(op0) or not op1.startswith("v_") or not ops0:
+                continue
+            w = regs(ops0[0])
+            if not w:
+                continue
+            for t in ops1[1:]:
+                r = regs(t.split()[0])
+                if r and (r & w):
+                    bad.append((name, ins[i - 1], ins[i]))
+                    break
+    return bad
+
+
 def main():
     rc = 0
     for lib in sys.argv[1:]:
         with tempfile.TemporaryDirectory() as tmp:
             total, allbad = 0, []
+            tbad = []
             for text in disassemble(lib, tmp):
-                n, bad = check(parse(text))
+                funcs = parse(text)
+                n, bad = check(funcs)
                 total += n
                 allbad += bad
+                tbad += check_trans(funcs)
         print("%s: %d DPP instructions, %d hazards" % (lib, total, len(allbad)))
         for name, w, d in allbad[:40]:
             print("  %s\n    %x: %s %s\n    %x: %s %s" % (name, w[0], w[1], ", ".join(w[2]), d[0], d[1], ", ".join(d[2])))
-        if allbad:
+        print("%s: %d transcendental results read in the next issue slot" % (lib, len(tbad)))
+        for name, w, d in tbad[:20]:
+            print("  %s\n    %x: %s %s\n    %x: %s %s" % (name, w[0], w[1], ", ".join(w[2]), d[0], d[1], ", ".join(d[2])))
+        if allbad or tbad:
             rc = 1
     return rc
 
