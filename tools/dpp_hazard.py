@@ -110,8 +110,6 @@ def check(funcs):
                         return k
                     if op.startswith("v_cmpx") and ws < need_e:
                         return k
-                    if op in ("v_readlane_b32", "v_readfirstlane_b32"):
-                        pass
                 step = 1
                 if op == "s_nop":
                     step = int(ops[0], 0) + 1
