@@ -614,6 +614,26 @@ def main():
         from basilisk_env_amd._lib import FLAG_DESAT, FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY
         cfg.flags |= FLAG_POWER | FLAG_SUN_THIRD_BODY | FLAG_DRAG | FLAG_DESAT
 
+    def dense_drag_edit(cfg):
+        """1 s dyn ticks under a thin-scale-height atmosphere: strong drag at 200 km, and the density's exponent moves by up to
+        0.02 per tick - both sides of the kernels' increment guard (bsk_device.hpp: Atmo; the oracle and this generator evaluate
+        the exponential every tick)"""
+        from basilisk_env_amd._lib import FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY
+        cfg.flags |= FLAG_POWER | FLAG_SUN_THIRD_BODY | FLAG_DRAG
+        cfg.dt = 1.0
+        cfg.base_density, cfg.scale_height = 1e-4, 20e3
+
+    def low_perigee_ic(cfg, ic):
+        """envs 0..3 at 180 - 260 km with radial velocities of +-380 / +-250 m/s (the others keep their sampled 500 km orbits)"""
+        for e, (alt, vr, ang) in enumerate(((180e3, 380.0, 0.3), (220e3, -380.0, 1.7), (260e3, 250.0, 3.1), (200e3, -250.0, 4.9))):
+            rhat = np.array([np.cos(ang), np.sin(ang) * 0.8, np.sin(ang) * 0.6])
+            rhat /= np.linalg.norm(rhat)
+            that = np.cross([0.3, -0.5, 0.8], rhat)
+            that /= np.linalg.norm(that)
+            rm = cfg.req + alt
+            ic[0:3, e] = rm * rhat
+            ic[3:6, e] = np.sqrt(cfg.mu / rm) * that + vr * rhat
+
     def penumbra_ic(cfg, ic):
         """envs 0..3 fly through the penumbra band behind the Earth during the run (the others keep their
         sampled orbits); env 3 starts with a nearly empty battery"""
@@ -645,6 +665,10 @@ def main():
         # row f2: desaturation (action 2 on envs whose wheel momentum exceeds hs_min), full scenario otherwise
         ("desat_rw3", lambda: run_case("desat_rw3", 3, GRAV_PM, 6, 16, [(np.array([2, 2, 0, 2, 1, 2]), k) for k in (7, 43, 100, 150)],
                                        cfg_edit=desat_edit)),
+        # the density along a fast radial motion (round 4: the kernels advance it incrementally): J2, 1 s ticks, no wheels (with
+        # them the reference's gains at a 10 s control period are an unstable loop that amplifies rounding to 5e-9 in 300 steps)
+        ("drag_dt1_norw", lambda: run_case("drag_dt1_norw", 0, GRAV_PM_J2, 6, 17, [(np.array([0, 1, 0, 1, 0, 0]), k) for k in (1, 9, 90, 200)],
+                                           cfg_edit=dense_drag_edit, ic_edit=low_perigee_ic)),
         ("sh8_rw3", lambda: run_case("sh8_rw3", 3, GRAV_SH, 4, 14, [(np.array([0, 1, 2, 0]), k) for k in (1, 9, 90, 300)],
                                      cfg_edit=sh_edit, sh=(8, cb, sb))),
     ]

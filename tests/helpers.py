@@ -29,6 +29,10 @@ def cfg_for_case(case):
     if case.get("cfg_edit") == "scenario_edit":
         cfg.flags |= FLAG_POWER | FLAG_SUN_THIRD_BODY | FLAG_DRAG
         cfg.base_density, cfg.scale_height = 1e-9, 100e3
+    if case.get("cfg_edit") == "dense_drag_edit":
+        cfg.flags |= FLAG_POWER | FLAG_SUN_THIRD_BODY | FLAG_DRAG
+        cfg.dt = 1.0
+        cfg.base_density, cfg.scale_height = 1e-4, 20e3
     if case.get("cfg_edit") == "desat_edit":
         from basilisk_env_amd._lib import FLAG_DESAT
         cfg.flags |= FLAG_POWER | FLAG_SUN_THIRD_BODY | FLAG_DRAG | FLAG_DESAT

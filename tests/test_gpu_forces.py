@@ -139,6 +139,28 @@ def test_full_scenario_matches_golden(golden):
     prop.close()
 
 
+@pytest.mark.parametrize("form", ["single", "pair", "tri"])
+def test_dense_drag_at_one_second_ticks_matches_golden(golden, form):
+    """Strong drag (180 - 330 km under a 20 km scale height) with the density's exponent moving by up to 0.02 per 1 s tick -
+    both sides of the increment's guard - against the 50-digit golden, with each form of the kernel asked for (a form that
+    is not built for this configuration falls back to the single-wave one)."""
+    case = [c for c in golden["cases"] if c["name"] == "drag_dt1_norw"][0]
+    cfg = cfg_for_case(case)
+    ic = np.array(case["ic"])
+    prop = _forced(cfg, ic.shape[1], BSKGPU_PAIR="1" if form == "pair" else "0", BSKGPU_TRI="1" if form == "tri" else "0")
+    prop.reset(ic)
+    for call in case["calls"]:
+        prop.step(np.array(call["actions"], np.int32), call["substeps"])
+        obs, rew, done, why = prop.get_obs()
+        s, gs, go = prop.get_state(), np.array(call["state"]), np.array(call["obs"])
+        errs = max_group_err(s, gs, case["n_rw"])
+        assert errs["r"] < 1e-13 and errs["v"] < 1e-13, (call["substeps"], errs)
+        assert max(errs.values()) < 1e-10, (call["substeps"], errs)
+        assert np.abs(obs - go).max() < 1e-11
+        assert (why == np.array(call["reason"])).all()
+    prop.close()
+
+
 @pytest.mark.parametrize("geometry", ["reference", "off_axis_centres", "tilted_normals", "five_facets"])
 def test_facet_geometries_match_oracle(geometry):
     """The three evaluation paths of the facet sums: facet centres on their own normal axes (the reference's
