@@ -623,6 +623,15 @@ def main():
         cfg.dt = 1.0
         cfg.base_density, cfg.scale_height = 1e-4, 20e3
 
+    def full_inertia_edit(cfg):
+        """a GENERAL hub - symmetric positive-definite inertia matrix with products of inertia, one wheel axis tilted by nine
+        degrees - in the full scenario minus desaturation: the case that pins the step kernels' general-inertia family
+        (3 x 3 back-substitution, full W = sum Js g g^T; csrc/bsk_capi.hip picks it whenever an off-diagonal is non-zero)"""
+        scenario_edit(cfg)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from helpers import general_hub       # (an edit of the INPUT constants, shared with the tests that rebuild the config)
+        general_hub(cfg)
+
     def low_perigee_ic(cfg, ic):
         """envs 0..3 at 180 - 260 km with radial velocities of +-380 / +-250 m/s (the others keep their sampled 500 km orbits)"""
         for e, (alt, vr, ang) in enumerate(((180e3, 380.0, 0.3), (220e3, -380.0, 1.7), (260e3, 250.0, 3.1), (200e3, -250.0, 4.9))):
@@ -669,6 +678,8 @@ def main():
         # them the reference's gains at a 10 s control period are an unstable loop that amplifies rounding to 5e-9 in 300 steps)
         ("drag_dt1_norw", lambda: run_case("drag_dt1_norw", 0, GRAV_PM_J2, 6, 17, [(np.array([0, 1, 0, 1, 0, 0]), k) for k in (1, 9, 90, 200)],
                                            cfg_edit=dense_drag_edit, ic_edit=low_perigee_ic)),
+        ("full_inertia_rw4", lambda: run_case("full_inertia_rw4", 4, GRAV_PM_J2, 6, 18, [(np.array([0, 1, 0, 1, 2, 0]), k) for k in (1, 9, 90, 200)],
+                                              cfg_edit=full_inertia_edit)),
         ("sh8_rw3", lambda: run_case("sh8_rw3", 3, GRAV_SH, 4, 14, [(np.array([0, 1, 2, 0]), k) for k in (1, 9, 90, 300)],
                                      cfg_edit=sh_edit, sh=(8, cb, sb))),
     ]

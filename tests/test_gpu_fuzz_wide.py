@@ -10,7 +10,7 @@ import pytest
 from basilisk_env_amd._lib import (FLAG_DESAT, FLAG_DRAG, FLAG_LDS_SCRATCH, FLAG_POWER, FLAG_SUN_THIRD_BODY, GRAV_PM, GRAV_PM_J2)
 from basilisk_env_amd.simulators.dynamics import BatchedPropagator, default_config
 from basilisk_env_amd.simulators.initial_conditions.batch import sample_ic_batch
-from helpers import max_group_err
+from helpers import general_hub, max_group_err
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
@@ -51,6 +51,10 @@ def test_random_variant_matches_oracle(seed, monkeypatch):
     cfg.max_length = int(rng.integers(1, 4))        # episodes end by length inside the run
     if level == 0:
         monkeypatch.setenv("BSKGPU_BLOCK", str(rng.choice([64, 128, 256])))
+    # a GENERAL hub in about half of the cases (the DIAG = false kernels), from a generator of its own: the seeds keep their cases
+    grng = np.random.default_rng(880000 + seed)
+    gen_inertia, gen_tilt = bool(grng.random() < 0.3), bool(n_rw and grng.random() < 0.3)
+    general_hub(cfg, grng, inertia=gen_inertia, tilt=gen_tilt)
     ic = sample_ic_batch(n, n_rw, seed=seed + 7)
     t = 12 + n_rw
     if n_rw:                                        # some wheels right at their limit
@@ -80,6 +84,7 @@ def test_random_variant_matches_oracle(seed, monkeypatch):
         assert np.abs(rew - o[1]).max() < 1e-12 and np.array_equal(why, o[3]) and np.array_equal(done.astype(bool), o[3] != 0), (tag, call)
         if level >= 1:
             assert np.abs(prop.get_state()[t + 7] - st[t + 7]).max() < 1e-7, (tag, call)
+        assert ("diag" in prop.kernel_info()["name"]) == (not (gen_inertia or gen_tilt)), (tag, prop.kernel_info()["name"])
         if call == 1:                               # checkpoint, scribble, restore: nothing but slab + counters is state
             snap, cs, ct = prop.get_state(), *prop.get_counters()
             prop.step(act, 3)
