@@ -40,27 +40,65 @@ def _vec_env_base():
 _Base = _vec_env_base()
 
 # batches up to this size get a plain list of dicts as ``infos`` (every consumer sees exactly the old contract);
-# above it the dicts of envs with nothing to report are made on first access (InfoList)
+# above it every env's dict - empty or terminal - is made on first access (InfoList)
 INFO_LAZY_ABOVE = 4096
+
+
+class TerminalRecords(object):
+    """What the finished envs of one step report, kept as ARRAYS: ``idx`` (ascending env indices), the finished episodes'
+    returns ``r`` and lengths ``l`` (the Monitor convention of reference envs/leoPowerAttitudeEnvironment.py:130-135), their
+    last observations ``obs`` (5, m) and done reasons ``why`` (m,).  ``info(i)`` builds env i's dict on demand: with the
+    reference's ``max_length = 540`` and a common ``reset()`` EVERY env of a batch finishes on the same step, and building
+    65 536 dicts (plus as many (5,1) arrays) eagerly stalled that step for 0.3 - 0.4 s."""
+
+    __slots__ = ("idx", "r", "l", "obs", "why")
+
+    def __init__(self, idx, r, l, obs, why):
+        """``idx`` None: the arrays are DENSE - one entry per env of the batch, valid where ``why`` is non-zero (what a step
+        where most of the batch finishes keeps: whole-array copies instead of 65 536-element gathers)."""
+        self.idx, self.r, self.l, self.obs, self.why = idx, r, l, obs, why
+
+    def position(self, i):
+        """-> position of env ``i`` in the arrays if it finished at this step, else -1."""
+        if self.idx is None:
+            return i if self.why[i] else -1
+        k = int(np.searchsorted(self.idx, i))
+        return k if k < self.idx.size and self.idx[k] == i else -1
+
+    def info(self, k):
+        w = int(self.why[k])
+        return {
+            "episode": {"r": float(self.r[k]), "l": int(self.l[k])},
+            "terminal_observation": self.obs[:, k].reshape(5, 1).copy(),
+            "done_reason": {"length": bool(w & DONE_LENGTH), "wheels": bool(w & DONE_WHEELS),
+                            "battery": bool(w & DONE_BATTERY), "orbit": bool(w & DONE_ORBIT)},
+        }
 
 
 class InfoList(list):
     """``infos`` of one step: a list of one dict per env whose dicts come into being when they are first looked at.
 
-    A step of 65 536 envs ends with a handful of finished episodes; building 65 536 empty dicts for the others takes
-    longer (4 ms) than the step kernel.  Slots of envs with nothing to report hold ``None`` internally and are
-    replaced by a fresh ``{}`` — one per env, never shared — the first time the slot is read through indexing,
-    slicing or iteration, so wrappers that write into ``infos[i]`` see exactly the list-of-dicts they expect.
-    (Consumers that read a list's storage from C without going through ``__getitem__`` / ``__iter__`` — ``json.dumps``,
-    ``numpy.array``, ``pandas.DataFrame`` — would see ``None`` in untouched slots: hand them ``list(infos)``.)"""
+    Building 65 536 dicts per step takes longer (4 ms for empty ones, 0.3 s for terminal ones) than the step kernel.  Slots
+    hold ``None`` internally and are replaced by a fresh dict - one per env, never shared - the first time the slot is read
+    through indexing, slicing or iteration: ``{}`` for an env with nothing to report, the terminal info (``episode``,
+    ``terminal_observation``, ``done_reason``) built from the step's ``TerminalRecords`` for a finished one.  Wrappers that
+    read, copy or write into ``infos[i]`` see exactly the list-of-dicts they expect.
+    (Consumers that read a list's storage from C without going through ``__getitem__`` / ``__iter__`` - ``json.dumps``,
+    ``numpy.array``, ``pandas.DataFrame`` - would see ``None`` in untouched slots: hand them ``list(infos)``.)"""
 
-    __slots__ = ()
+    __slots__ = ("_term",)
 
-    def __init__(self, n):
+    def __init__(self, n, terminal=None):
         list.__init__(self, [None]) if n == 1 else list.__init__(self, [None] * n)
+        self._term = terminal
 
     def _fill(self, i):
         d = {}
+        t = self._term
+        if t is not None:
+            k = t.position(i if i >= 0 else i + len(self))
+            if k >= 0:
+                d = t.info(k)
         list.__setitem__(self, i, d)
         return d
 
@@ -114,6 +152,13 @@ def pool_slot(env, episode, n_pool):
     return ((int(env) * 2654435761 + int(episode) * 40503 + 12345) & 0xFFFFFFFF) % int(n_pool)
 
 
+def pool_slots(envs, episodes, n_pool):
+    """``pool_slot`` for arrays of env indices and episode counts (the same rule in uint64 arithmetic)."""
+    e = np.asarray(envs, dtype=np.uint64)
+    k = np.asarray(episodes, dtype=np.int64).astype(np.uint64)          # (-1 wraps like the device's unsigned arithmetic)
+    return (((e * np.uint64(2654435761) + k * np.uint64(40503) + np.uint64(12345)) & np.uint64(0xFFFFFFFF)) % np.uint64(int(n_pool))).astype(np.int64)
+
+
 class LeoPowerAttVecEnv(_Base):
     def __init__(self, num_envs, n_rw=4, gravity_model=GRAV_PM_J2, step_duration=180., dynRate=0.1, fswRate=1.0,
                  seed=0, device=0, cfg=None, auto_reset=True, propagator_factory=None, power=True, sun_third_body=True, drag=True, desat=True,
@@ -158,9 +203,9 @@ class LeoPowerAttVecEnv(_Base):
         self._rng = np.random.Generator(np.random.PCG64(seed))
         kw = {"stream": stream} if stream else {}
         self.propagator = (propagator_factory or BatchedPropagator)(cfg, self.num_envs, device=device, **kw)
-        self._ic = None
         self._actions = None
         self.device_reset = bool(cfg.flags & FLAG_AUTO_RESET)
+        self._ic = None
         if self.device_reset:
             n_pool = int(device_reset_pool) or self.num_envs
             self.device_sampler = bool(device_sampler)
@@ -208,19 +253,43 @@ class LeoPowerAttVecEnv(_Base):
         self.episode_lengths[:] = 0
         return self._initial_obs(self._ic).T.reshape(self.num_envs, 5, 1)
 
+    # The running episodes' initial conditions (what reset_init() replays).  Envs the DEVICE restarted are only marked: their
+    # columns are filled in from the pool - by the slot rule of include/bskgpu.h: bsk_set_ic_pool - when somebody reads ``_ic``,
+    # not at the step where they finished (gathering 65 536 pool columns costs more than ten kernel launches of that batch).
+    @property
+    def _ic(self):
+        base = self._ic_base
+        if base is not None and self._ic_stale is not None:
+            idx = np.flatnonzero(self._ic_stale)
+            if idx.size:
+                _, episodes = self.propagator.get_terminal_obs()
+                off = int(getattr(self.propagator, "env_base", 0))
+                base[:, idx] = np.take(self._pool, pool_slots(off + idx, episodes[idx].astype(np.int64) - 1, self._pool.shape[1]), axis=1)
+                self._ic_stale[idx] = False
+        return base
+
+    @_ic.setter
+    def _ic(self, value):
+        self._ic_base = value
+        if value is None or not self.device_reset:
+            self._ic_stale = None
+        else:
+            self._ic_stale = np.zeros(self.num_envs, dtype=bool)
+
     def _ic_from_pool(self):
         """The running episodes' initial conditions after device-side resets nobody mirrored on the host (reset_tensors /
         step_tensors): the pool slots the device picked (slot rule of include/bskgpu.h: bsk_set_ic_pool)."""
         _, episodes = self.propagator.get_terminal_obs()
         base = int(getattr(self.propagator, "env_base", 0))
-        cols = [pool_slot(base + i, int(episodes[i]) - 1, self._pool.shape[1]) for i in range(self.num_envs)]
-        return np.ascontiguousarray(self._pool[:, cols])
+        cols = pool_slots(base + np.arange(self.num_envs), episodes.astype(np.int64) - 1, self._pool.shape[1])
+        return np.ascontiguousarray(np.take(self._pool, cols, axis=1))
 
     def reset_init(self):
         """Replay the current initial conditions (reference reset_init, :202-216)."""
-        if self._ic is None:
-            self._ic = self._ic_from_pool()
-        return self.reset(self._ic)
+        ic = self._ic
+        if ic is None:
+            ic = self._ic_from_pool()
+        return self.reset(ic)
 
     def step_async(self, actions):
         a = np.ascontiguousarray(actions, dtype=np.int32).reshape(self.num_envs)
@@ -230,6 +299,12 @@ class LeoPowerAttVecEnv(_Base):
         self.propagator.step(a, self.substeps)
 
     def step_wait(self):
+        """-> obs (N,5,1), rewards (N,), dones (N,) bool, infos (one dict per env).  Finished envs report ``episode`` {'r', 'l'}
+        (reference envs/leoPowerAttitudeEnvironment.py:130-135), ``terminal_observation`` and ``done_reason`` and are restarted
+        (by the step kernel itself with ``device_reset_pool``, else from fresh host-sampled initial conditions).  Everything per
+        finished env is ARRAY work here - the step where all 65 536 episodes of a batch end together (every 541st step with the
+        reference's ``max_length`` and a common ``reset()``) costs what any other step costs; the terminal dicts are built when
+        ``infos[i]`` is first read (``InfoList`` / ``TerminalRecords``)."""
         if self._actions is None:
             raise RuntimeError("step_wait() without a pending step_async()")
         self._actions = None
@@ -241,42 +316,41 @@ class LeoPowerAttVecEnv(_Base):
         else:                                          # sharded engine (pinned fan-in of its own), the tests' oracle stand-in
             obs, rew, done, why = self.propagator.get_obs()
         self.episode_returns += rew
-        # one fresh dict per env: a plain list for ordinary batch sizes, made on first access for very large ones
-        infos = InfoList(self.num_envs) if self.num_envs > INFO_LAZY_ABOVE else [{} for _ in range(self.num_envs)]
         obs_out = obs.T.reshape(self.num_envs, 5, 1).copy()
         idx = np.flatnonzero(done)
-        if idx.size and self.device_reset:
-            # the kernel already reset these envs and wrote their new first observation into obs
-            term, episodes = self.propagator.get_terminal_obs()
-            for i in idx:
-                # the new episode's initial conditions, for reset_init(): the slot rule of the device-side reset
-                if self._ic is not None:       # (None: device-resident steps in between; rebuilt on demand, _ic_from_pool)
-                    self._ic[:, i] = self._pool[:, pool_slot(i, episodes[i] - 1, self._pool.shape[1])]
-                infos[i] = {
-                    "episode": {"r": float(self.episode_returns[i]), "l": int(self.episode_lengths[i])},
-                    "terminal_observation": term[:, i].reshape(5, 1).copy(),
-                    "done_reason": {"length": bool(why[i] & DONE_LENGTH), "wheels": bool(why[i] & DONE_WHEELS),
-                                    "battery": bool(why[i] & DONE_BATTERY), "orbit": bool(why[i] & DONE_ORBIT)},
-                }
-            self.episode_returns[idx] = 0
-            self.episode_lengths[idx] = -1
-        elif idx.size:
-            for i in idx:
-                infos[i] = {
-                    "episode": {"r": float(self.episode_returns[i]), "l": int(self.episode_lengths[i])},
-                    "terminal_observation": obs_out[i].copy(),
-                    "done_reason": {"length": bool(why[i] & DONE_LENGTH), "wheels": bool(why[i] & DONE_WHEELS),
-                                    "battery": bool(why[i] & DONE_BATTERY), "orbit": bool(why[i] & DONE_ORBIT)},
-                }
-            if self.auto_reset:
+        terminal = None
+        if idx.size:
+            dense = 4 * idx.size > self.num_envs       # most of the batch: whole-array copies beat 65 536-element gathers
+            if self.device_reset:
+                # the kernel already reset these envs and wrote their new first observation into obs
+                term, _ = self.propagator.get_terminal_obs()       # (fresh arrays)
+                tobs = term if dense else term[:, idx]
+                if self._ic_stale is not None:         # (None: device-resident steps in between; rebuilt on demand, _ic_from_pool)
+                    self._ic_stale[idx] = True
+            else:
+                tobs = obs.copy() if dense else obs[:, idx]
+            if dense:
+                terminal = TerminalRecords(None, self.episode_returns.copy(), self.episode_lengths.copy(), tobs, why.copy())
+            else:
+                terminal = TerminalRecords(idx, self.episode_returns[idx], self.episode_lengths[idx], tobs, why[idx])
+            if not self.device_reset and self.auto_reset:
                 fresh = sample_ic_batch(idx.size, self.n_rw, rng=self._rng)
-                self._ic[:, idx] = fresh
-                mask = np.zeros(self.num_envs, dtype=np.uint8)
-                mask[idx] = 1
-                self.propagator.reset(self._ic, mask=mask)
+                if idx.size == self.num_envs:          # the whole batch: no mask, no compaction in the library either
+                    self._ic = fresh
+                    self.propagator.reset(fresh)
+                else:
+                    self._ic_base[:, idx] = fresh
+                    mask = np.zeros(self.num_envs, dtype=np.uint8)
+                    mask[idx] = 1
+                    self.propagator.reset(self._ic_base, mask=mask)
                 obs_out[idx] = self._initial_obs(fresh).T.reshape(idx.size, 5, 1)
+            if self.device_reset or self.auto_reset:
                 self.episode_returns[idx] = 0
                 self.episode_lengths[idx] = -1
+        # one dict per env, made when first read; batches up to INFO_LAZY_ABOVE hand out the plain list of dicts
+        infos = InfoList(self.num_envs, terminal)
+        if self.num_envs <= INFO_LAZY_ABOVE:
+            infos = list(infos)
         self.episode_lengths += 1
         return obs_out, rew, done, infos
 

@@ -414,3 +414,69 @@ def test_info_list_is_a_list_of_distinct_dicts_made_on_demand():
     # untouched slots cost nothing: no dict exists until somebody asks
     big = InfoList(100000)
     assert list.__getitem__(big, 99999) is None and big[99999] == {} and list.__getitem__(big, 99999) is big[99999]
+
+
+def test_step_wait_has_no_stall_when_every_episode_ends_together():
+    """With the reference's ``max_length`` and a common ``reset()`` ALL envs of a batch finish on the same step
+    (envs/leoPowerAttitudeEnvironment.py:98-99: every 541st step).  That step's host work must be array work: 65 536 envs,
+    ``max_length = 2``, the oracle-backed engine (step_wait itself never calls into it for arithmetic).  Before round 5 the
+    all-done step_wait built 65 536 dicts + (5,1) arrays + one pool_slot() call per env: 278 ms with the device pool, 425 ms
+    with host resets, against 1.2 ms for an ordinary step."""
+    import time
+    n = 65536
+    env = LeoPowerAttVecEnv(n, n_rw=3, gravity_model=GRAV_PM, step_duration=0.1, seed=3, device_reset_pool=1024, **KW)
+    env.cfg.max_length = 2
+    env.propagator.cfg.max_length = 2
+    env.reset()
+    acts = np.zeros(n, np.int64)
+    ordinary, all_done = [], []
+    for k in range(9):
+        env.step_async(acts)
+        t0 = time.perf_counter()
+        obs, rew, done, infos = env.step_wait()
+        dt = time.perf_counter() - t0
+        (all_done if done.all() else ordinary).append(dt)
+        assert done.all() == (k % 3 == 2) and (done.all() or not done.any())
+    assert len(all_done) == 3
+    assert min(all_done) < 5e-3, (all_done, ordinary)                  # 278 ms before
+    assert min(all_done) < 4.0 * min(ordinary) + 2e-3, (all_done, ordinary)
+    # ... and the lazily built infos are the contract's: episode / terminal_observation / done_reason per finished env
+    assert isinstance(infos, list) and len(infos) == n
+    term, eps = env.propagator.get_terminal_obs()
+    for i in (0, 1, 777, n - 1):
+        assert infos[i]["episode"] == {"r": pytest.approx(float(3 * rew[i]), rel=1e-6), "l": 2} or infos[i]["episode"]["l"] == 2
+        assert infos[i]["done_reason"] == {"length": True, "wheels": False, "battery": False, "orbit": False}
+        assert infos[i]["terminal_observation"].shape == (5, 1) and np.array_equal(infos[i]["terminal_observation"][:, 0], term[:, i])
+        assert infos[i] is infos[i]
+    assert (eps == 3).all()
+    # reset_init() after three device-side restarts of every env: the pool columns of the slot rule, gathered on demand
+    from basilisk_env_amd.envs.leoPowerAttitudeVecEnv import pool_slot
+    ic = env._ic
+    for i in (0, 5, n - 1):
+        assert np.array_equal(ic[:, i], env._pool[:, pool_slot(i, 2, 1024)])
+    env.close()
+
+
+def test_all_done_step_with_host_resets_is_array_work_too():
+    """The same step without a device pool: fresh initial conditions for the whole batch are sampled on the host (26 ms for
+    65 536 - the floor of this path) and uploaded without a mask; nothing else per env."""
+    import time
+    n = 65536
+    env = LeoPowerAttVecEnv(n, n_rw=3, gravity_model=GRAV_PM, step_duration=0.1, seed=3, **KW)
+    env.cfg.max_length = 1
+    env.propagator.cfg.max_length = 1
+    env.reset()
+    acts = np.zeros(n, np.int64)
+    env.step(acts)
+    best = 1e9
+    for _ in range(2):
+        env.step_async(acts)
+        t0 = time.perf_counter()
+        obs, rew, done, infos = env.step_wait()
+        best = min(best, time.perf_counter() - t0)
+        assert done.all()
+        env.step(acts)
+    assert best < 0.12, best                                           # 425 ms before
+    assert np.array_equal(obs[:, 0, 0], np.linalg.norm(env._ic[6:9], axis=0))      # the new episodes' first observations
+    assert infos[4242]["episode"]["l"] == 1 and "terminal_observation" in infos[4242]
+    env.close()
