@@ -1,0 +1,276 @@
+// bsk_aux.hip — the small kernels around the step kernel (a translation unit of their own: they compile in seconds, the
+// step kernel's 36+ instantiations in minutes):
+//   stats_kernel            deterministic batch scalars of the last step (sum of rewards, finished envs): SURVEY.md section 8 row a7
+//   scatter_reset_kernel    masked reset from host initial conditions (reference reset / reset_init,
+//                           basilisk_env/envs/leoPowerAttitudeEnvironment.py:172-216)
+//   sample_pool_kernel      on-device IC sampler, Philox4x32-10 (row f4; distributions of
+//                           basilisk_env/simulators/leoPowerAttitudeSimulator.py:119-193, leo_orbit.py:25-40, sc_attitudes.py:3-13)
+//   reset_from_pool_kernel / init_outputs_kernel    device-side (re)start from the staged pool, first observations
+#include "bsk_device.hpp"
+#include "bsk_aux.hpp"
+
+#include <algorithm>
+
+namespace bsk {
+
+// Sum over the 64 lanes of a wave in the order of the xor butterfly v += v[lane ^ off], off = 32, 16, ..., 1 - as far as lane 0 is
+// concerned, which is the only lane whose result is used: at every level the lanes below `off` add the value `off` lanes up
+// (lane ^ off = lane + off there, and the addition commutes bit for bit).  The two upper levels cross 16-lane rows (ds_bpermute),
+// the four lower ones stay inside a row: DPP row shifts, no trip through the LDS crossbar.
+template <int CTRL>
+__device__ __forceinline__ double dpp_pull(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v += __shfl_down(v, 32, 64);
+    v += __shfl_down(v, 16, 64);
+    v += dpp_pull<0x108>(v);      // row_shl:8  lane i <- lane i + 8
+    v += dpp_pull<0x104>(v);      // row_shl:4
+    v += dpp_pull<0x102>(v);      // row_shl:2
+    v += dpp_pull<0x101>(v);      // row_shl:1
+    return v;                     // (lane 0)
+}
+
+// Deterministic batch scalars of the last step: sum of its rewards and number of finished envs (SURVEY.md section 8 row a7:
+// "batch sum-reward / sum-done via wave reductions"; reward semantics: reference envs/leoPowerAttitudeEnvironment.py:161-170).
+// The step kernel's epilogue carries no reward reduction (a six-stage butterfly through the LDS crossbar on the critical
+// path of every launch, for a number asked for once per rollout); these two kernels form the sums from the reward buffer and
+// the per-wave done ballots when somebody asks.  Two levels, the order fixed by the batch alone:
+//   stats_kernel (many workgroups; hardware wave k of workgroup b takes the step kernel's waves w = 4 b + k, + 4 gridDim, ...):
+//     wave w = rewards [64 w, 64 w + 64) summed in the butterfly's order -> wave_sum[w]; the waves' done ballots are popcounted
+//     into one integer per workgroup -> done_part[b] (no atomics: when a whole batch finishes together 2 048 workgroups adding
+//     to one word took 23 us of a 28 us launch);
+//   stats_join_kernel (one workgroup, launched behind it on the same stream): thread t of 256 adds wave_sum[w], w = t (mod 256),
+//     in ascending order, a halving tree joins the 256 partials - the documented tree of
+//     tests/test_gpu_device_surface.py::_stats_order, bit for bit what the single-workgroup kernel of round 4 produced.
+// Measured and rejected (profiles/r05/rejected/stats_forms.txt): ONE launch whose last workgroup joins the partials - with
+// agent-scope fences 24 us at 65 536 envs and 236 us at 4 Mi (every fence walks the L2), with write-through publications and a
+// ticket 7.6 / 99 us; the kernel boundary is the cheap device-wide synchronisation here.
+constexpr int STATS_MAX_GRID = 2048;   // workgroups of the first level at most (eight per CU: a 4 Mi batch takes eight trips)
+struct StatsScratch {
+    double* wave_sum;               // [ceil(n / 64)]
+    unsigned* done_part;            // [STATS_MAX_GRID] finished envs per first-level workgroup
+};
+__global__ __launch_bounds__(256) void stats_kernel(const double* __restrict__ reward, int n,
+                                                    const unsigned long long* __restrict__ done_mask, int n_waves, StatsScratch sc) {
+    __shared__ unsigned sdone[4];
+    const int lane = (int)(threadIdx.x & 63u), hw = (int)(threadIdx.x >> 6);
+    const int stride_w = 4 * (int)gridDim.x;
+    unsigned nd = 0;
+    // four trips at a time: their rewards are loaded together (four 512-byte rows in flight per wave), then summed one by one
+    for (int w0 = (int)blockIdx.x * 4 + hw; w0 < n_waves; w0 += 4 * stride_w) {
+        double r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int w = w0 + k * stride_w, i = 64 * w + lane;
+            r[k] = (w < n_waves && i < n) ? reward[i] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int w = w0 + k * stride_w;
+            if (w < n_waves) {                 // (wave-uniform)
+                const double ws = wave_sum(r[k]);
+                if (lane == 0) {
+                    sc.wave_sum[w] = ws;
+                    nd += (unsigned)__popcll(done_mask[w]);
+                }
+            }
+        }
+    }
+    if (lane == 0) sdone[hw] = nd;
+    __syncthreads();
+    if (threadIdx.x == 0) sc.done_part[blockIdx.x] = sdone[0] + sdone[1] + sdone[2] + sdone[3];
+}
+__global__ __launch_bounds__(256) void stats_join_kernel(StatsScratch sc, int n_waves, int n_parts, double* out_sum, long long* out_done, double* out2) {
+    __shared__ double sr[256];
+    __shared__ long long sd[256];
+    long long nd = 0;
+    for (int g = (int)threadIdx.x; g < n_parts; g += 256) nd += (long long)sc.done_part[g];
+    sd[threadIdx.x] = nd;
+    const double* __restrict__ ws = sc.wave_sum;
+    double acc = 0.0;
+    int w = (int)threadIdx.x;
+    // a row of 256 wave sums per trip (2 KB, coalesced); up to 64 rows in flight, added in ascending order
+    for (; w + 63 * 256 < n_waves; w += 64 * 256) {
+        double v[64];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) v[k] = ws[w + 256 * k];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) acc += v[k];
+    }
+    for (; w + 15 * 256 < n_waves; w += 16 * 256) {
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = ws[w + 256 * k];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += v[k];
+    }
+    for (; w < n_waves; w += 256) acc += ws[w];
+    sr[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) { sr[threadIdx.x] += sr[threadIdx.x + off]; sd[threadIdx.x] += sd[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *out_sum = sr[0];
+        *out_done = sd[0];
+        out2[0] = sr[0]; out2[1] = (double)sd[0];      // {sum reward, #done} as two doubles: one all-reduce operand
+    }
+}
+
+// Scatter a compact IC block [nf][m] into the state slab at env indices idx[0..m) and zero their
+// counters (bsk_reset with a mask; reference reset / reset_init,
+// basilisk_env/envs/leoPowerAttitudeEnvironment.py:172-216).
+__global__ void scatter_reset_kernel(double* __restrict__ st, int64_t stride, int nf, const double* __restrict__ ic,
+                                     const int* __restrict__ idx, int m, int2* __restrict__ cnt) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    const int e = idx[t];
+    for (int f = 0; f < nf; ++f) st[f * stride + e] = ic[(int64_t)f * m + t];
+    cnt[e] = make_int2(0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// On-device initial-condition sampler (row f4).  Philox4x32-10 (Salmon et al. 2011), written out by
+// hand: counter (slot, draw, 0, 0), key (seed_lo, seed_hi); every call yields four 32-bit words =
+// two 53-bit uniforms, so each pool slot is reproducible independently of every other slot.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned* out) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1,
+                       n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// two uniforms in [0, 1) with 53 random bits each (same bit recipe as numpy's random_double)
+__device__ __forceinline__ void philox_u2(unsigned slot, unsigned draw, unsigned k0, unsigned k1, double& a, double& b) {
+    unsigned w[4];
+    philox4x32_10(slot, draw, 0u, 0u, k0, k1, w);
+    a = (double)(((unsigned long long)(w[0] >> 5) << 26) | (w[1] >> 6)) * (1.0 / 9007199254740992.0);
+    b = (double)(((unsigned long long)(w[2] >> 5) << 26) | (w[3] >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+__global__ void sample_pool_kernel(double* __restrict__ pool, int n_pool, int n_rw, unsigned k0, unsigned k1, double mu) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_pool) return;
+    const double PI = 3.14159265358979323846, RPM = 2.0 * PI / 60.0;
+    double u[20];
+#pragma unroll
+    for (int d = 0; d < 10; ++d) philox_u2((unsigned)s, (unsigned)d, k0, k1, u[2 * d], u[2 * d + 1]);
+    // orbit: sampled_400km (leo_orbit.py:25-40) -> elem2rv
+    const double a = 6371.0 * 1000.0 + 500.0 * 1000.0;
+    const double e = 0.05 * u[0], inc = PI * u[1] - 0.5 * PI, Om = 2.0 * PI * u[2], om = 2.0 * PI * u[3], f = 2.0 * PI * u[4];
+    const double p = a * (1.0 - e * e), r = p / (1.0 + e * cos(f)), th = om + f;
+    const double ct = cos(th), st = sin(th), cO = cos(Om), sO = sin(Om), ci = cos(inc), si = sin(inc);
+    const double h = sqrt(mu * p), A = st + e * sin(om), B = ct + e * cos(om), mh = -mu / h;
+    auto put = [&](int fld, double v) { pool[(int64_t)fld * n_pool + s] = v; };
+    put(BSK_F_R + 0, r * (cO * ct - sO * st * ci)); put(BSK_F_R + 1, r * (sO * ct + cO * st * ci)); put(BSK_F_R + 2, r * (st * si));
+    put(BSK_F_V + 0, mh * (cO * A + sO * B * ci)); put(BSK_F_V + 1, mh * (sO * A - cO * B * ci)); put(BSK_F_V + 2, mh * (-B * si));
+    // attitude: random_tumble(maxSpinRate = 1e-5) (sc_attitudes.py:3-13, ...Simulator.py:124)
+    put(BSK_F_SIGMA + 0, u[5]); put(BSK_F_SIGMA + 1, u[6]); put(BSK_F_SIGMA + 2, u[7]);
+    put(BSK_F_OMEGA + 0, 1e-5 * (2.0 * u[8] - 1.0)); put(BSK_F_OMEGA + 1, 1e-5 * (2.0 * u[9] - 1.0));
+    put(BSK_F_OMEGA + 2, 1e-5 * (2.0 * u[10] - 1.0));
+    // wheel speeds U(-800, 800) RPM (...Simulator.py:155)
+    for (int k = 0; k < n_rw; ++k) put(BSK_NF_BASE + k, (1600.0 * u[11 + k] - 800.0) * RPM);
+    const int T = BSK_NF_BASE + n_rw;
+    // disturbance torque 2e-4 * N(0,1)^3 (...Simulator.py:151-152, 295): Box-Muller on (u15,u16), (u17,u18)
+    const double r1 = sqrt(-2.0 * log(1.0 - u[15])), r2 = sqrt(-2.0 * log(1.0 - u[17]));
+    put(T + BSK_T_LEXT + 0, 2e-4 * r1 * cos(2.0 * PI * u[16]));
+    put(T + BSK_T_LEXT + 1, 2e-4 * r1 * sin(2.0 * PI * u[16]));
+    put(T + BSK_T_LEXT + 2, 2e-4 * r2 * cos(2.0 * PI * u[18]));
+    for (int k = BSK_T_UCMD; k < BSK_NF_TAIL; ++k) put(T + k, 0.0);
+    // battery U(8, 20) W h (...Simulator.py:167)
+    put(T + BSK_T_CHARGE, (8.0 + 12.0 * u[19]) * 3600.0);
+}
+
+// what a reset leaves in the output buffers of env i: the new episode's first observation (the vec env's convention:
+// |sigma_BN|, |omega|, |Omega| / limit in rad/s, charge / 3600 / power_max, 1), zero reward / reason / done / return
+__device__ __forceinline__ void init_outputs(const ResetOut& ro, const double* __restrict__ st, int64_t stride, int i) {
+    const V3 sg = mk(st[(int64_t)(BSK_F_SIGMA + 0) * stride + i], st[(int64_t)(BSK_F_SIGMA + 1) * stride + i], st[(int64_t)(BSK_F_SIGMA + 2) * stride + i]);
+    const V3 w = mk(st[(int64_t)(BSK_F_OMEGA + 0) * stride + i], st[(int64_t)(BSK_F_OMEGA + 1) * stride + i], st[(int64_t)(BSK_F_OMEGA + 2) * stride + i]);
+    double om2 = 0.0;
+    for (int k = 0; k < ro.n_rw; ++k) {
+        const double v = st[(int64_t)(BSK_NF_BASE + k) * stride + i];
+        om2 = fma(v, v, om2);
+    }
+    const double o[5] = {sqrt_nr(dot(sg, sg)), sqrt_nr(dot(w, w)), sqrt_nr(om2) * ro.inv_wheel_limit,
+                         st[(int64_t)(BSK_NF_BASE + ro.n_rw + BSK_T_CHARGE) * stride + i] * ro.charge_scale, 1.0};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        ro.obs[(int64_t)k * stride + i] = o[k];
+        if (ro.obs_rm) ro.obs_rm[(int64_t)i * 5 + k] = o[k];
+    }
+    ro.reward[i] = 0.0;
+    ro.reason[i] = 0;
+    if (ro.done) ro.done[i] = 0;
+    if (ro.ep_return) ro.ep_return[i] = 0.0;
+}
+
+// (re)start envs from the pool with the slot rule of the step kernel's auto-reset
+__global__ void reset_from_pool_kernel(double* __restrict__ st, int64_t stride, int nf, const double* __restrict__ pool,
+                                       int n_pool, const unsigned char* __restrict__ mask, int n, int2* __restrict__ cnt,
+                                       int* __restrict__ episodes, unsigned env_base, const ResetOut ro) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || (mask && !mask[i])) return;
+    const int ep = episodes[i];
+    episodes[i] = ep + 1;
+    const unsigned slot = (((unsigned)i + env_base) * 2654435761u + (unsigned)ep * 40503u + 12345u) % (unsigned)n_pool;
+    for (int f = 0; f < nf; ++f) st[f * stride + i] = pool[(int64_t)f * n_pool + slot];
+    cnt[i] = make_int2(0, 0);
+    init_outputs(ro, st, stride, i);
+}
+
+// after a reset from host initial conditions: all n envs (idx == NULL) or the m listed ones
+__global__ void init_outputs_kernel(const double* __restrict__ st, int64_t stride, const int* __restrict__ idx, int m, const ResetOut ro) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    init_outputs(ro, st, stride, idx ? idx[t] : t);
+}
+
+hipError_t launch_sample_pool(double* pool, int n_pool, int n_rw, unsigned long long seed, double mu, hipStream_t s) {
+    hipLaunchKernelGGL(sample_pool_kernel, dim3((n_pool + 255) / 256), dim3(256), 0, s, pool, n_pool, n_rw,
+                       (unsigned)(seed & 0xFFFFFFFFull), (unsigned)(seed >> 32), mu);
+    return hipGetLastError();
+}
+
+hipError_t launch_reset_from_pool(double* st, int64_t stride, int nf, const double* pool, int n_pool, const unsigned char* mask,
+                                  int n, int2* cnt, int* episodes, unsigned env_base, const ResetOut& ro, hipStream_t s) {
+    hipLaunchKernelGGL(reset_from_pool_kernel, dim3((n + 255) / 256), dim3(256), 0, s, st, stride, nf, pool, n_pool, mask, n, cnt,
+                       episodes, env_base, ro);
+    return hipGetLastError();
+}
+
+hipError_t launch_init_outputs(const double* st, int64_t stride, const int* idx, int m, const ResetOut& ro, hipStream_t s) {
+    if (m <= 0) return hipSuccess;
+    hipLaunchKernelGGL(init_outputs_kernel, dim3((m + 255) / 256), dim3(256), 0, s, st, stride, idx, m, ro);
+    return hipGetLastError();
+}
+
+hipError_t launch_stats(const double* reward, int n, const unsigned long long* done_mask, int n_waves, double* wsum,
+                        unsigned* done_part, double* out_sum, long long* out_done, double* out2, hipStream_t s) {
+    // one 256-thread workgroup per four waves of rewards, at most STATS_MAX_GRID of them
+    const int grid = std::max(1, std::min((n_waves + 3) / 4, STATS_MAX_GRID));
+    hipLaunchKernelGGL(stats_kernel, dim3(grid), dim3(256), 0, s, reward, n, done_mask, n_waves, StatsScratch{wsum, done_part});
+    hipLaunchKernelGGL(stats_join_kernel, dim3(1), dim3(256), 0, s, StatsScratch{wsum, done_part}, n_waves, grid, out_sum, out_done, out2);
+    return hipGetLastError();
+}
+
+int stats_done_parts() { return STATS_MAX_GRID; }
+
+hipError_t launch_scatter_reset(double* st, int64_t stride, int nf, const double* ic, const int* idx, int m, int2* cnt,
+                                hipStream_t s) {
+    if (m <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_reset_kernel, dim3((m + 255) / 256), dim3(256), 0, s, st, stride, nf, ic, idx, m, cnt);
+    return hipGetLastError();
+}
+
+}  // namespace bsk

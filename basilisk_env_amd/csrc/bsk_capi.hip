@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/bskgpu.h"
+#include "bsk_aux.hpp"
 #include "bsk_launch.hpp"
 
 namespace {
@@ -402,6 +403,8 @@ struct bsk_handle {
     unsigned char* d_reason = nullptr;
     double* d_stat_sum = nullptr;
     long long* d_stat_done = nullptr;
+    double* d_wave_sum = nullptr;              // stats_kernel scratch: one reward sum per 64 envs
+    unsigned* d_done_part = nullptr;           // stats_kernel scratch: finished envs per first-level workgroup
     // masked-reset staging
     double* d_ic_stage = nullptr;
     int* d_idx_stage = nullptr;
@@ -431,6 +434,10 @@ struct bsk_handle {
     double* d_stats2 = nullptr;   // {sum of rewards, number of done envs} of the last step, as two doubles (all-reduce operand)
     bool stats_fresh = false;     // d_stat_sum / d_stat_done / d_stats2 hold the LAST STEP's batch scalars (snapshot_stats)
     bool stepped = false;         // some step has run since the handle was created
+    // A launch of this handle has been recorded into a HIP graph (note_capture): replays advance the device without this
+    // host-side state, so from then on nothing evaluated at enqueue time is trusted - the batch scalars are formed again
+    // whenever asked for (stats_fresh ignored) and the bare levels read the battery charge again (static_charge off).
+    bool replayable = false;
     // error word the kernels can raise (page-locked host memory, device-visible): checked by every synchronising entry point
     int* h_err = nullptr;
     // bare levels: no spacecraft of the batch / of the reset pool started its episode with an empty battery (bsk_launch.hpp:
@@ -517,9 +524,16 @@ bsk::ResetOut reset_out(const bsk_handle* h) {
 // The batch scalars of the last step (sum of rewards, number of done envs) are formed from the reward buffer and the done
 // ballots by a kernel of their own, once, when somebody asks - or just before a reset entry point overwrites the restarted
 // envs' rewards with zeros (the vec env auto-resets BEFORE a training loop reads the step's statistics).
+static bool note_capture(bsk_handle* h) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (!h->replayable && hipStreamIsCapturing(h->stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone) h->replayable = true;
+    return h->replayable;
+}
+
 static int snapshot_stats(bsk_handle* h) {
-    if (h->stats_fresh) return BSK_OK;
-    HIP_TRY(bsk::launch_stats(h->d_reward, h->n, h->d_done_mask, (h->n + 63) / 64, h->d_stat_sum, h->d_stat_done, h->d_stats2, h->stream));
+    if (h->stats_fresh && !note_capture(h)) return BSK_OK;
+    HIP_TRY(bsk::launch_stats(h->d_reward, h->n, h->d_done_mask, (h->n + 63) / 64, h->d_wave_sum, h->d_done_part,
+                              h->d_stat_sum, h->d_stat_done, h->d_stats2, h->stream));
     h->stats_fresh = true;
     return BSK_OK;
 }
@@ -548,7 +562,8 @@ int do_step(bsk_handle* h, const void* d_actions, int substeps, int act_shift) {
     b.cnt = h->d_cnt;
     b.act = (const int*)d_actions;
     b.act_shift = act_shift;
-    b.static_charge = (h->sp.feat == bsk::FEAT_BARE || h->sp.feat == bsk::FEAT_LDSS) && h->charge_pos && (h->n_pool == 0 || h->pool_charge_pos) ? 1 : 0;
+    const bool replayable = note_capture(h);      // (a captured launch must not freeze a host-side decision into the graph)
+    b.static_charge = !replayable && (h->sp.feat == bsk::FEAT_BARE || h->sp.feat == bsk::FEAT_LDSS) && h->charge_pos && (h->n_pool == 0 || h->pool_charge_pos) ? 1 : 0;
     b.ep_return = h->d_ep_return; b.term_return = h->d_term_return; b.term_len = h->d_term_len; b.done = h->d_done;
     b.obs_rm = h->d_obs_rm; b.err = h->h_err; b.dbg = h->d_dbg;
     b.obs = h->d_obs;
@@ -770,13 +785,17 @@ int bsk_create(const bsk_config* cfg, int n_envs, int device_id, void* stream, b
     if (e == hipSuccess) e = alloc((void**)&h->d_state, (size_t)h->nf * S * sizeof(double));
     if (e == hipSuccess) e = alloc((void**)&h->d_cnt, (size_t)S * sizeof(int2));
     if (e == hipSuccess) e = alloc((void**)&h->d_act, (size_t)S * sizeof(int));
-    if (e == hipSuccess) e = alloc((void**)&h->d_obs, (size_t)5 * S * sizeof(double));
-    if (e == hipSuccess) e = alloc((void**)&h->d_reward, (size_t)S * sizeof(double));
+    // observation rows and the reward row in ONE allocation, f64[6][stride]: a shard whose size equals its stride hands the
+    // exchange step one contiguous block per rank (rccl.py: rank-major gather)
+    if (e == hipSuccess) e = alloc((void**)&h->d_obs, (size_t)6 * S * sizeof(double));
+    if (e == hipSuccess) h->d_reward = h->d_obs + (size_t)5 * S;
     if (e == hipSuccess) e = alloc((void**)&h->d_done_mask, (size_t)(S / 64) * sizeof(unsigned long long));
     if (e == hipSuccess) e = alloc((void**)&h->d_reason, (size_t)S);
     if (e == hipSuccess) e = alloc((void**)&h->d_stat_sum, sizeof(double));
     if (e == hipSuccess) e = alloc((void**)&h->d_stat_done, sizeof(long long));
     if (e == hipSuccess) e = alloc((void**)&h->d_stats2, 2 * sizeof(double));
+    if (e == hipSuccess) e = alloc((void**)&h->d_wave_sum, (size_t)(S / 64) * sizeof(double));
+    if (e == hipSuccess) e = alloc((void**)&h->d_done_part, (size_t)bsk::stats_done_parts() * sizeof(unsigned));
     if (e == hipSuccess) e = alloc((void**)&h->d_dbg, (size_t)(S / 64) * sizeof(unsigned long long));
     if (e == hipSuccess && (cfg->flags & BSK_FLAG_EPISODE_STATS)) {
         e = alloc((void**)&h->d_ep_return, (size_t)S * sizeof(double));
@@ -808,9 +827,9 @@ void bsk_destroy(bsk_handle* h) {
     for (hipEvent_t ev : h->ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : h->ev_warm)
         if (ev) (void)hipEventDestroy(ev);
-    void* bufs[] = {h->d_state, h->d_cnt, h->d_act, h->d_obs, h->d_reward, h->d_done_mask, h->d_reason,
+    void* bufs[] = {h->d_state, h->d_cnt, h->d_act, h->d_obs /* + d_reward: one block */, h->d_done_mask, h->d_reason,
                     h->d_stat_sum, h->d_stat_done, h->d_ic_stage, h->d_idx_stage, h->d_mask_stage, h->d_cold, h->d_sh_tab, h->d_sh_tab4, h->d_pool, h->d_term_obs, h->d_episodes,
-                    h->d_ep_return, h->d_term_return, h->d_term_len, h->d_done, h->d_obs_rm, h->d_stats2, h->d_dbg};
+                    h->d_ep_return, h->d_term_return, h->d_term_len, h->d_done, h->d_obs_rm, h->d_stats2, h->d_dbg, h->d_wave_sum, h->d_done_part};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (h->h_err) (void)hipHostFree(h->h_err);

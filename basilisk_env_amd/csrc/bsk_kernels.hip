@@ -9,8 +9,7 @@
 //   VGPRs for all `substeps` RK4 steps, and is written back once.  The done flags are reduced per
 //   wavefront (__ballot: one 64-bit mask, one store per wave); the batch's reward sum is formed by stats_kernel
 //   from the reward buffer when somebody asks for it — no atomics, bitwise reproducible.
-// sample_pool_kernel / reset_from_pool_kernel: on-device IC sampler and reset (row f4).
-// stats_kernel: deterministic batch scalars.  scatter_reset_kernel: masked reset from host ICs.
+// (bsk_aux.hip: the small kernels around it - batch scalars, on-device IC sampler, resets.)
 //
 // Replaces run_sim + reward/done logic for N spacecraft:
 //   reference basilisk_env/simulators/leoPowerAttitudeSimulator.py:535-644
@@ -23,12 +22,6 @@
 #define __COMMA__ ,
 
 namespace bsk {
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
 
 // a wave-uniform condition as an integer in a scalar register
 __device__ __forceinline__ int uni(bool b) { return __builtin_amdgcn_readfirstlane(b ? 1 : 0); }
@@ -1023,177 +1016,6 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
     }
 }
 
-// Deterministic batch scalars, one 256-thread workgroup, fixed order: sum of the last step's rewards and number of finished
-// envs.  The step kernel used to leave a per-wave reward sum for this (a six-stage butterfly through the LDS crossbar in every
-// launch's epilogue - a third of a microsecond on the critical path of a 6.5 us launch, for a number asked for once per
-// rollout); now this kernel forms the same sums from the reward buffer itself: wave w of the step kernel = rewards
-// [64 w, 64 w + 64), the same xor butterfly, then - as before - thread t of 256 adds the waves w = t (mod 256) in ascending
-// order and a halving tree joins the 256 partials.  Same operations in the same order: the same bits.
-__global__ __launch_bounds__(256) void stats_kernel(const double* __restrict__ reward, int n,
-                                                    const unsigned long long* __restrict__ done_mask, int n_waves,
-                                                    double* out_sum, long long* out_done, double* out2) {
-    __shared__ double sr[256];
-    __shared__ long long sd[256];
-    const int lane = (int)(threadIdx.x & 63u), hw = (int)(threadIdx.x >> 6);
-    sr[threadIdx.x] = 0.0;
-    __syncthreads();
-    // hardware wave k takes the step kernel's waves w = k (mod 4): their slots w mod 256 are disjoint from the other waves'
-    for (int w = hw; w < n_waves; w += 4) {
-        const int i = 64 * w + lane;
-        const double ws = wave_sum(i < n ? reward[i] : 0.0);
-        if (lane == 0) sr[w & 255] += ws;
-    }
-    long long d = 0;
-    for (int w = threadIdx.x; w < n_waves; w += 256) d += __popcll(done_mask[w]);
-    sd[threadIdx.x] = d;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) {
-            sr[threadIdx.x] += sr[threadIdx.x + off];
-            sd[threadIdx.x] += sd[threadIdx.x + off];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        *out_sum = sr[0];
-        *out_done = sd[0];
-        out2[0] = sr[0]; out2[1] = (double)sd[0];   // {sum reward, #done} as two doubles: one all-reduce operand
-    }
-}
-
-// Scatter a compact IC block [nf][m] into the state slab at env indices idx[0..m) and zero their
-// counters (bsk_reset with a mask; reference reset / reset_init,
-// basilisk_env/envs/leoPowerAttitudeEnvironment.py:172-216).
-__global__ void scatter_reset_kernel(double* __restrict__ st, int64_t stride, int nf, const double* __restrict__ ic,
-                                     const int* __restrict__ idx, int m, int2* __restrict__ cnt) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= m) return;
-    const int e = idx[t];
-    for (int f = 0; f < nf; ++f) st[f * stride + e] = ic[(int64_t)f * m + t];
-    cnt[e] = make_int2(0, 0);
-}
-
-// ---------------------------------------------------------------------------------------------
-// On-device initial-condition sampler (row f4).  Philox4x32-10 (Salmon et al. 2011), written out by
-// hand: counter (slot, draw, 0, 0), key (seed_lo, seed_hi); every call yields four 32-bit words =
-// two 53-bit uniforms, so each pool slot is reproducible independently of every other slot.
-__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
-                                              unsigned* out) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
-        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1,
-                       n3 = (unsigned)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-// two uniforms in [0, 1) with 53 random bits each (same bit recipe as numpy's random_double)
-__device__ __forceinline__ void philox_u2(unsigned slot, unsigned draw, unsigned k0, unsigned k1, double& a, double& b) {
-    unsigned w[4];
-    philox4x32_10(slot, draw, 0u, 0u, k0, k1, w);
-    a = (double)(((unsigned long long)(w[0] >> 5) << 26) | (w[1] >> 6)) * (1.0 / 9007199254740992.0);
-    b = (double)(((unsigned long long)(w[2] >> 5) << 26) | (w[3] >> 6)) * (1.0 / 9007199254740992.0);
-}
-
-__global__ void sample_pool_kernel(double* __restrict__ pool, int n_pool, int n_rw, unsigned k0, unsigned k1, double mu) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_pool) return;
-    const double PI = 3.14159265358979323846, RPM = 2.0 * PI / 60.0;
-    double u[20];
-#pragma unroll
-    for (int d = 0; d < 10; ++d) philox_u2((unsigned)s, (unsigned)d, k0, k1, u[2 * d], u[2 * d + 1]);
-    // orbit: sampled_400km (leo_orbit.py:25-40) -> elem2rv
-    const double a = 6371.0 * 1000.0 + 500.0 * 1000.0;
-    const double e = 0.05 * u[0], inc = PI * u[1] - 0.5 * PI, Om = 2.0 * PI * u[2], om = 2.0 * PI * u[3], f = 2.0 * PI * u[4];
-    const double p = a * (1.0 - e * e), r = p / (1.0 + e * cos(f)), th = om + f;
-    const double ct = cos(th), st = sin(th), cO = cos(Om), sO = sin(Om), ci = cos(inc), si = sin(inc);
-    const double h = sqrt(mu * p), A = st + e * sin(om), B = ct + e * cos(om), mh = -mu / h;
-    auto put = [&](int fld, double v) { pool[(int64_t)fld * n_pool + s] = v; };
-    put(BSK_F_R + 0, r * (cO * ct - sO * st * ci)); put(BSK_F_R + 1, r * (sO * ct + cO * st * ci)); put(BSK_F_R + 2, r * (st * si));
-    put(BSK_F_V + 0, mh * (cO * A + sO * B * ci)); put(BSK_F_V + 1, mh * (sO * A - cO * B * ci)); put(BSK_F_V + 2, mh * (-B * si));
-    // attitude: random_tumble(maxSpinRate = 1e-5) (sc_attitudes.py:3-13, ...Simulator.py:124)
-    put(BSK_F_SIGMA + 0, u[5]); put(BSK_F_SIGMA + 1, u[6]); put(BSK_F_SIGMA + 2, u[7]);
-    put(BSK_F_OMEGA + 0, 1e-5 * (2.0 * u[8] - 1.0)); put(BSK_F_OMEGA + 1, 1e-5 * (2.0 * u[9] - 1.0));
-    put(BSK_F_OMEGA + 2, 1e-5 * (2.0 * u[10] - 1.0));
-    // wheel speeds U(-800, 800) RPM (...Simulator.py:155)
-    for (int k = 0; k < n_rw; ++k) put(BSK_NF_BASE + k, (1600.0 * u[11 + k] - 800.0) * RPM);
-    const int T = BSK_NF_BASE + n_rw;
-    // disturbance torque 2e-4 * N(0,1)^3 (...Simulator.py:151-152, 295): Box-Muller on (u15,u16), (u17,u18)
-    const double r1 = sqrt(-2.0 * log(1.0 - u[15])), r2 = sqrt(-2.0 * log(1.0 - u[17]));
-    put(T + BSK_T_LEXT + 0, 2e-4 * r1 * cos(2.0 * PI * u[16]));
-    put(T + BSK_T_LEXT + 1, 2e-4 * r1 * sin(2.0 * PI * u[16]));
-    put(T + BSK_T_LEXT + 2, 2e-4 * r2 * cos(2.0 * PI * u[18]));
-    for (int k = BSK_T_UCMD; k < BSK_NF_TAIL; ++k) put(T + k, 0.0);
-    // battery U(8, 20) W h (...Simulator.py:167)
-    put(T + BSK_T_CHARGE, (8.0 + 12.0 * u[19]) * 3600.0);
-}
-
-// what a reset leaves in the output buffers of env i: the new episode's first observation (the vec env's convention:
-// |sigma_BN|, |omega|, |Omega| / limit in rad/s, charge / 3600 / power_max, 1), zero reward / reason / done / return
-__device__ __forceinline__ void init_outputs(const ResetOut& ro, const double* __restrict__ st, int64_t stride, int i) {
-    const V3 sg = mk(st[(int64_t)(BSK_F_SIGMA + 0) * stride + i], st[(int64_t)(BSK_F_SIGMA + 1) * stride + i], st[(int64_t)(BSK_F_SIGMA + 2) * stride + i]);
-    const V3 w = mk(st[(int64_t)(BSK_F_OMEGA + 0) * stride + i], st[(int64_t)(BSK_F_OMEGA + 1) * stride + i], st[(int64_t)(BSK_F_OMEGA + 2) * stride + i]);
-    double om2 = 0.0;
-    for (int k = 0; k < ro.n_rw; ++k) {
-        const double v = st[(int64_t)(BSK_NF_BASE + k) * stride + i];
-        om2 = fma(v, v, om2);
-    }
-    const double o[5] = {sqrt_nr(dot(sg, sg)), sqrt_nr(dot(w, w)), sqrt_nr(om2) * ro.inv_wheel_limit,
-                         st[(int64_t)(BSK_NF_BASE + ro.n_rw + BSK_T_CHARGE) * stride + i] * ro.charge_scale, 1.0};
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        ro.obs[(int64_t)k * stride + i] = o[k];
-        if (ro.obs_rm) ro.obs_rm[(int64_t)i * 5 + k] = o[k];
-    }
-    ro.reward[i] = 0.0;
-    ro.reason[i] = 0;
-    if (ro.done) ro.done[i] = 0;
-    if (ro.ep_return) ro.ep_return[i] = 0.0;
-}
-
-// (re)start envs from the pool with the slot rule of the step kernel's auto-reset
-__global__ void reset_from_pool_kernel(double* __restrict__ st, int64_t stride, int nf, const double* __restrict__ pool,
-                                       int n_pool, const unsigned char* __restrict__ mask, int n, int2* __restrict__ cnt,
-                                       int* __restrict__ episodes, unsigned env_base, const ResetOut ro) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || (mask && !mask[i])) return;
-    const int ep = episodes[i];
-    episodes[i] = ep + 1;
-    const unsigned slot = (((unsigned)i + env_base) * 2654435761u + (unsigned)ep * 40503u + 12345u) % (unsigned)n_pool;
-    for (int f = 0; f < nf; ++f) st[f * stride + i] = pool[(int64_t)f * n_pool + slot];
-    cnt[i] = make_int2(0, 0);
-    init_outputs(ro, st, stride, i);
-}
-
-// after a reset from host initial conditions: all n envs (idx == NULL) or the m listed ones
-__global__ void init_outputs_kernel(const double* __restrict__ st, int64_t stride, const int* __restrict__ idx, int m, const ResetOut ro) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= m) return;
-    init_outputs(ro, st, stride, idx ? idx[t] : t);
-}
-
-hipError_t launch_sample_pool(double* pool, int n_pool, int n_rw, unsigned long long seed, double mu, hipStream_t s) {
-    hipLaunchKernelGGL(sample_pool_kernel, dim3((n_pool + 255) / 256), dim3(256), 0, s, pool, n_pool, n_rw,
-                       (unsigned)(seed & 0xFFFFFFFFull), (unsigned)(seed >> 32), mu);
-    return hipGetLastError();
-}
-
-hipError_t launch_reset_from_pool(double* st, int64_t stride, int nf, const double* pool, int n_pool, const unsigned char* mask,
-                                  int n, int2* cnt, int* episodes, unsigned env_base, const ResetOut& ro, hipStream_t s) {
-    hipLaunchKernelGGL(reset_from_pool_kernel, dim3((n + 255) / 256), dim3(256), 0, s, st, stride, nf, pool, n_pool, mask, n, cnt,
-                       episodes, env_base, ro);
-    return hipGetLastError();
-}
-
-hipError_t launch_init_outputs(const double* st, int64_t stride, const int* idx, int m, const ResetOut& ro, hipStream_t s) {
-    if (m <= 0) return hipSuccess;
-    hipLaunchKernelGGL(init_outputs_kernel, dim3((m + 255) / 256), dim3(256), 0, s, st, stride, idx, m, ro);
-    return hipGetLastError();
-}
-
 template <int GRAV, int NRW, bool DIAG>
 static void fill_hot(const StepParams& p, HotCfg<NRW, DIAG>& h) {
     h.h = p.dt; h.h2 = 0.5 * p.dt; h.h3 = p.dt / 3.0; h.h6 = p.dt / 6.0;
@@ -1296,7 +1118,11 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     X(BSK_GRAV_PM, 0, false, -1) X(BSK_GRAV_PM, 3, false, -1) X(BSK_GRAV_PM, 4, false, -1)                   \
     X(BSK_GRAV_PM_J2, 0, false, -1) X(BSK_GRAV_PM_J2, 3, false, -1) X(BSK_GRAV_PM_J2, 4, false, -1)
 #endif
+#if defined(BSK_FAST_BUILD) && BSK_FAST_BUILD == 3   // ... or only the kernel the drop-in env runs, in its three forms (tests/test_dpp_build.py)
+#define BSK_VARIANTS(X) X(BSK_GRAV_PM_J2, 3, true, 2)
+#else
 #define BSK_VARIANTS(X) BSK_VARIANTS_P(X, 0) BSK_VARIANTS_P(X, 1) BSK_VARIANTS_P(X, 2) BSK_VARIANTS_P(X, 3) BSK_VARIANTS_L(X)
+#endif
 
 // pair form (SPLIT == 2): built for the power / full-scenario levels of the point-mass and J2 kernels with a diagonal hub
 template <int G, int R, bool D, int P>
@@ -1352,19 +1178,6 @@ const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat, int sh_form,
     BSK_VARIANTS(CASE)
 #undef CASE
     return nullptr;
-}
-
-hipError_t launch_stats(const double* reward, int n, const unsigned long long* done_mask, int n_waves, double* out_sum,
-                        long long* out_done, double* out2, hipStream_t s) {
-    hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(256), 0, s, reward, n, done_mask, n_waves, out_sum, out_done, out2);
-    return hipGetLastError();
-}
-
-hipError_t launch_scatter_reset(double* st, int64_t stride, int nf, const double* ic, const int* idx, int m, int2* cnt,
-                                hipStream_t s) {
-    if (m <= 0) return hipSuccess;
-    hipLaunchKernelGGL(scatter_reset_kernel, dim3((m + 255) / 256), dim3(256), 0, s, st, stride, nf, ic, idx, m, cnt);
-    return hipGetLastError();
 }
 
 }  // namespace bsk

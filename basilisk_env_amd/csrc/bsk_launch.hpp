@@ -119,32 +119,9 @@ struct StepBuffers {
     unsigned long long* dbg;
 };
 
-// what a reset leaves in the output buffers of the envs it restarts (init_outputs_kernel)
-struct ResetOut {
-    double* obs;                   // [5][stride]
-    double* obs_rm;                // [n][5] or NULL
-    double* reward;                // [stride]
-    unsigned char* reason;         // [stride]
-    unsigned char* done;           // [stride] or NULL
-    double* ep_return;             // [stride] or NULL
-    double inv_wheel_limit, charge_scale;
-    int n_rw;
-};
-
 hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams& p, const StepBuffers& b, int block,
                        hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat, int sh_form, bool pair, bool tri = false);
 bool pair_available(int grav, bool diag, int feat);
 bool tri_available(int grav, bool diag, int feat);
-hipError_t launch_sample_pool(double* pool, int n_pool, int n_rw, unsigned long long seed, double mu, hipStream_t s);
-hipError_t launch_reset_from_pool(double* st, int64_t stride, int nf, const double* pool, int n_pool, const unsigned char* mask,
-                                  int n, int2* cnt, int* episodes, unsigned env_base, const ResetOut& ro, hipStream_t s);
-// first observation [|sigma_BN|, |omega|, |Omega|/limit, charge/3600/power_max, 1], zero reward / reason / done / episode
-// return of freshly reset envs: all n (idx == NULL) or the m listed ones
-hipError_t launch_init_outputs(const double* st, int64_t stride, const int* idx, int m, const ResetOut& ro, hipStream_t s);
-hipError_t launch_stats(const double* reward, int n, const unsigned long long* done_mask, int n_waves, double* out_sum,
-                        long long* out_done, double* out2, hipStream_t s);
-hipError_t launch_scatter_reset(double* st, int64_t stride, int nf, const double* ic, const int* idx, int m, int2* cnt,
-                                hipStream_t s);
-
 }  // namespace bsk

@@ -10,8 +10,22 @@ a DPP read of it, FIVE after a VALU write of EXEC; the compiler's hazard recogni
 selected itself and does not look inside inline asm.  Wherever the register allocator reloads a table row (from an AGPR, a
 copy, a spill) right in front of one of these instructions the DPP read would see the stale register.  So the Makefile
 compiles the device side to assembly, this script inserts exactly the `s_nop`s the hazard recognizer would have, and the
-result is assembled, linked and bundled as hipcc would have done it.  tools/dpp_hazard.py makes the same analysis on the
-disassembly of the built library (tests/test_dpp_hazard.py): the two must agree that nothing is left.
+result is assembled, linked and bundled as hipcc would have done it (hipcc_dpp.py).  tools/dpp_hazard.py makes the same analysis
+on the disassembly of the built library (tests/test_dpp_hazard.py): the two must agree that nothing is left.
+
+WHICH reads are padded (ADVICE r04).  LLVM's GCNHazardRecognizer::checkDPPHazards is more conservative than this pass: it pads
+every VGPR *use* of a DPP instruction - also the accumulator and the plain second factor of `v_fmac_f64_dpp acc, tab, x` - against
+any def.  This pass pads the operand that goes through the DPP crossbar (src0: `tab`, the row the broadcast reads another
+lane's copy of) and nothing else, because that is the read the hardware performs early: the DPP permute of src0 is set up one
+stage ahead of the ordinary operand fetch, which is why a VALU result needs two wait states before a DPP instruction may take
+it as src0 while acc / src1 are fetched with every other VALU operand through the bypass network (an accumulator chain
+`v_fmac_f64_dpp v[2:3], ..` -> `v_fmac_f64_dpp v[2:3], ..` back to back is what the harmonics walk issues 50 000 times per step;
+tools/micro/dpp_rate.hip measures it at full rate with bit-exact sums, and the round-4 failure this pass was written for was a
+stale *src0*).  Padding acc / src1 as well would put an s_nop pair on every broadcast FMA of the hot loops (measured cost of an
+issue slot with one wave per SIMD: DESIGN.md section 4).  The checker shares this model on purpose - it answers "did the pass
+do what it says on what ships" - and the model itself is held by the parity suite: every kernel with DPP operands is compared
+with the CPU oracle at 1e-11 on the GPU (tests/test_gpu_*.py), where a stale accumulator would not survive.
+Two-destination VALU operations (v_swap_b32, v_permlane16/32_swap) write BOTH their operands: counted as writers of both.
 """
 import re
 import sys
@@ -83,6 +97,8 @@ def process(lines):
                 continue
             if op.startswith("v_") and ops:
                 w = regs(ops[0])
+                if (op.startswith("v_swap_") or "permlane16_swap" in op or "permlane32_swap" in op) and len(ops) > 1:
+                    w = (w or set()) | (regs(ops[1]) or set())          # both operands are destinations
                 if w and (w & src) and ws < DPP_VGPR_WAIT:
                     worst = max(worst, DPP_VGPR_WAIT - ws)
                 if op.startswith("v_cmpx") and ws < DPP_EXEC_WAIT:

@@ -144,11 +144,18 @@ class DirectRcclGather(object):
     consumer on the root GPU needs to train on) - no torch tensor, no staging copy, no host synchronisation between the
     step kernel and the exchange.  ``all_reduce_stats`` is the other collective of the path: two doubles per rank."""
 
-    def __init__(self, prop, dist, root=0, group=None, rows=7):
+    def __init__(self, prop, dist, root=0, group=None, rows=7, layout="columns"):
+        """``layout``: "columns" - the root's buffers are ``[5][n_total]`` / ``[n_total]`` / ``u8[n_total]`` in env-index order, one
+        message per row and rank (seven per rank); "rank-major" - the root's buffer holds one ``f64[6][n_r]`` block per rank
+        (observation rows, then the reward row) and the reasons in rank order: ONE f64 message + one u8 message per rank whose
+        shard is contiguous (rccl.py: rank_major_contiguous), fourteen receives on the root of an 8-GPU node instead of 49."""
         from . import _hip, rccl
         if rows not in (5, 7):
             raise ValueError("rows: 5 (observations) or 7 (+ reward, reason)")
-        self.prop, self.root, self.rows = prop, int(root), int(rows)
+        if layout not in ("columns", "rank-major") or (layout == "rank-major" and rows != 7):
+            raise ValueError("layout: 'columns' or 'rank-major' (the latter always moves the seven rows)")
+        self.prop, self.root, self.rows, self.layout = prop, int(root), int(rows), layout
+        self._stats_out = None
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         box = [rccl.unique_id() if self.rank == 0 else None]
@@ -166,23 +173,43 @@ class DirectRcclGather(object):
         if self.rows == 5:
             self.bufs = self.bufs[:1]
         self.bytes_over_fabric = rccl.gather_bytes(self.sizes, self.bufs, self.root)
+        others = [s for r, s in enumerate(self.sizes) if r != self.root and s]
+        if layout == "rank-major":
+            self.rm = rccl.RankMajorBufs(ptr("obs"), v["stride"] * 8, ptr("reward"), ptr("reason"), o, o + 6 * n * 8)
+            self.messages_on_root = rccl.rank_major_messages(self.sizes, self.root)
+        else:
+            self.messages_on_root = len(others) * sum(b.rows for b in self.bufs)
         self.stream = prop.stream_ptr()
+
+    def comm_count(self):
+        """Ranks the communicator spans as RCCL itself reports them (ncclCommCount)."""
+        from . import rccl
+        return rccl.comm_count(self.comm)
 
     def enqueue(self):
         """Queue one gather behind whatever the handle's stream holds (asynchronous)."""
         from . import rccl
         rccl.group_start()
-        rccl.enqueue_gather(self.comm, self.stream, self.root, self.sizes, self.bufs)
+        if self.layout == "rank-major":
+            rccl.enqueue_gather_rank_major(self.comm, self.stream, self.root, self.sizes, self.rm)
+        else:
+            rccl.enqueue_gather(self.comm, self.stream, self.root, self.sizes, self.bufs)
         rccl.group_end()
-        rccl.copy_own(self.comm, self.stream, self.root, self.sizes, self.bufs)
+        if self.layout == "rank-major":
+            rccl.copy_own_rank_major(self.comm, self.stream, self.root, self.sizes, self.rm)
+        else:
+            rccl.copy_own(self.comm, self.stream, self.root, self.sizes, self.bufs)
 
     def all_reduce_stats(self):
         """{sum of rewards, number of done envs} of the whole batch on every rank's GPU: the device-side partial of this rank
-        (bsk_get_batch_stats_device) all-reduced in place on the handle's stream.  -> device pointer of f64[2]."""
-        from . import rccl
-        p = self.prop.batch_stats_device()
-        rccl.all_reduce_sum_f64(self.comm, self.stream, p, p, 2)
-        return p
+        (bsk_get_batch_stats_device; untouched by the collective) all-reduced OUT OF PLACE on the handle's stream into a
+        result block of this object's own - calling it again before the next step gives the same sums again.
+        -> device pointer of the result f64[2]."""
+        from . import _hip, rccl
+        if self._stats_out is None:
+            self._stats_out = _hip.DeviceBuffer(16, self.prop.device)
+        rccl.all_reduce_sum_f64(self.comm, self.stream, self.prop.batch_stats_device(), self._stats_out.ptr, 2)
+        return self._stats_out.ptr
 
     def _view(self, k, shape, typestr):
         from .simulators.dynamics.propagator import _DevArray
@@ -195,16 +222,37 @@ class DirectRcclGather(object):
         return self._view(0, (5, self.n_total), "<f8")
 
     def result_views(self):
-        """Root only: {"obs" (5, n_total), "reward" (n_total,), "reason" (n_total,) uint8}."""
+        """Root only: {"obs" (5, n_total), "reward" (n_total,), "reason" (n_total,) uint8} - layout "columns"."""
+        if self.layout == "rank-major":
+            raise ValueError("rank-major layout: result_blocks()")
         if self.out is None or self.rows != 7:
             return None if self.out is None else {"obs": self.result_view()}
         return {"obs": self.result_view(), "reward": self._view(1, (self.n_total,), "<f8"), "reason": self._view(2, (self.n_total,), "|u1")}
+
+    def result_blocks(self):
+        """Root only, layout "rank-major": per rank {"lo", "hi" (env-index range), "obs" (5, n_r), "reward" (n_r,)} zero-copy views
+        of its block, and "reason" (n_total,) uint8 in env-index order for the whole batch."""
+        from . import rccl
+        from .simulators.dynamics.propagator import _DevArray
+        if self.out is None:
+            return None
+        offs, n = rccl.column_offsets(self.sizes)
+        kw = {"owner": self.prop, "device": self.prop.device, "stream": self.stream}
+        blocks = []
+        for r, n_r in enumerate(self.sizes):
+            base = self.rm.out_f64 + 48 * offs[r]
+            blocks.append({"lo": offs[r], "hi": offs[r] + n_r, "obs": _DevArray(base, (5, n_r), "<f8", **kw),
+                           "reward": _DevArray(base + 40 * n_r, (n_r,), "<f8", **kw)})
+        return {"blocks": blocks, "reason": _DevArray(self.rm.out_u8, (n,), "|u1", **kw)}
 
     def close(self):
         self.comm.destroy()
         if self.out is not None:
             self.out.free()
             self.out = None
+        if self._stats_out is not None:
+            self._stats_out.free()
+            self._stats_out = None
 
 
 def concat_shards(gathered):

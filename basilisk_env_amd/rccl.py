@@ -199,6 +199,97 @@ def copy_own(comm, stream, root, sizes, bufs):
                                 int(sizes[root]) * b.itemsize, b.rows, _hip.hipMemcpyDeviceToDevice, stream)
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# Rank-major root layout: ONE message per rank and data type.  The column-offset form above lands every row of every shard at
+# its place in a [rows][n_total] buffer, which takes `rows` messages per rank and buffer (7 x 7 = 49 receives on the root of an
+# 8-GPU node).  Here the root's buffer is laid out BY RANK - rank r's block is f64[6][n_r] (five observation rows, then the
+# reward row) at byte offset 48 * offs[r], and the done reasons u8[n_total] in rank (= env-index) order behind the f64 part -
+# and the library keeps observation rows and reward row in ONE allocation f64[6][stride] (bsk_create), so a shard whose size
+# equals its stride (n_r a multiple of 256: BASELINE configs[3]'s 131 072 and configs[2]'s 65 536 are) is one contiguous
+# 6 n_r doubles: TWO messages per rank (f64 block, u8 reasons) instead of seven, 14 receives on the root instead of 49.
+# A shard with padding (n_r not a multiple of 256) sends its six rows one by one into the same block (seven messages, as before).
+# Which of the two a rank does is a function of sizes[r] alone, so sender and receiver agree without talking.
+STRIDE_QUANTUM = 256          # bsk_create pads the env stride to a multiple of this
+
+
+def rank_major_contiguous(n_r):
+    return int(n_r) > 0 and int(n_r) % STRIDE_QUANTUM == 0
+
+
+class RankMajorBufs(object):
+    """This rank's sources - obs ``f64[5][pitch]``, reward ``f64[n_r]`` (directly behind the observation rows when the shard is
+    contiguous), reason ``u8[n_r]`` - and the root's rank-major destination: ``out_f64`` (6 * n_total doubles), ``out_u8``
+    (n_total bytes); the ``out_*`` pointers are only read on the root."""
+
+    def __init__(self, obs_ptr, obs_pitch_bytes, reward_ptr, reason_ptr, out_f64, out_u8):
+        self.obs_ptr, self.obs_pitch_bytes, self.reward_ptr, self.reason_ptr = int(obs_ptr), int(obs_pitch_bytes), int(reward_ptr), int(reason_ptr)
+        self.out_f64, self.out_u8 = int(out_f64 or 0), int(out_u8 or 0)
+
+    def contiguous(self, n_r):
+        """The six f64 rows of this shard are one block (the precondition of the single-message form)."""
+        return self.obs_pitch_bytes == 8 * int(n_r) and self.reward_ptr == self.obs_ptr + 5 * self.obs_pitch_bytes
+
+
+def rank_major_messages(sizes, root):
+    """Receives the root posts per gather (= sends of all other ranks together)."""
+    return sum((2 if rank_major_contiguous(n) else 7) for r, n in enumerate(sizes) if r != root and n)
+
+
+def enqueue_gather_rank_major(comm, stream, root, sizes, b):
+    """This rank's part of the rank-major gather (between group_start() and group_end(), every rank of the communicator)."""
+    lib = load()
+    offs, n_total = column_offsets(sizes)
+    vp = C.c_void_p
+    if comm.rank == root:
+        for r in range(comm.world):
+            n_r = int(sizes[r])
+            if r == root or n_r == 0:
+                continue
+            blk = b.out_f64 + 48 * offs[r]
+            if rank_major_contiguous(n_r):
+                _ck(lib.ncclRecv(vp(blk), 6 * n_r, ncclFloat64, r, vp(comm.handle), vp(stream)), "ncclRecv")
+            else:
+                for f in range(6):
+                    _ck(lib.ncclRecv(vp(blk + 8 * f * n_r), n_r, ncclFloat64, r, vp(comm.handle), vp(stream)), "ncclRecv")
+            _ck(lib.ncclRecv(vp(b.out_u8 + offs[r]), n_r, ncclUint8, r, vp(comm.handle), vp(stream)), "ncclRecv")
+        return
+    n_r = int(sizes[comm.rank])
+    if n_r == 0:
+        return
+    if rank_major_contiguous(n_r):
+        if not b.contiguous(n_r):
+            raise RcclError("rank-major gather: a shard of %d envs must be one f64[6][%d] block (observation pitch %d bytes, reward at +%d)"
+                            % (n_r, n_r, b.obs_pitch_bytes, b.reward_ptr - b.obs_ptr))
+        _ck(lib.ncclSend(vp(b.obs_ptr), 6 * n_r, ncclFloat64, root, vp(comm.handle), vp(stream)), "ncclSend")
+    else:
+        for f in range(5):
+            _ck(lib.ncclSend(vp(b.obs_ptr + f * b.obs_pitch_bytes), n_r, ncclFloat64, root, vp(comm.handle), vp(stream)), "ncclSend")
+        _ck(lib.ncclSend(vp(b.reward_ptr), n_r, ncclFloat64, root, vp(comm.handle), vp(stream)), "ncclSend")
+    _ck(lib.ncclSend(vp(b.reason_ptr), n_r, ncclUint8, root, vp(comm.handle), vp(stream)), "ncclSend")
+
+
+def copy_own_rank_major(comm, stream, root, sizes, b):
+    """The root's own shard into its block (after group_end()): observation rows (strided), reward row, reasons."""
+    n_r = int(sizes[root])
+    if comm.rank != root or not n_r:
+        return
+    offs, _ = column_offsets(sizes)
+    blk = b.out_f64 + 48 * offs[root]
+    with _hip.device_guard(comm.device):
+        _hip.memcpy2d_async(blk, 8 * n_r, b.obs_ptr, b.obs_pitch_bytes, 8 * n_r, 5, _hip.hipMemcpyDeviceToDevice, stream)
+        _hip.memcpy2d_async(blk + 40 * n_r, 8 * n_r, b.reward_ptr, 8 * n_r, 8 * n_r, 1, _hip.hipMemcpyDeviceToDevice, stream)
+        _hip.memcpy2d_async(b.out_u8 + offs[root], n_r, b.reason_ptr, n_r, n_r, 1, _hip.hipMemcpyDeviceToDevice, stream)
+
+
+def comm_count(comm):
+    """ncclCommCount: how many ranks this communicator really spans (what a first multi-GPU run reads back as proof)."""
+    lib = load()
+    n = C.c_int(-1)
+    lib.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    _ck(lib.ncclCommCount(C.c_void_p(comm.handle), C.byref(n)), "ncclCommCount")
+    return n.value
+
+
 def enqueue_gather_rows(comm, stream, root, sizes, src_ptr, src_pitch_bytes, rows, out_ptr, itemsize=8, dtype=ncclFloat64):
     """One buffer (the observation rows alone): see enqueue_gather."""
     enqueue_gather(comm, stream, root, sizes, [GatherBuf(src_ptr, src_pitch_bytes, rows, out_ptr, itemsize, dtype)])
@@ -209,7 +300,9 @@ def copy_own_rows(comm, stream, root, sizes, src_ptr, src_pitch_bytes, rows, out
 
 
 def all_reduce_sum_f64(comm, stream, send_ptr, recv_ptr, count):
-    """ncclAllReduce(sum) of ``count`` doubles on ``stream`` (in place when the pointers are equal): the batch scalars
-    {sum of rewards, number of done envs} of a sharded step - two doubles per rank (bsk_get_batch_stats_device)."""
+    """ncclAllReduce(sum) of ``count`` doubles on ``stream``: the batch scalars {sum of rewards, number of done envs} of a
+    sharded step - two doubles per rank.  Callers reduce OUT OF PLACE: the send buffer is the handle's own
+    bsk_get_batch_stats_device() block, which the library only refreshes after the next step - reduced in place, a second
+    call between two steps would sum the already-summed values (world x the batch sum)."""
     _ck(load().ncclAllReduce(C.c_void_p(send_ptr), C.c_void_p(recv_ptr), int(count), ncclFloat64, ncclSum, C.c_void_p(comm.handle), C.c_void_p(stream)),
         "ncclAllReduce")

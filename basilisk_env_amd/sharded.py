@@ -42,6 +42,11 @@ class ShardedPropagator(object):
         self.ranges = [shard_range(self.n_envs, r, world) for r in range(world)]
         self.sizes = [hi - lo for lo, hi in self.ranges]
         self.shards = []
+        self._host = None          # pinned [5 obs rows + reward][n] f64 and [n] u8, made on first get_obs
+        self._comms = None
+        self._stats_out = None     # per-device result blocks of all_reduce_stats_device (out of place)
+        self._gather_buf = None
+        self._pool_exec = None
         try:
             for (lo, hi), d in zip(self.ranges, self.devices):
                 p = propagator_factory(cfg, hi - lo, device=d)
@@ -51,9 +56,6 @@ class ShardedPropagator(object):
             self.close()
             raise
         self._pool_exec = ThreadPoolExecutor(max_workers=world, thread_name_prefix="bsk-shard")
-        self._host = None          # pinned [5 obs rows + reward][n] f64 and [n] u8, made on first get_obs
-        self._comms = None
-        self._gather_buf = None
 
     # ------------------------------------------------------------------ plumbing
     def _each(self, fn):
@@ -70,6 +72,9 @@ class ShardedPropagator(object):
         if self._gather_buf is not None:
             self._gather_buf.free()
             self._gather_buf = None
+        for b in self._stats_out or []:
+            b.free()
+        self._stats_out = None
         for p in self.shards:
             p.close()
         self.shards = []
@@ -253,15 +258,20 @@ class ShardedPropagator(object):
         """Batch scalars of the last step on EVERY shard's GPU: one ncclAllReduce of two doubles {sum of rewards, number of done
         envs} on the handles' streams, operands produced on the device (bsk_get_batch_stats_device) - no host value involved.
         -> list of device pointers (f64[2]), one per shard; a single shard needs no collective."""
-        from . import rccl
+        from . import _hip, rccl
         ptrs = [p.batch_stats_device() for p in self.shards]
         if len(self.shards) > 1:
             if self._comms is None:
                 self._comms = rccl.Comm.init_all(self.devices)
+            if self._stats_out is None:
+                self._stats_out = [_hip.DeviceBuffer(16, d) for d in self.devices]
+            # OUT OF PLACE: the handles' own blocks are only refreshed after the next step - reduced in place, a second call
+            # between two steps would add the already-summed values once more per shard
             rccl.group_start()
-            for c, p, ptr in zip(self._comms, self.shards, ptrs):
-                rccl.all_reduce_sum_f64(c, p.stream_ptr(), ptr, ptr, 2)
+            for c, p, ptr, out in zip(self._comms, self.shards, ptrs, self._stats_out):
+                rccl.all_reduce_sum_f64(c, p.stream_ptr(), ptr, out.ptr, 2)
             rccl.group_end()
+            return [o.ptr for o in self._stats_out]
         return ptrs
 
 

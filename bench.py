@@ -281,6 +281,8 @@ def settle_roofline(roof, key, stamped_us, wall_us, work, peak, fp=None):
         roof["achieved"] = work / used / unit
         roof["frac"] = roof["achieved"] / peak
         roof["frac_stamped"] = work / stamped_us / unit / peak if stamped_us > 0 else None
+        if roof.get("algorithmic_bytes_moved"):
+            roof["frac_on_bytes_moved"] = roof["algorithmic_bytes_moved"] / used / unit / peak
     return roof
 
 
@@ -341,9 +343,22 @@ def fp64_roofline(key, rk4_steps_per_gpu, kernel_s, info):
     return out
 
 
-def hbm_roofline(n, kernel_s, info, traffic_bytes, traffic_src, launches):
+INFINITY_CACHE_BYTES = 256 << 20   # MI355X_MICROARCH.md: 256 MiB of Infinity Cache in front of HBM
+
+
+def hbm_roofline(n, kernel_s, info, traffic_bytes, traffic_src, launches, static_o3=True, n_fields=47):
+    """``static_o3``: the bare levels neither load the battery charge nor store obs[3] when no battery of the batch started empty
+    (StepArgs::static_charge): 8 of the 340 algorithmic bytes do not move - ``algorithmic_bytes_moved`` / ``frac_on_bytes_moved``
+    say so, ``frac`` stays priced on SURVEY.md section 8(d)'s 340.  ``working_set``: a batch whose slab and outputs fit the Infinity
+    Cache is served from it between launches - its fraction is cache bandwidth priced on the HBM peak, not an HBM figure."""
     achieved = BYTES_PER_ENV_STEP * n / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    stride = (n + 255) // 256 * 256
+    footprint = (n_fields + 6 + 1) * stride * 8 + stride * 2
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "algorithmic_bytes_moved": (BYTES_PER_ENV_STEP - (8.0 if static_o3 else 0.0)) * n,
+            "working_set_bytes": footprint,
+            "working_set": ("cache-resident working set (%.0f MB of state + outputs against the 256 MiB Infinity Cache): the fraction is cache bandwidth priced on the HBM peak" % (footprint / 1e6)
+                            if footprint < INFINITY_CACHE_BYTES else "streams from HBM (%.0f MB per launch working set)" % (footprint / 1e6)),
             "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS, "copy_ceiling": HBM_COPY_CEILING_GBS,
             "traffic": traffic_bytes, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
             "algorithmic_bytes": BYTES_PER_ENV_STEP * n, "kernel": info["name"], "kernel_us": kernel_s * 1e6,
@@ -401,14 +416,28 @@ def direct_rccl_leg(prop, dist, torch, world, clock):
     reason: SURVEY.md section 8(e)); then the one all-reduce of the path, {sum of rewards, number of done envs} as two doubles
     from device-side partials.  Checked against the torch leg / the host sums on rank 0."""
     from basilisk_env_amd.parallel import DirectRcclGather, ObsGatherer, concat_shards
-    out = {}
-    for rows in (5, 7):
-        d = DirectRcclGather(prop, dist, root=0, rows=rows)
+    out = {"messages_on_root": {}}
+    for rows, layout in ((5, "columns"), (7, "columns"), (7, "rank-major")):
+        d = DirectRcclGather(prop, dist, root=0, rows=rows, layout=layout)
         try:
             ms = clock(d.enqueue)
-            key = "direct_rccl_gather_to_rank0" if rows == 5 else "direct_rccl_gather7_to_rank0"
+            key = "direct_rccl_gather_to_rank0" if rows == 5 else ("direct_rccl_gather7_to_rank0" if layout == "columns" else "direct_rccl_gather7_rank_major")
             out[key + "_ms"] = ms
             out.setdefault("bytes", {})[key] = d.bytes_over_fabric
+            out["messages_on_root"][key] = d.messages_on_root          # receives the root posts per gather
+            out["nccl_comm_count"] = d.comm_count()                    # ranks RCCL itself says the direct communicator spans
+            if layout == "rank-major":
+                # same data as the column form, one block per rank: checked against this rank's own buffers on the root
+                prop.sync()
+                if dist.get_rank() == 0:
+                    rb = d.result_blocks()
+                    own = rb["blocks"][0]
+                    got_o = torch.as_tensor(own["obs"], device="cuda")
+                    got_r = torch.as_tensor(own["reward"], device="cuda")
+                    v = prop.device_views()
+                    out["direct_rccl_rank_major_matches_own_shard"] = bool(torch.equal(got_o, torch.as_tensor(v["obs"], device="cuda")) and
+                                                                           torch.equal(got_r, torch.as_tensor(v["reward"], device="cuda")))
+                continue
             if rows == 5:
                 ref = ObsGatherer(prop, dist).gather(0)
                 if dist.get_rank() == 0:
@@ -435,7 +464,8 @@ def direct_rccl_leg(prop, dist, torch, world, clock):
                     out["direct_rccl_gather7_shapes"] = [list(rew.shape), list(why.shape)]
         finally:
             d.close()
-    out["direct_rccl_form"] = "one group of ncclSend/ncclRecv per gather, rows straight into rank 0's buffers, handle stream; 7 = obs(5) + reward + reason"
+    out["direct_rccl_form"] = ("one group of ncclSend/ncclRecv per gather, rows straight into rank 0's buffers, handle stream; 7 = obs(5) + reward + reason; "
+                               "rank_major = rank 0's buffer holds one f64[6][n_r] block per rank: 2 messages per rank instead of 7 (rccl.py)")
     return out
 
 
@@ -455,6 +485,46 @@ def with_deadline(seconds, on_timeout, fn):
         return fn()
     finally:
         done.set()
+
+
+def guarded_leg(out, rank, seconds, leg, exit_fn=os._exit):
+    """Run the auxiliary collective ``leg()`` (-> dict merged into ``out['gather']``) under a watchdog: if it has not returned
+    after ``seconds`` every rank gives up - rank 0 still prints the ONE JSON line - and the process ends with status 3, so that
+    the launcher records a failure (never a re-exec: this process has initialised the GPU).  BENCH_FAULT_HANG_LEG=1 replaces the
+    leg by one that never returns (rehearsal of exactly this path; tests/test_bench_host.py)."""
+    def give_up():
+        out.setdefault("gather", {})["direct_rccl"] = "timeout after %g s: leg abandoned" % seconds
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        exit_fn(3)
+
+    if os.environ.get("BENCH_FAULT_HANG_LEG") == "1":
+        import threading
+        leg = threading.Event().wait          # blocks for ever
+    try:
+        res = with_deadline(seconds, give_up, leg)
+        out.setdefault("gather", {}).setdefault("bytes", {}).update(res.pop("bytes", {}))
+        out["gather"].update(res)
+    except Exception as e:
+        out.setdefault("gather", {})["direct_rccl_error"] = repr(e)
+
+
+def rank_identity(torch, dist, rank, local, world):
+    """Which HIP device every rank bound and how many ranks its process group spans, gathered on rank 0 (and printed per rank
+    on stderr): the first real multi-GPU record must show N ranks on N distinct devices."""
+    p = torch.cuda.get_device_properties(local)
+    me = {"rank": rank, "local_rank": local, "hip_device": int(torch.cuda.current_device()), "name": p.name,
+          "pci_bus_id": getattr(p, "pci_bus_id", None), "uuid": str(getattr(p, "uuid", "")), "pid": os.getpid(),
+          "process_group_size": int(dist.get_world_size()) if dist is not None else 1,
+          "backend": dist.get_backend() if dist is not None else None}
+    sys.stderr.write("[bench rank %d/%d] hip device %d (%s, pci bus %s), process group of %d over %s\n"
+                     % (rank, world, me["hip_device"], me["name"], me["pci_bus_id"], me["process_group_size"], me["backend"]))
+    sys.stderr.flush()
+    if dist is None:
+        return [me]
+    box = [None] * world
+    dist.all_gather_object(box, me)
+    return box
 
 
 def profile_key(a, sh):
@@ -504,6 +574,67 @@ def fp64_point(key, mix_key, prop, d_ptr, n, substeps, steps, warmup, stamped, b
         roof["executed_frac"] = roof["executed_tflops"] / FP64_PEAK_TFLOPS
     return {"env_steps_per_s": n * steps / el, "rk4_substeps_per_s": n * steps * substeps / el, "ms_per_step": el / steps * 1e3,
             "kernel_ms": roof["kernel_us"] * 1e-3, "roofline": roof}
+
+
+def batch_stats_point(torch, cfg, n, n_rw, local, sample_ic_batch, BatchedPropagator, steps):
+    """What asking for the batch scalars after EVERY step costs (bsk_get_batch_stats_device: stats_kernel enqueued behind the
+    step kernel, no synchronisation): wall time per step of a back-to-back loop with and without the request.  The kernel's own
+    duration is in the committed rocprofv3 trace (profiles/r05/kt_stats_*.csv)."""
+    p = BatchedPropagator(cfg, n, device=local)
+    p.reset(sample_ic_batch(n, n_rw, seed=5))
+    act = torch.zeros(n, dtype=torch.int32, device="cuda")
+    dp = act.data_ptr()
+
+    def loop(with_stats):
+        for _ in range(max(steps // 10, 5)):
+            p.step_device(dp, 1)
+            if with_stats:
+                p.batch_stats_device()
+        p.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            p.step_device(dp, 1)
+            if with_stats:
+                p.batch_stats_device()
+        p.sync()
+        return (time.perf_counter() - t0) / steps * 1e6
+
+    base = min(loop(False) for _ in range(3))
+    both = min(loop(True) for _ in range(3))
+    rsum, ndone = p.batch_stats()
+    rew = p.get_obs()[1]
+    ok = abs(rsum - float(rew.sum())) < 1e-9 * max(1.0, abs(float(rew.sum())))
+    p.close()
+    return {"envs": n, "step_us": base, "step_plus_stats_us": both, "added_us_per_step": both - base, "matches_host_sum": bool(ok),
+            "stats_grid": max(1, min((((n + 63) // 64) + 3) // 4, 2048))}
+
+
+def vecenv_episode_end(n, device_pool):
+    """Host time of LeoPowerAttVecEnv.step_wait at the step where EVERY episode of the batch ends (max_length = 2, so every third
+    step; with the reference's max_length = 540 and a common reset() it is every 541st) beside an ordinary step: the surface
+    stable-baselines drops in on.  278 ms (device pool) / 425 ms (host resets) before round 5."""
+    import numpy as np
+    from basilisk_env_amd.envs import LeoPowerAttVecEnv
+    kw = {"n_rw": 4, "step_duration": 0.1, "seed": 0, "device_reset_pool": device_pool, "device_sampler": bool(device_pool)}
+    probe = LeoPowerAttVecEnv(64, **kw)
+    cfg = probe.cfg.copy()
+    probe.close()
+    cfg.max_length = 2
+    env = LeoPowerAttVecEnv(n, cfg=cfg, **kw)
+    env.reset()
+    acts = np.zeros(n, np.int64)
+    ordinary, all_done = [], []
+    for _ in range(12):
+        env.step_async(acts)
+        t0 = time.perf_counter()
+        _, _, done, infos = env.step_wait()
+        dt = (time.perf_counter() - t0) * 1e3
+        (all_done if done.all() else ordinary).append(dt)
+    one = infos[0] if all_done else None
+    env.close()
+    srt = lambda v: sorted(v)[len(v) // 2] if v else None     # noqa: E731
+    return {"envs": n, "device_reset_pool": device_pool, "ordinary_step_wait_ms": srt(ordinary), "all_done_step_wait_ms": srt(all_done),
+            "all_done_steps_seen": len(all_done), "terminal_info_keys": sorted(one.keys()) if one else None}
 
 
 def rl_loop(torch, n, substeps, steps, warmup=10):
@@ -652,7 +783,7 @@ def main():
     value = n * world * a.steps / el
     kernel_s = kernel_ms * 1e-3
     traffic_bytes, traffic_src = pmc_traffic(n, a.substeps) if (not sh and a.scenario == "bare") else (None, None)
-    hbm = hbm_roofline(n, kernel_s, info, traffic_bytes, traffic_src, n_launch)
+    hbm = hbm_roofline(n, kernel_s, info, traffic_bytes, traffic_src, n_launch, static_o3=a.scenario == "bare" and not sh)
     hbm.update(kstats)
     settle_roofline(hbm, key, kernel_ms * 1e3, wall_us, BYTES_PER_ENV_STEP * n, HBM_PEAK_GBS, fp)
     hbm["frac_of_copy_ceiling"] = hbm["achieved"] / HBM_COPY_CEILING_GBS
@@ -687,7 +818,8 @@ def main():
                                % ("4" if sh else "2", n, "degree-70 spherical-harmonic (synthetic Kaula field)" if sh else "J2",
                                   a.substeps),
                    "envs_per_gpu": n, "substeps": a.substeps, "scenario": a.scenario, "lds_scratch": bool(a.lds_scratch), "fsw_timing": a.fsw_timing, "features": a.features,
-                   "sharding": "env ranges, no step-path collective", "kernel_fingerprint": fp},
+                   "sharding": "env ranges, no step-path collective", "kernel_fingerprint": fp,
+                   "batch_stats": "on demand (bsk_get_batch_stats*: one launch of stats_kernel; a step produces the per-wave done ballot, no reward reduction)"},
         "roofline": fp64 if fp64_bound else hbm,
         "rk4_substeps_per_s": value * a.substeps,
     }
@@ -696,6 +828,10 @@ def main():
     if sh:
         out["sh"] = {"degree": 70, "field_evals_per_s": n * world * a.steps * a.substeps * 4 / el}
 
+    ranks = rank_identity(torch, dist, rank, local, world)
+    if rank == 0:
+        out["ranks"] = ranks
+        out["distinct_devices"] = len({(r["pci_bus_id"], r["uuid"], r["hip_device"]) for r in ranks})
     clock = None
     if dist is not None:
         out["gather"] = gather_legs(prop, dist, torch, world, n)
@@ -816,6 +952,17 @@ def main():
                                         "what": "bsk_step (host int32 actions) + bsk_get_obs (obs, reward, reason -> pinned host arrays), synchronised every step"}
         except Exception as e:
             extra["host_buffers_k1"] = {"error": repr(e)}
+        # the batch scalars on demand (row a7): what bsk_get_batch_stats_device after every step adds, at four batch sizes
+        try:
+            extra["batch_stats_us"] = {str(nn): batch_stats_point(torch, cfg, nn, n_rw, local, sample_ic_batch, BatchedPropagator, st_)
+                                       for nn, st_ in ((65536, 3000), (131072, 2000), (1 << 20, 400), (1 << 22, 120))}
+        except Exception as e:
+            extra["batch_stats_us"] = {"error": repr(e)}
+        # the VecEnv's host path at a synchronized episode end (every env of the batch finishes on the same step)
+        try:
+            extra["vecenv_episode_end_ms"] = {"device_pool": vecenv_episode_end(n, 4096), "host_resets": vecenv_episode_end(n, 0)}
+        except Exception as e:
+            extra["vecenv_episode_end_ms"] = {"error": repr(e)}
         # the device-resident RL loop (row f4): on-GPU policy -> step_tensors, at K = 1 and at the reference's K = 1 800
         try:
             extra["rl_loop"] = {"k1": rl_loop(torch, n, 1, 200), "k1800": rl_loop(torch, n, 1800, 200 if a.steps >= 1000 else 40)}
@@ -874,20 +1021,11 @@ def main():
             c5 = default_config(n_rw=n_rw, gravity_model=GRAV_SH)
             c5.sh_degree = 70
             extra["sh70"]["cpu_baseline"] = cpu_baseline(c5, n_rw, 1, budget_s=5.0, n=256, sh=70)
-    if dist is not None and not rehearsal and os.environ.get("BSKGPU_DIRECT_RCCL", "1") != "0":
+    hang = os.environ.get("BENCH_FAULT_HANG_LEG") == "1"
+    if dist is not None and (not rehearsal or hang) and os.environ.get("BSKGPU_DIRECT_RCCL", "1") != "0":
         # last, and under a watchdog: if the direct-RCCL leg (a second communicator, never run on more than one rank
         # before the driver's 8-GPU node) hangs, every rank gives up after 90 s and rank 0 still prints the line
-        def give_up():
-            out["gather"]["direct_rccl"] = "timeout after 90 s: leg abandoned"
-            if rank == 0:
-                print(json.dumps(out), flush=True)
-            os._exit(3)      # the line is out, but a collective deadlocked: the launcher must see a failure (never a re-exec)
-        try:
-            leg = with_deadline(90.0, give_up, lambda: direct_rccl_leg(prop, dist, torch, world, clock))
-            out["gather"].setdefault("bytes", {}).update(leg.pop("bytes", {}))
-            out["gather"].update(leg)
-        except Exception as e:
-            out["gather"]["direct_rccl_error"] = repr(e)
+        guarded_leg(out, rank, float(os.environ.get("BENCH_LEG_DEADLINE_S", "90")), lambda: direct_rccl_leg(prop, dist, torch, world, clock))
     prop.close()
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -236,9 +236,19 @@ int bsk_get_obs_device(bsk_handle* h, double** d_obs, double** d_reward, uint64_
  *               step ('l' = env steps taken before this one, as the reference counts: ...Environment.py:133)
  *   done        u8[stride]   0 / 1 (a torch.bool view needs no kernel)
  *   obs_rowmajor f64[n_envs][5]
- * Every reset entry point (bsk_reset, bsk_reset_from_pool*, the step kernel's own auto-reset) leaves the NEW episode's first
- * observation [|sigma_BN|, |omega|, |Omega|/limit, charge/3600/power_max, 1] in the observation buffers and zero in reward, reason,
- * done and ep_return of the envs it restarts, so that a device-resident loop never has to compute or upload a reset observation. */
+ * Every reset leaves the NEW episode's first observation [|sigma_BN|, |omega|, |Omega|/limit, charge/3600/power_max, 1] in the
+ * observation buffers of the envs it restarts, so that a device-resident loop never has to compute or upload a reset observation.
+ *  - The step kernel's own auto-reset (BSK_FLAG_AUTO_RESET) KEEPS that step's reward, reason and done byte - the finished episode's
+ *    last transition is what the step reports - and zeroes only ep_return (the new episode's running return).
+ *  - The explicit entry points (bsk_reset, bsk_reset_from_pool, bsk_reset_from_pool_device) ALSO zero reward, reason, done and
+ *    ep_return of the envs they restart: a consumer that reads those buffers on the device must have consumed the last step's
+ *    values - or be ordered before the reset on the handle's stream - before it calls a masked reset entry point, or the
+ *    terminal reward and penalty of the restarted envs are gone (bsk_get_batch_stats* still report the last step's sums: the
+ *    snapshot is taken before the zeroing).
+ * HIP graphs: the device-resident entry points (bsk_step_device*, bsk_reset_from_pool_device, bsk_get_batch_stats_device) may be
+ * captured.  The library notices the capture and from then on evaluates nothing at enqueue time for that handle (batch scalars
+ * are re-formed on every request, the bare levels read the battery charge in every launch), so replays stay correct after a later
+ * bsk_set_state / bsk_set_ic_pool / bsk_reset; launch GEOMETRY (substeps, kernel form) is what was captured. */
 int bsk_get_episode_device(bsk_handle* h, double** d_ep_return, double** d_term_return, int32_t** d_term_len, uint8_t** d_done,
                            double** d_obs_rowmajor);
 int bsk_get_stream(bsk_handle* h, void** stream);
@@ -246,9 +256,11 @@ int bsk_get_terminal_obs_device(bsk_handle* h, double** d_term_obs, int32_t** d_
 int bsk_get_state_device(bsk_handle* h, double** d_state, int64_t* stride);
 
 /* Batch scalars of the LAST STEP: sum of its rewards and number of done envs, formed in a fixed order (bitwise
- * reproducible) from the reward buffer and the per-wave done ballots by a small kernel of their own - once, when first asked
- * for, or just before a reset entry point zeroes the restarted envs' rewards; the step kernel's epilogue carries no reward
- * reduction.  (Synchronises.) */
+ * reproducible: per 64 envs an xor butterfly, the wave sums w = t mod 256 added in ascending order by thread t, a halving tree
+ * over the 256 partials) from the reward buffer and the per-wave done ballots by ONE launch of a kernel of their own (a
+ * multi-workgroup first level, the last workgroup to finish joins the partials) - once, when first asked for, or just before a
+ * reset entry point zeroes the restarted envs' rewards.  A step does NOT produce them: its epilogue carries the done ballot
+ * (one 64-bit mask per wave) and no reward reduction.  (Synchronises.) */
 int bsk_get_batch_stats(bsk_handle* h, double* reward_sum, int64_t* n_done);
 /* The same two scalars left ON the device as f64[2] = {sum of rewards, number of done envs}, enqueued on the handle's stream
  * without synchronising: the operand of the one all-reduce a sharded batch needs. */

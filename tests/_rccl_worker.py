@@ -41,11 +41,38 @@ def main():
     rew = torch.tensor([prop.batch_stats()[0]], dtype=torch.float64, device="cuda")
     dist.all_reduce(rew)
     torch.cuda.synchronize()
+    # the direct librccl leg in its rank-major form (one f64[6][n_r] block per rank), RCCL's own rank count, and the batch
+    # scalars' all-reduce called TWICE between two steps (out of place: the second call must give the same sums)
+    import ctypes
+    from basilisk_env_amd import _hip
+    from basilisk_env_amd.parallel import DirectRcclGather
+    d = DirectRcclGather(prop, dist, root=0, rows=7, layout="rank-major")
+    d.enqueue()
+    sums = []
+    for _ in range(2):
+        p = d.all_reduce_stats()
+        host = (ctypes.c_double * 2)()
+        prop.sync()
+        _hip.check(_hip.runtime().hipMemcpyAsync(ctypes.cast(host, ctypes.c_void_p), ctypes.c_void_p(p), 16, _hip.hipMemcpyDeviceToHost, ctypes.c_void_p(0)), "hipMemcpyAsync")
+        torch.cuda.synchronize()
+        sums.append([host[0], host[1]])
+    rb = d.result_blocks()
+    blk_obs = torch.cat([torch.as_tensor(b["obs"], device="cuda") for b in rb["blocks"]], dim=1)
+    blk_rew = torch.cat([torch.as_tensor(b["reward"], device="cuda") for b in rb["blocks"]])
+    blk_why = torch.as_tensor(rb["reason"], device="cuda")
+    meta = {"comm_count": d.comm_count(), "messages_on_root": d.messages_on_root, "sums": sums}
     if rank == 0:
         np.save(os.path.join(out_dir, "obs_full.npy"), full.cpu().numpy())
         np.save(os.path.join(out_dir, "obs_root.npy"), concat_shards(rooted).cpu().numpy())
         np.save(os.path.join(out_dir, "rew_sum.npy"), rew.cpu().numpy())
+        np.save(os.path.join(out_dir, "rm_obs.npy"), blk_obs.cpu().numpy())
+        np.save(os.path.join(out_dir, "rm_rew.npy"), blk_rew.cpu().numpy())
+        np.save(os.path.join(out_dir, "rm_why.npy"), blk_why.cpu().numpy())
+        import json
+        with open(os.path.join(out_dir, "meta.json"), "w") as f:
+            json.dump(meta, f)
     dist.barrier()
+    d.close()
     prop.close()
     dist.destroy_process_group()
 

@@ -278,3 +278,37 @@ def test_with_deadline_returns_fn_result_and_fires_only_on_overrun():
         raise AssertionError("the leg's exception was swallowed")
     time.sleep(0.4)
     assert not fired.is_set()
+
+
+def test_a_hung_collective_leg_ends_in_status_3_with_exactly_one_json_line():
+    """Rehearsal of the watchdog's failure path (bench.py: guarded_leg): a deliberately hung auxiliary leg
+    (BENCH_FAULT_HANG_LEG=1 swaps it for one that never returns) must neither take the bench line with it nor look like
+    success - rank 0 prints the ONE JSON line, the process ends with status 3 (os._exit: no re-exec, no atexit work on a
+    process that has touched the GPU), every other rank prints nothing and ends with 3 as well."""
+    code = "\n".join([
+        "import importlib.util, sys, os",
+        "spec = importlib.util.spec_from_file_location('bench_module', %r)" % os.path.join(ROOT, "bench.py"),
+        "b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)",
+        "out = {'metric': 'm', 'value': 1.0, 'gather': {'all_gather_ms': 0.5}}",
+        "b.guarded_leg(out, int(sys.argv[1]), 0.3, lambda: {'never': 'reached'})",
+        "print('not reached')"])
+    env = dict(os.environ, BENCH_FAULT_HANG_LEG="1")
+    for rank in (0, 1):
+        res = subprocess.run([sys.executable, "-c", code, str(rank)], capture_output=True, text=True, timeout=60, env=env)
+        assert res.returncode == 3, (res.returncode, res.stderr[-500:])
+        lines = [l for l in res.stdout.splitlines() if l.strip()]
+        if rank == 0:
+            assert len(lines) == 1, lines
+            d = json.loads(lines[0])
+            assert d["value"] == 1.0 and d["gather"]["all_gather_ms"] == 0.5 and "timeout after 0.3 s" in d["gather"]["direct_rccl"]
+        else:
+            assert lines == []
+    # ... and a leg that returns in time is merged into the line, its byte counts beside the others', no exit
+    b = _load_bench()
+    out = {"gather": {"bytes": {"all_gather": 10}}}
+    os.environ.pop("BENCH_FAULT_HANG_LEG", None)
+    b.guarded_leg(out, 0, 5.0, lambda: {"x_ms": 1.0, "bytes": {"direct": 7}}, exit_fn=lambda c: (_ for _ in ()).throw(AssertionError("fired")))
+    assert out["gather"] == {"bytes": {"all_gather": 10, "direct": 7}, "x_ms": 1.0}
+    out = {}
+    b.guarded_leg(out, 0, 5.0, lambda: 1 // 0)
+    assert "ZeroDivisionError" in out["gather"]["direct_rccl_error"]

@@ -274,6 +274,73 @@ def test_batch_stats_reward_sum_has_a_fixed_order(n):
     p.close()
 
 
+@pytest.mark.parametrize("n", [65536, 131072 + 77, (1 << 20) + 77, 1 << 22])
+def test_batch_stats_order_holds_at_every_scale(n):
+    """The two-level stats_kernel (a multi-workgroup first level, the last workgroup joins the wave sums) gives the documented
+    tree bit for bit from one workgroup's worth of envs to 4 Mi (2 048 workgroups, eight trips each), the done count included,
+    and asking twice - or through the device pointer - changes nothing."""
+    import ctypes
+    cfg = default_config(4, GRAV_PM_J2)
+    cfg.max_length = 1
+    p = BatchedPropagator(cfg, n)
+    p.reset(sample_ic_batch(n, 4, seed=22))
+    rng = np.random.default_rng(n)
+    for k in range(3):
+        p.step(rng.integers(0, 3, n).astype(np.int32), 1)
+        s, d = p.batch_stats()
+        obs, rew, done, why = p.get_obs()
+        assert s == _stats_order(rew) and d == int((why != 0).sum()), (n, k)
+        assert (d > 0) == (k >= 1)                                  # episodes of max_length 1 end from the second step on
+        assert p.batch_stats() == (s, d)
+        ptr = p.batch_stats_device()
+        p.sync()
+        from basilisk_env_amd import _hip
+        host = (ctypes.c_double * 2)()
+        _hip.check(_hip.runtime().hipMemcpyAsync(ctypes.cast(host, ctypes.c_void_p), ctypes.c_void_p(ptr), 16, _hip.hipMemcpyDeviceToHost, ctypes.c_void_p(0)), "hipMemcpyAsync")
+        _hip.stream_sync(0)
+        assert (host[0], host[1]) == (s, float(d))
+    p.close()
+
+
+def test_a_captured_graph_stays_correct_after_the_host_state_it_was_recorded_under_has_changed():
+    """host-side decisions evaluated at enqueue time (the bare levels' static_charge, the batch scalars' freshness)
+    would be frozen into a captured launch.  A step of the BARE kernel and a batch-stats request are captured while every
+    battery is charged, then bsk_set_state empties some batteries: the replayed graph must report them (battery-empty
+    termination, obs[3] = 0) and the replayed stats request must describe the replayed step, not the one before."""
+    import torch
+    n = 1000
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        cfg = default_config(4, GRAV_PM_J2)
+        p = BatchedPropagator(cfg, n, stream=side.cuda_stream)
+        ic = sample_ic_batch(n, 4, seed=23)
+        p.reset(ic)
+        act = torch.zeros(n, dtype=torch.int32, device="cuda")
+        for _ in range(3):
+            p.step_device(act.data_ptr(), 1)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            p.step_device(act.data_ptr(), 1)
+            stats_ptr = p.batch_stats_device()
+        graph.replay()
+        torch.cuda.synchronize()
+        obs, rew, done, why = p.get_obs()
+        assert not (why & 4).any()
+        st = p.get_state()
+        t = 12 + 4
+        st[t + 7, ::10] = 0.0                                       # every tenth battery is empty now
+        p.set_state(st)
+        graph.replay()
+        torch.cuda.synchronize()
+        obs, rew, done, why = p.get_obs()
+        assert np.array_equal((why & 4) != 0, np.arange(n) % 10 == 0) and np.all(obs[3, ::10] == 0.0) and np.all(obs[3, 1::10] > 0.0)
+        s, d = p.batch_stats()
+        assert s == _stats_order(rew) and d == int((why != 0).sum()) == n // 10
+        del graph
+        p.close()
+
+
 def test_step_tensors_loop_is_hip_graph_capturable():
     """The device-resident loop - policy kernels + step kernel + device-side auto-reset - captured in a HIP graph and replayed
     gives exactly what the eager loop gives: step_tensors launches on the capturing stream and issues nothing a capture

@@ -44,6 +44,15 @@ def test_rccl_gather_single_rank(tmp_path):
     assert np.abs(full - obs).max() < 1e-11
     assert np.array_equal(np.load(tmp_path / "obs_root.npy"), full)
     assert abs(np.load(tmp_path / "rew_sum.npy")[0] - rew.sum()) < 1e-10
+    # the direct leg, rank-major root layout: the same observations, rewards and reasons, one block per rank
+    import json
+    assert np.array_equal(np.load(tmp_path / "rm_obs.npy"), full)
+    assert np.abs(np.load(tmp_path / "rm_rew.npy") - rew).max() < 1e-12 and np.array_equal(np.load(tmp_path / "rm_why.npy"), why)
+    meta = json.load(open(tmp_path / "meta.json"))
+    assert meta["comm_count"] == 1 and meta["messages_on_root"] == 0          # one rank: RCCL says so; nothing crosses the fabric
+    # ... and the batch scalars' all-reduce twice between two steps: the same sums both times (in place it doubled)
+    assert meta["sums"][0] == meta["sums"][1]
+    assert abs(meta["sums"][0][0] - rew.sum()) < 1e-10 and meta["sums"][0][1] == float((why != 0).sum())
 
 
 def test_bench_collective_legs_on_rccl_single_rank(tmp_path):
@@ -68,6 +77,12 @@ def test_bench_collective_legs_on_rccl_single_rank(tmp_path):
     assert g["shard_bytes"] == 5 * 65536 * 8
     # the direct librccl leg (its own communicator from ncclCommInitRank, gather on the handle's stream) ran and agrees
     assert g.get("direct_rccl_matches_torch_gather") is True and g["direct_rccl_gather_to_rank0_ms"] > 0, g
+    # both root layouts of the seven-row form, their message counts, RCCL's own rank count, the all-reduce after repeated calls
+    assert g["direct_rccl_gather7_to_rank0_ms"] > 0 and g["direct_rccl_gather7_rank_major_ms"] > 0, g
+    assert g.get("direct_rccl_rank_major_matches_own_shard") is True and g.get("all_reduce_stats_matches_host_sums") is True, g
+    assert g["nccl_comm_count"] == 1 and set(g["messages_on_root"]) == {"direct_rccl_gather_to_rank0", "direct_rccl_gather7_to_rank0", "direct_rccl_gather7_rank_major"}
+    assert len(d["ranks"]) == 1 and d["ranks"][0]["process_group_size"] == 1 and d["ranks"][0]["backend"] == "nccl" and d["distinct_devices"] == 1
+    assert d["config"]["batch_stats"].startswith("on demand")
     x = d["extra"]
     assert "1048576" not in x["config3"]["workload"] and "131072 per GPU" in x["config3"]["workload"]
     assert x["config3"]["gather"]["shard_bytes"] == 5 * 131072 * 8

@@ -238,3 +238,139 @@ def test_dlpack_capsule_roundtrip_on_host_memory():
     gc.collect()
     assert _dlpack.live_exports() == before
     assert _dlpack.typestr_to_dl("|u1").bits == 8 and _dlpack.typestr_to_dl("<i4").code == 0
+
+
+def test_rank_major_gather_address_arithmetic(monkeypatch):
+    """rccl.enqueue_gather_rank_major / copy_own_rank_major: the root's buffer holds ONE f64[6][n_r] block per rank (five
+    observation rows, then the reward row) and the reasons in env-index order.  A shard whose size equals its stride (a multiple
+    of 256: the library keeps observation rows and reward row in one allocation) travels as TWO messages - 6 n_r doubles, n_r
+    bytes - instead of seven; a padded shard sends its rows one by one into the same block.  Played back against numpy buffers
+    with a fake librccl, like the column-offset form above."""
+    import ctypes
+
+    from basilisk_env_amd import _hip, rccl
+
+    sizes = [256, 300, 512, 256]                   # ranks 0, 2, 3 contiguous; rank 1 padded (stride 512)
+    strides = [256, 512, 512, 256]
+    n_total, root = sum(sizes), 3
+    blocks = [np.arange(6 * st, dtype=np.float64).reshape(6, st) + 10000 * (r + 1) for r, st in enumerate(strides)]     # obs rows 0..4 + reward row 5: ONE allocation
+    why = [(np.arange(st) % 251 + r).astype(np.uint8) for r, st in enumerate(strides)]
+    out_f64, out_u8 = np.zeros(6 * n_total), np.zeros(n_total, np.uint8)
+    sends, recvs = {}, []
+
+    class FakeLib(object):
+        def ncclSend(self, ptr, count, dtype, peer, comm, stream):
+            sends.setdefault(comm.value, []).append((ptr.value, count, dtype, peer))
+            return 0
+
+        def ncclRecv(self, ptr, count, dtype, peer, comm, stream):
+            recvs.append((ptr.value, count, dtype, peer))
+            return 0
+
+    monkeypatch.setattr(rccl, "load", lambda: FakeLib())
+    hip = _FakeHip(monkeypatch, _hip)
+    assert [rccl.rank_major_contiguous(n) for n in sizes] == [True, False, True, True]
+    assert rccl.rank_major_messages(sizes, root) == 2 + 7 + 2
+    for r in range(4):
+        comm = rccl.Comm(1000 + r, r, 4, r)
+        b = rccl.RankMajorBufs(blocks[r].ctypes.data, strides[r] * 8, blocks[r][5].ctypes.data, why[r].ctypes.data, out_f64.ctypes.data, out_u8.ctypes.data)
+        assert b.contiguous(sizes[r]) == (sizes[r] == strides[r])
+        rccl.enqueue_gather_rank_major(comm, 7, root, sizes, b)
+        rccl.copy_own_rank_major(comm, 7, root, sizes, b)
+    assert [len(sends.get(1000 + r, [])) for r in range(4)] == [2, 7, 2, 0] and len(recvs) == 11
+    taken = {}
+    for ptr, count, dtype, peer in recvs:          # the k-th receive from a peer pairs with its k-th send
+        k = taken.get(peer, 0)
+        sptr, scount, sdtype, to = sends[1000 + peer][k]
+        taken[peer] = k + 1
+        assert (scount, sdtype, to) == (count, dtype, root)
+        ctypes.memmove(ptr, sptr, count * (1 if dtype == rccl.ncclUint8 else 8))
+    assert len(hip.copies) == 3
+    for dev, dst, dpitch, src, spitch, width, height, kind, stream in hip.copies:
+        assert dev == root
+        for f in range(height):
+            ctypes.memmove(dst + f * dpitch, src + f * spitch, width)
+    offs = np.cumsum([0] + sizes)
+    for r, n_r in enumerate(sizes):
+        blk = out_f64[6 * offs[r]:6 * offs[r + 1]].reshape(6, n_r)
+        assert np.array_equal(blk, blocks[r][:, :n_r])
+        assert np.array_equal(out_u8[offs[r]:offs[r + 1]], why[r][:n_r])
+    # a shard that claims to be contiguous and is not (reward elsewhere) is refused, not silently mis-sent
+    bad = rccl.RankMajorBufs(blocks[0].ctypes.data, 256 * 8, why[0].ctypes.data, why[0].ctypes.data, 0, 0)
+    with pytest.raises(rccl.RcclError):
+        rccl.enqueue_gather_rank_major(rccl.Comm(1, 0, 4, 0), 7, root, sizes, bad)
+
+
+def test_all_reduce_stats_twice_between_steps_gives_the_same_sums(monkeypatch):
+    """the batch scalars' all-reduce ran IN PLACE on the handle's own bsk_get_batch_stats_device block, which
+    the library refreshes only after the next step - a second call between two steps reduced the already-reduced values
+    (world x the sum; bench.py's clocked repeats did exactly that).  Now out of place: DirectRcclGather (one process per rank)
+    and ShardedPropagator (one process, several devices), three ranks each, every rank called twice, fake librccl / device memory."""
+    import ctypes
+
+    from basilisk_env_amd import _hip, parallel, rccl, sharded
+
+    world = 3
+    partial = [np.array([1.5 + r, 10.0 * (r + 1)]) for r in range(world)]      # each rank's {sum of rewards, done envs}
+    want = np.sum(partial, axis=0)
+    pending = []
+
+    class FakeLib(object):
+        def ncclAllReduce(self, send, recv, count, dtype, op, comm, stream):
+            assert count == 2 and dtype == rccl.ncclFloat64 and op == rccl.ncclSum
+            pending.append((send.value, recv.value))
+            if len(pending) == world:              # every rank has called: perform the collective on the "device" memory
+                tot = np.sum([np.ctypeslib.as_array((ctypes.c_double * 2).from_address(s)) for s, _ in pending], axis=0)
+                for _, r in pending:
+                    ctypes.memmove(r, tot.ctypes.data, 16)
+                del pending[:]
+            return 0
+
+        def ncclGroupStart(self):
+            return 0
+
+        def ncclGroupEnd(self):
+            return 0
+
+        def ncclCommDestroy(self, h):
+            return 0
+
+    class FakeBuf(object):
+        def __init__(self, nbytes, device):
+            self.arr = np.zeros(max(nbytes // 8, 1))
+            self.ptr, self.device = self.arr.ctypes.data, device
+
+        def free(self):
+            pass
+
+    class FakeProp(object):
+        def __init__(self, r):
+            self.r, self.device, self.n_envs = r, r, 256
+
+        def batch_stats_device(self):
+            return partial[self.r].ctypes.data
+
+        def stream_ptr(self):
+            return 100 + self.r
+
+    monkeypatch.setattr(rccl, "load", lambda: FakeLib())
+    monkeypatch.setattr(_hip, "DeviceBuffer", FakeBuf)
+    # one process per rank
+    ranks = []
+    for r in range(world):
+        d = parallel.DirectRcclGather.__new__(parallel.DirectRcclGather)
+        d.prop, d.comm, d.stream, d._stats_out, d.out = FakeProp(r), rccl.Comm(500 + r, r, world, r), 100 + r, None, None
+        ranks.append(d)
+    for _ in range(2):
+        ptrs = [d.all_reduce_stats() for d in ranks]
+        for r, p in enumerate(ptrs):
+            assert p != partial[r].ctypes.data                                # never the handle's own block
+            assert np.array_equal(np.ctypeslib.as_array((ctypes.c_double * 2).from_address(p)), want)
+        assert all(np.array_equal(partial[r], [1.5 + r, 10.0 * (r + 1)]) for r in range(world))      # the partials are untouched
+    # one process, several devices
+    sp = sharded.ShardedPropagator.__new__(sharded.ShardedPropagator)
+    sp.shards, sp.devices, sp._stats_out = [FakeProp(r) for r in range(world)], list(range(world)), None
+    sp._comms = [rccl.Comm(600 + r, r, world, r) for r in range(world)]
+    for _ in range(2):
+        for p in sp.all_reduce_stats_device():
+            assert np.array_equal(np.ctypeslib.as_array((ctypes.c_double * 2).from_address(p)), want)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copy what tools/round.sh, tools/isa_mix.sh and tools/bench_lines.sh merged back under gpurun_out/ into profiles/TAG (tracked).
 # Usage (this container, repo root): tools/collect_evidence.sh r03
-TAG=${1:-r04}
+TAG=${1:-r05}
 S=gpurun_out/$TAG; D=profiles/$TAG
 mkdir -p $D
 cp $S/kernel_trace.json $S/summary_latest.json $D/ 2>/dev/null
@@ -31,6 +31,35 @@ for line in open(log):
         print(line.strip())
 PY
 fi
+# stats_kernel per batch size (tools/exp/stats_trace.py under the kernel tracer): per-dispatch durations + a summary
+python3 - $S $D <<'PY'
+import csv, glob, json, os, sys
+s, d = sys.argv[1], sys.argv[2]
+out = {}
+for run in sorted(glob.glob(s + "/kt_stats_*")):
+    if not os.path.isdir(run):
+        continue
+    n = run.rsplit("_", 1)[1]
+    rows = []
+    for f in glob.glob(run + "/*/*_kernel_trace.csv"):
+        for r in csv.DictReader(open(f)):
+            if "stats_kernel" in r["Kernel_Name"]:
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r.get("Grid_Size_X") or r.get("Grid_Size")))
+    if not rows:
+        continue
+    rows.sort()
+    with open(os.path.join(d, "kt_stats_%s.csv" % n), "w") as g:
+        g.write("dispatch,start_offset_us,duration_ns,grid\n")
+        for k, (t, dur, grid) in enumerate(rows):
+            g.write("%d,%.3f,%d,%s\n" % (k, (t - rows[0][0]) / 1e3, dur, grid))
+    dur = sorted(r[1] for r in rows[len(rows) // 4:])          # the first quarter set aside (clock ramp)
+    cut = len(dur) // 10
+    core = dur[cut:len(dur) - cut] or dur
+    out[n] = {"dispatches": len(rows), "median_us": dur[len(dur) // 2] / 1e3, "trimmed_mean_us": sum(core) / len(core) / 1e3, "min_us": dur[0] / 1e3, "grid": rows[0][2]}
+if out:
+    json.dump(out, open(os.path.join(d, "kt_stats.json"), "w"), indent=1)
+    print("stats_kernel:", {k: round(v["trimmed_mean_us"], 2) for k, v in out.items()})
+PY
 [ -f gpurun_out/isa_$TAG/isa_mix.json ] && cp gpurun_out/isa_$TAG/isa_mix.json $D/
 [ -d gpurun_out/${TAG}_lines ] && cp gpurun_out/${TAG}_lines/bench_*.json $D/ 2>/dev/null
 python3 - $D <<'PY'

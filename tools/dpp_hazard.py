@@ -106,6 +106,8 @@ def check(funcs):
                     continue                         # no fall-through from an unconditional transfer
                 if op.startswith("v_") and ops:
                     w = regs(ops[0])
+                    if (op.startswith("v_swap_") or "permlane16_swap" in op or "permlane32_swap" in op) and len(ops) > 1:
+                        w = (w or set()) | (regs(ops[1]) or set())      # two-destination operations write both operands
                     if w and (w & src) and ws < need_v:
                         return k
                     if op.startswith("v_cmpx") and ws < need_e:

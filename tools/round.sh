@@ -2,7 +2,7 @@
 # One GPU-box pass of the round's evidence: GPU tests, bench lines, the 2-rank rehearsal of the self-launch path on
 # one card, kernel traces and counter passes.  Usage: tools/round.sh TAG   (outputs under gpurun_out/TAG/)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r04}
+TAG=${1:-r05}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
@@ -43,6 +43,10 @@ prof kt_power_k1800 --kernel-trace --stats --output-format csv -d $O/kt_power_k1
 BS="$B --gravity sh --steps 1000 --warmup 300"
 prof kt_sh --kernel-trace --stats --output-format csv -d $O/kt_sh -- $BS
 prof sq_sh --pmc $SQ --output-format csv -d $O/sq_sh -- $BS
+# the batch scalars on demand (row a7): stats_kernel's own duration at four batch sizes, a request after every step
+for ns in 65536 131072 1048576 4194304; do
+  prof kt_stats_$ns --kernel-trace --stats --output-format csv -d $O/kt_stats_$ns -- python3 $R/tools/exp/stats_trace.py $ns
+done
 cd $R
 python3 tools/prof_summary.py $O > $O/summary_latest.json 2>/dev/null && echo summary ok
 python3 tools/kernel_trace_summary.py $O $O > $O/kernel_trace.json && echo kernel_trace ok
