@@ -16,6 +16,7 @@
 #include "../../include/bskgpu.h"
 #include "bsk_aux.hpp"
 #include "bsk_launch.hpp"
+#include "bsk_rollout.hpp"
 
 namespace {
 
@@ -453,6 +454,7 @@ struct bsk_handle {
     // wave; full-scenario level only, preferred over the pair form where both apply (profiles/r03/tri_form.txt: -16 % against
     // the pair form up to one workgroup per CU, twice the time above).  BSKGPU_TRI=0 / 1 forces it off / on.
     bool tri_ok = false, last_tri = false;
+    bool last_rollout = false;    // the last launch was bsk_step_n's rollout kernel (bsk_kernel_info)
     int tri_min_substeps = 16, tri_max_envs = 16384;
 };
 
@@ -551,19 +553,13 @@ int check_device_error(bsk_handle* h) {
 }
 #define SYNC_CHECKED(h) do { HIP_SYNC(hipStreamSynchronize((h)->stream)); int rc_ = check_device_error(h); if (rc_) return rc_; } while (0)
 
-int do_step(bsk_handle* h, const void* d_actions, int substeps, int act_shift) {
-    if (h->cfg.gravity_model == BSK_GRAV_SH && !h->sp.sh_tab)
-        return fail(BSK_EINVAL, "BSK_GRAV_SH: call bsk_set_gravity_sh before stepping");
-    if ((h->cfg.flags & BSK_FLAG_AUTO_RESET) && h->n_pool == 0)
-        return fail(BSK_EINVAL, "BSK_FLAG_AUTO_RESET: call bsk_set_ic_pool before stepping");
-    bsk::StepBuffers b;
+void fill_buffers(bsk_handle* h, bsk::StepBuffers& b, const void* d_actions, int substeps, int act_shift, bool static_charge) {
     b.cold = h->d_cold;
     b.st = h->d_state;
     b.cnt = h->d_cnt;
     b.act = (const int*)d_actions;
     b.act_shift = act_shift;
-    const bool replayable = note_capture(h);      // (a captured launch must not freeze a host-side decision into the graph)
-    b.static_charge = !replayable && (h->sp.feat == bsk::FEAT_BARE || h->sp.feat == bsk::FEAT_LDSS) && h->charge_pos && (h->n_pool == 0 || h->pool_charge_pos) ? 1 : 0;
+    b.static_charge = static_charge ? 1 : 0;
     b.ep_return = h->d_ep_return; b.term_return = h->d_term_return; b.term_len = h->d_term_len; b.done = h->d_done;
     b.obs_rm = h->d_obs_rm; b.err = h->h_err; b.dbg = h->d_dbg;
     b.obs = h->d_obs;
@@ -579,32 +575,49 @@ int do_step(bsk_handle* h, const void* d_actions, int substeps, int act_shift) {
     b.n_pool = h->n_pool;
     b.n_fields = h->nf;
     b.env_base = h->env_base;
-    // Dispatch-timestamp sampling.  stride == 1: every launch is stamped.  stride > 1: launches
-    // seq % stride == 0 and 1 are stamped as a pair and only the second is counted — the first one
-    // absorbs the transition from un-stamped back-to-back launches (a lone stamped launch reads ~25 %
-    // long), the second runs under the same conditions as in an every-launch-stamped run.
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (h->prof) {
-        const int ph = h->ev_seq++ % h->ev_stride;
-        if (h->ev_stride == 1 || ph == 1) {
-            if (h->ev_used + 2 <= (int)h->ev.size()) {
-                e0 = h->ev[h->ev_used];
-                e1 = h->ev[h->ev_used + 1];
-                h->ev_used += 2;
-            }
-        } else if (ph == 0) {
-            if (!h->ev_warm[0]) {
-                HIP_TRY(hipEventCreate(&h->ev_warm[0]));
-                HIP_TRY(hipEventCreate(&h->ev_warm[1]));
-            }
-            e0 = h->ev_warm[0];
-            e1 = h->ev_warm[1];
+}
+
+// Dispatch-timestamp sampling.  stride == 1: every launch is stamped.  stride > 1: launches
+// seq % stride == 0 and 1 are stamped as a pair and only the second is counted — the first one
+// absorbs the transition from un-stamped back-to-back launches (a lone stamped launch reads ~25 %
+// long), the second runs under the same conditions as in an every-launch-stamped run.
+int stamp_events(bsk_handle* h, hipEvent_t& e0, hipEvent_t& e1) {
+    e0 = e1 = nullptr;
+    if (!h->prof) return BSK_OK;
+    const int ph = h->ev_seq++ % h->ev_stride;
+    if (h->ev_stride == 1 || ph == 1) {
+        if (h->ev_used + 2 <= (int)h->ev.size()) {
+            e0 = h->ev[h->ev_used];
+            e1 = h->ev[h->ev_used + 1];
+            h->ev_used += 2;
         }
+    } else if (ph == 0) {
+        if (!h->ev_warm[0]) {
+            HIP_TRY(hipEventCreate(&h->ev_warm[0]));
+            HIP_TRY(hipEventCreate(&h->ev_warm[1]));
+        }
+        e0 = h->ev_warm[0];
+        e1 = h->ev_warm[1];
     }
+    return BSK_OK;
+}
+
+int do_step(bsk_handle* h, const void* d_actions, int substeps, int act_shift) {
+    if (h->cfg.gravity_model == BSK_GRAV_SH && !h->sp.sh_tab)
+        return fail(BSK_EINVAL, "BSK_GRAV_SH: call bsk_set_gravity_sh before stepping");
+    if ((h->cfg.flags & BSK_FLAG_AUTO_RESET) && h->n_pool == 0)
+        return fail(BSK_EINVAL, "BSK_FLAG_AUTO_RESET: call bsk_set_ic_pool before stepping");
+    bsk::StepBuffers b;
+    const bool replayable = note_capture(h);      // (a captured launch must not freeze a host-side decision into the graph)
+    fill_buffers(h, b, d_actions, substeps, act_shift,
+                 !replayable && (h->sp.feat == bsk::FEAT_BARE || h->sp.feat == bsk::FEAT_LDSS) && h->charge_pos && (h->n_pool == 0 || h->pool_charge_pos));
+    hipEvent_t e0, e1;
+    { int rc = stamp_events(h, e0, e1); if (rc) return rc; }
     h->sp.tri = (h->tri_ok && substeps >= h->tri_min_substeps && h->n <= h->tri_max_envs) ? 1 : 0;
     h->sp.pair = (!h->sp.tri && h->pair_ok && substeps >= h->pair_min_substeps && h->n <= h->pair_max_envs) ? 1 : 0;
     h->last_pair = h->sp.pair != 0;
     h->last_tri = h->sp.tri != 0;
+    h->last_rollout = false;
     HIP_TRY(bsk::launch_step(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp.feat, h->sp, b, h->block, h->stream, e0, e1));
     h->stats_fresh = false;
     h->stepped = true;
@@ -934,6 +947,32 @@ int bsk_step_device_i64(bsk_handle* h, const int64_t* d_actions, int substeps) {
     return do_step(h, d_actions, substeps, 0);       // the kernel reads the low word of every little-endian int64
 }
 
+int bsk_step_n(bsk_handle* h, const int32_t* d_actions, int32_t constant_action, int substeps, int n_steps,
+               double* d_obs_hist, double* d_reward_hist, uint8_t* d_reason_hist) {
+    if (!h) return fail(BSK_EINVAL, "handle is NULL");
+    if (substeps < 1 || n_steps < 1) return fail(BSK_EINVAL, "substeps and n_steps must be >= 1");
+    if (!d_actions && (constant_action < 0 || constant_action > 2)) return fail(BSK_EINVAL, "constant_action must be 0, 1 or 2");
+    if (!bsk::rollout_available(h->cfg.gravity_model, h->sp.feat))
+        return fail(BSK_EINVAL, "bsk_step_n is built for the bare propagator (point mass / J2 without BSK_FLAG_POWER / BSK_FLAG_LDS_SCRATCH)");
+    if ((h->cfg.flags & BSK_FLAG_AUTO_RESET) && h->n_pool == 0)
+        return fail(BSK_EINVAL, "BSK_FLAG_AUTO_RESET: call bsk_set_ic_pool before stepping");
+    DeviceGuard guard(h->device);
+    bsk::StepBuffers b;
+    (void)note_capture(h);
+    fill_buffers(h, b, nullptr, substeps, 1, false);
+    bsk::RolloutBuffers r;
+    r.actions = d_actions; r.obs_hist = d_obs_hist; r.reward_hist = d_reward_hist; r.reason_hist = d_reason_hist;
+    r.n_steps = n_steps; r.const_action = constant_action;
+    hipEvent_t e0, e1;
+    { int rc = stamp_events(h, e0, e1); if (rc) return rc; }
+    h->last_pair = h->last_tri = false;
+    h->last_rollout = true;
+    HIP_TRY(bsk::launch_rollout(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp, b, r, h->block, h->stream, e0, e1));
+    h->stats_fresh = false;
+    h->stepped = true;
+    return BSK_OK;
+}
+
 int bsk_get_obs(bsk_handle* h, double* obs, double* reward, uint8_t* done, uint8_t* done_reason) {
     if (!h) return fail(BSK_EINVAL, "handle is NULL");
     DeviceGuard guard(h->device);
@@ -1251,11 +1290,14 @@ int bsk_kernel_info(bsk_handle* h, char* name, int name_cap, int* vgprs, int* ld
     DeviceGuard guard(h->device);
     const bool sh = h->cfg.gravity_model == BSK_GRAV_SH;
     // (the kernel of the LAST launch: the pair form is chosen per launch by its number of sub-steps)
-    const void* fp = bsk::step_kernel_ptr(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp.feat, h->sp.sh_form, h->last_pair, h->last_tri);
+    const void* fp = h->last_rollout ? bsk::rollout_kernel_ptr(h->cfg.gravity_model, h->cfg.n_rw, h->diag)
+                                     : bsk::step_kernel_ptr(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp.feat, h->sp.sh_form, h->last_pair, h->last_tri);
     if (!fp) return fail(BSK_EINVAL, "no kernel variant for this config");
     hipFuncAttributes at;
     HIP_TRY(hipFuncGetAttributes(&at, fp));
-    if (name && name_cap > 0)
+    if (name && name_cap > 0 && h->last_rollout)
+        std::snprintf(name, name_cap, "rollout_kernel<%s,%d,%s>", h->cfg.gravity_model == BSK_GRAV_PM ? "PM" : "PM_J2", h->cfg.n_rw, h->diag ? "diag" : "full");
+    else if (name && name_cap > 0)
         std::snprintf(name, name_cap, "step_kernel<%s,%d,%s>",
                       h->cfg.gravity_model == BSK_GRAV_PM ? "PM" : (h->cfg.gravity_model == BSK_GRAV_PM_J2 ? "PM_J2" : (h->sp.sh_form == 5 ? "SH/dpp2" : (h->sp.sh_form == 4 ? "SH/dpp" : "SH/scalar"))), h->cfg.n_rw,
                       h->sp.feat >= 2 ? (h->sp.feat == 3 ? (h->diag ? "diag,scenario/generic-facets" : "full,scenario/generic-facets")

@@ -119,6 +119,34 @@ struct StepBuffers {
     unsigned long long* dbg;
 };
 
+// the loop's constants as the kernels take them (by value in the kernarg segment)
+template <int GRAV, int NRW, bool DIAG>
+inline void fill_hot(const StepParams& p, HotCfg<NRW, DIAG>& h) {
+    h.h = p.dt; h.h2 = 0.5 * p.dt; h.h3 = p.dt / 3.0; h.h6 = p.dt / 6.0;
+    h.nmu = -p.mu; h.j2k = p.j2k;
+    for (int i = 0; i < (DIAG ? 3 : 9); ++i) {
+        h.Dm[i] = DIAG ? p.dmat[4 * i] : p.dmat[i];
+        h.Di[i] = DIAG ? p.dinv[4 * i] : p.dinv[i];
+        h.W[i] = DIAG ? p.wmat[4 * i] : p.wmat[i];
+    }
+    for (int i = 0; i < NRW; ++i) {
+        for (int k = 0; k < 3; ++k) h.g[i][k] = p.gs[i][k];
+        h.js[i] = p.js[i];
+        h.ijs[i] = 1.0 / p.js[i];
+    }
+    h.fc = p.f_coulomb;
+    h.fsw_every = p.fsw_every;
+    h.sh_degree = p.sh_degree;
+    h.sh_split = p.sh_split;
+    h.sh_bodies = p.sh_bodies; h.sh_bodies0 = p.sh_bodies0; h.sh_bodies1 = p.sh_bodies1; h.sh_chunk1 = p.sh_chunk1;
+    h.pad_ = 0;
+    h.sh_tab = p.sh_tab;
+    h.mu_over_req = p.mu / p.req;
+    h.req = p.req;
+    h.inv_req = 1.0 / p.req;
+    h.planet_rate = p.planet_rate;
+}
+
 hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams& p, const StepBuffers& b, int block,
                        hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat, int sh_form, bool pair, bool tri = false);

@@ -171,6 +171,43 @@ class BatchedPropagator(object):
         fn = self._lib.bsk_step_device_i64 if int64 else self._lib.bsk_step_device
         check(fn(self._handle(), C.c_void_p(int(d_actions_ptr)), int(substeps)))
 
+    def step_n(self, n_steps, substeps, d_actions_ptr=None, constant_action=0, d_obs_hist=None, d_reward_hist=None, d_reason_hist=None):
+        """Open-loop rollout: ``n_steps`` env steps in ONE launch (``bsk_step_n``; what the reference's mains do with a constant
+        action, envs/leoPowerAttitudeEnvironment.py:218-231).  ``d_actions_ptr``: device pointer of int32[n_steps][n_envs], or None
+        for ``constant_action``; the history arguments are device pointers (or None) of f64[n_steps][5][n_envs],
+        f64[n_steps][n_envs], u8[n_steps][n_envs].  Asynchronous; the handle's buffers end as after ``n_steps`` single steps."""
+        vp = lambda p: C.c_void_p(int(p)) if p else None      # noqa: E731
+        check(self._lib.bsk_step_n(self._handle(), vp(d_actions_ptr), int(constant_action), int(substeps), int(n_steps),
+                                   vp(d_obs_hist), vp(d_reward_hist), vp(d_reason_hist)))
+
+    def rollout(self, n_steps, substeps, actions=None, constant_action=0):
+        """``step_n`` with host arrays: ``actions`` int32 (n_steps, n_envs) or None -> (obs (n_steps, 5, n_envs), reward
+        (n_steps, n_envs), reason (n_steps, n_envs) uint8) as numpy arrays.  Allocates device scratch per call and synchronises:
+        the convenience form (tests, scripted evaluations); a training process hands ``step_n`` its own device buffers."""
+        from ... import _hip
+        n, T = self.n_envs, int(n_steps)
+        rt = _hip.runtime()
+        bufs = [_hip.DeviceBuffer(T * 5 * n * 8, self.device), _hip.DeviceBuffer(T * n * 8, self.device), _hip.DeviceBuffer(T * n, self.device)]
+        act = None
+        stream = C.c_void_p(self.stream_ptr())
+        try:
+            if actions is not None:
+                a = np.ascontiguousarray(actions, dtype=np.int32)
+                if a.shape != (T, n):
+                    raise ValueError("actions must have shape (%d, %d)" % (T, n))
+                act = _hip.DeviceBuffer(T * n * 4, self.device)
+                _hip.check(rt.hipMemcpyAsync(C.c_void_p(act.ptr), C.c_void_p(a.ctypes.data), T * n * 4, _hip.hipMemcpyHostToDevice, stream), "hipMemcpyAsync")
+                self.sync()                      # (pageable source: the copy must have left `a` before it goes out of scope)
+            self.step_n(T, substeps, act.ptr if act else None, constant_action, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr)
+            obs, rew, why = np.empty((T, 5, n)), np.empty((T, n)), np.empty((T, n), dtype=np.uint8)
+            for dst, b in ((obs, bufs[0]), (rew, bufs[1]), (why, bufs[2])):
+                _hip.check(rt.hipMemcpyAsync(C.c_void_p(dst.ctypes.data), C.c_void_p(b.ptr), dst.nbytes, _hip.hipMemcpyDeviceToHost, stream), "hipMemcpyAsync")
+            self.sync()
+        finally:
+            for b in bufs + ([act] if act else []):
+                b.free()
+        return obs, rew, why
+
     pinned_read_back = True     # get_obs(copy=False) exists
 
     def get_obs(self, copy=True):

@@ -609,6 +609,37 @@ def batch_stats_point(torch, cfg, n, n_rw, local, sample_ic_batch, BatchedPropag
             "stats_grid": max(1, min((((n + 63) // 64) + 3) // 4, 2048))}
 
 
+def rollout_point(torch, cfg, n, n_rw, local, sample_ic_batch, BatchedPropagator, T=541, reps=5):
+    """Open-loop rollouts (bsk_step_n): T env steps of ONE RK4 sub-step in one launch, state in registers across them - the
+    reference's own mains step whole episodes under one action (envs/leoPowerAttitudeEnvironment.py:218-231).  A point of its own,
+    never `value`: per env step the launch reads 4 B (0 with a constant action) and writes 49 B (five observations, reward, done
+    reason); the state slab moves once per launch.  What bounds it is fp64 issue (one wave per SIMD at 65 536 spacecraft)."""
+    p = BatchedPropagator(cfg, n, device=local)
+    p.reset(sample_ic_batch(n, n_rw, seed=6))
+    act = torch.zeros((T, n), dtype=torch.int32, device="cuda")
+    ob = torch.empty((T, 5, n), dtype=torch.float64, device="cuda")
+    rw = torch.empty((T, n), dtype=torch.float64, device="cuda")
+    wy = torch.empty((T, n), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    out = {"envs": n, "steps_per_launch": T, "substeps": 1}
+    for key, a in (("constant_action", None), ("device_actions", act.data_ptr())):
+        p.step_n(T, 1, a, 0, ob.data_ptr(), rw.data_ptr(), wy.data_ptr())
+        p.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            p.step_n(T, 1, a, 0, ob.data_ptr(), rw.data_ptr(), wy.data_ptr())
+        p.sync()
+        dt = (time.perf_counter() - t0) / reps
+        bytes_step = 49 + (4 if a else 0)
+        out[key] = {"env_steps_per_s": n * T / dt, "us_per_env_step": dt / T * 1e6, "ms_per_launch": dt * 1e3,
+                    "algorithmic_bytes_per_env_step": bytes_step + 2 * 128.0 / T,
+                    "history_GBps": bytes_step * n * T / dt / 1e9}
+    assert bool(torch.isfinite(ob).all()) and bool(torch.isfinite(rw).all())
+    out["kernel"] = p.kernel_info()
+    p.close()
+    return out
+
+
 def vecenv_episode_end(n, device_pool):
     """Host time of LeoPowerAttVecEnv.step_wait at the step where EVERY episode of the batch ends (max_length = 2, so every third
     step; with the reference's max_length = 540 and a common reset() it is every 541st) beside an ordinary step: the surface
@@ -958,6 +989,14 @@ def main():
                                        for nn, st_ in ((65536, 3000), (131072, 2000), (1 << 20, 400), (1 << 22, 120))}
         except Exception as e:
             extra["batch_stats_us"] = {"error": repr(e)}
+        # open-loop rollouts: a whole 541-step episode per launch (bsk_step_n), 65 536 and 4 Mi spacecraft
+        try:
+            extra["rollout"] = {str(nn): rollout_point(torch, cfg, nn, n_rw, local, sample_ic_batch, BatchedPropagator, T=tt, reps=rr)
+                                for nn, tt, rr in ((65536, 541, 5), (1 << 22, 100, 2))}
+            r1 = extra["rollout"]["65536"]["constant_action"]
+            r1["over_one_launch_per_step"] = r1["env_steps_per_s"] / value
+        except Exception as e:
+            extra["rollout"] = {"error": repr(e)}
         # the VecEnv's host path at a synchronized episode end (every env of the batch finishes on the same step)
         try:
             extra["vecenv_episode_end_ms"] = {"device_pool": vecenv_episode_end(n, 4096), "host_resets": vecenv_episode_end(n, 0)}

@@ -1,0 +1,195 @@
+"""GPU: open-loop rollouts (bsk_step_n: T env steps in one launch, state in registers across them) against T single launches.
+
+The contract (include/bskgpu.h): row t of the history is what bsk_get_obs returns after step t of T calls of bsk_step_device, and
+afterwards every buffer of the handle holds, BIT FOR BIT, what those T calls leave - state slab, counters, observation / reward /
+reason / done mask, terminal observations, episode counts and statistics.  The single launches are themselves held to the CPU
+oracle (tests/test_gpu_parity.py, test_gpu_fuzz.py), so bit-identity here carries that parity over; one case checks the rollout
+against the oracle directly.  Reference: the mains that step whole episodes under one action,
+envs/leoPowerAttitudeEnvironment.py:218-231, simulators/leoPowerAttitudeSimulator.py:657-694."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from basilisk_env_amd import _hip
+from basilisk_env_amd._lib import (FLAG_AUTO_RESET, FLAG_EPISODE_STATS, FLAG_OBS_ROWMAJOR, FLAG_POWER, GRAV_PM, GRAV_PM_J2, GRAV_SH, BskError)
+from basilisk_env_amd.simulators.dynamics import BatchedPropagator, default_config
+from basilisk_env_amd.simulators.initial_conditions.batch import sample_ic_batch
+from helpers import general_hub, max_group_err
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev_array(view, dtype, count):
+    """host copy of a device view's first `count` elements (contiguous views only)"""
+    out = np.empty(count, dtype=dtype)
+    ptr = view.__cuda_array_interface__["data"][0]
+    _hip.check(_hip.runtime().hipMemcpyAsync(ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(ptr), out.nbytes, _hip.hipMemcpyDeviceToHost, ctypes.c_void_p(0)), "hipMemcpyAsync")
+    _hip.stream_sync(0)
+    return out
+
+
+def _everything(p, pool):
+    """every buffer of the handle a step writes, as host arrays"""
+    p.sync()
+    out = {"state": p.get_state(), "steps": p.get_counters()[0], "ticks": p.get_counters()[1]}
+    out["obs"], out["rew"], _, out["why"] = p.get_obs()
+    out["stats"] = np.array(p.batch_stats(), dtype=np.float64)
+    v = p.device_views()
+    out["done_mask"] = _dev_array(v["done_mask"], np.uint64, (p.n_envs + 63) // 64)
+    if pool:
+        out["term_obs"], out["episodes"] = p.get_terminal_obs()
+    if "episode_return" in v:
+        out["ep_return"] = _dev_array(v["episode_return"], np.float64, p.n_envs)
+        out["term_return"] = _dev_array(v["terminal_return"], np.float64, p.n_envs)
+        out["term_len"] = _dev_array(v["terminal_length"], np.int32, p.n_envs)
+        out["done"] = _dev_array(v["done"], np.uint8, p.n_envs)
+    if "obs_rowmajor" in v:
+        out["obs_rm"] = _dev_array(v["obs_rowmajor"], np.float64, p.n_envs * 5)
+    return out
+
+
+def _pair(cfg, n, seed, pool=0):
+    ic = sample_ic_batch(n, cfg.n_rw, seed=seed)
+    if cfg.n_rw:
+        ic[12:12 + cfg.n_rw] *= 2.5                    # some wheels beyond their limit during the run: wheel terminations too
+    props = []
+    for _ in range(2):
+        p = BatchedPropagator(cfg, n)
+        if pool:
+            p.set_ic_pool(sample_ic_batch(pool, cfg.n_rw, seed=seed + 1))
+        p.reset(ic)
+        props.append(p)
+    return props
+
+
+def _compare(single, rolled, T, k, actions, const=None, pool=0, tag=None):
+    """T launches on `single`, one rollout on `rolled`; histories and every buffer bit for bit"""
+    n = single.n_envs
+    h_obs, h_rew, h_why = np.empty((T, 5, n)), np.empty((T, n)), np.empty((T, n), np.uint8)
+    for t in range(T):
+        single.step(actions[t] if const is None else np.full(n, const, np.int32), k)
+        h_obs[t], h_rew[t], _, h_why[t] = single.get_obs()
+    r_obs, r_rew, r_why = rolled.rollout(T, k, actions=None if const is not None else actions, constant_action=const or 0)
+    assert np.array_equal(r_why, h_why), tag
+    assert np.array_equal(r_rew, h_rew), (tag, np.abs(r_rew - h_rew).max())
+    assert np.array_equal(r_obs, h_obs), (tag, np.abs(r_obs - h_obs).max(axis=(1, 2)))
+    a, b = _everything(single, pool), _everything(rolled, pool)
+    assert a.keys() == b.keys()
+    for key in a:
+        assert np.array_equal(a[key], b[key]), (tag, key)
+    assert rolled.kernel_info()["name"].startswith("rollout_kernel<") and single.kernel_info()["name"].startswith("step_kernel<")
+    return h_obs, h_rew, h_why
+
+
+@pytest.mark.parametrize("n", [1, 63, 65, 200, 1000])
+@pytest.mark.parametrize("grav,n_rw", [(GRAV_PM, 0), (GRAV_PM_J2, 3), (GRAV_PM_J2, 4), (GRAV_PM, 4)])
+def test_rollout_equals_single_steps(grav, n_rw, n):
+    cfg = default_config(n_rw, grav)
+    cfg.max_length = 5                                  # episodes end (by length) inside the rollout; no pool: they stay "done"
+    single, rolled = _pair(cfg, n, seed=300 + n)
+    rng = np.random.default_rng(n + 7 * n_rw)
+    T, k = 9, int(rng.choice([1, 3, 10, 12]))
+    actions = rng.integers(0, 3, (T, n)).astype(np.int32)
+    h_obs, h_rew, h_why = _compare(single, rolled, T, k, actions, tag=(grav, n_rw, n, k))
+    assert (h_why != 0).any() and (h_why == 0).any()
+    single.close(); rolled.close()
+
+
+@pytest.mark.parametrize("flags", [FLAG_AUTO_RESET, FLAG_AUTO_RESET | FLAG_EPISODE_STATS | FLAG_OBS_ROWMAJOR])
+@pytest.mark.parametrize("lags", [(1, 1), (0, 1), (0, 0)])
+@pytest.mark.parametrize("fsw_every", [1, 3, 10])
+def test_rollout_with_device_side_restarts(flags, lags, fsw_every):
+    """Episodes end - by length and by wheel speed - and restart from the staged pool INSIDE the launch: the restarted env's
+    registers, the slab's untracked fields, terminal observations, episode counts and (with the flags) the Monitor statistics
+    all follow the single-step kernel; FSW phases of one wave's lanes part ways after the first restart."""
+    n, T, k = 300, 14, 7
+    cfg = default_config(4, GRAV_PM_J2)
+    cfg.flags |= flags
+    cfg.max_length = 3
+    cfg.fsw_every = fsw_every
+    cfg.fsw_lag, cfg.nav_lag = lags
+    single, rolled = _pair(cfg, n, seed=41 + fsw_every, pool=37)
+    rng = np.random.default_rng(fsw_every)
+    actions = rng.integers(0, 3, (T, n)).astype(np.int32)
+    h_obs, h_rew, h_why = _compare(single, rolled, T, k, actions, pool=37, tag=(hex(flags), lags, fsw_every))
+    _, eps = rolled.get_terminal_obs()
+    assert eps.min() >= 2 and (h_why & 2).any() and (h_why & 1).any()       # several restarts per env; wheel and length terminations
+    # the rollout can be cut anywhere: two launches of 5 + 9 steps leave what one of 14 leaves
+    a, b = _pair(cfg, n, seed=41 + fsw_every, pool=37)
+    o1 = a.rollout(5, k, actions=actions[:5])
+    o2 = a.rollout(9, k, actions=actions[5:])
+    o = b.rollout(T, k, actions=actions)
+    for x, y, z in zip(o1, o2, o):
+        assert np.array_equal(np.concatenate([x, y]), z)
+    ea, eb = _everything(a, 37), _everything(b, 37)
+    assert all(np.array_equal(ea[key], eb[key]) for key in ea)
+    for p in (single, rolled, a, b):
+        p.close()
+
+
+def test_rollout_general_hub_and_constant_action_against_the_oracle():
+    """A hub with products of inertia and a tilted wheel axis (the DIAG = false kernels), the reference mains' pattern - ONE action
+    for the whole episode - and the CPU oracle as the checker of the history itself."""
+    n, n_rw, T, k = 130, 4, 12, 10
+    cfg = general_hub(default_config(n_rw, GRAV_PM_J2), np.random.default_rng(4))
+    cfg.max_length = 100
+    single, rolled = _pair(cfg, n, seed=9)
+    h_obs, h_rew, h_why = _compare(single, rolled, T, k, None, const=0, tag="general hub")
+    assert "full" in rolled.kernel_info()["name"] and "diag" not in rolled.kernel_info()["name"]
+    st = sample_ic_batch(n, n_rw, seed=9)
+    st[12:12 + n_rw] *= 2.5
+    steps, ticks = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    for t in range(T):
+        o = oracle.step(cfg, st, steps, ticks, np.zeros(n, np.int32), k)
+        assert np.abs(h_obs[t] - o[0]).max() < 1e-11 and np.abs(h_rew[t] - o[1]).max() < 1e-12 and np.array_equal(h_why[t], o[3]), t
+    assert max(max_group_err(rolled.get_state(), st, n_rw).values()) < 1e-11
+    single.close(); rolled.close()
+
+
+def test_whole_episode_in_one_launch_at_full_size():
+    """65 536 spacecraft, a 541-step episode of the reference's length (max_length = 540) under action 0 in ONE launch of the
+    rollout kernel (K = 1 per step): every env finishes exactly at the last step, by length, and the summed rewards are the
+    episode returns the device-side statistics report."""
+    n = 65536
+    cfg = default_config(4, GRAV_PM_J2)
+    cfg.flags |= FLAG_AUTO_RESET | FLAG_EPISODE_STATS
+    p = BatchedPropagator(cfg, n)
+    p.sample_ic_pool(4096, 11)
+    p.reset_from_pool()
+    d_rew = _hip.DeviceBuffer(541 * n * 8, 0)
+    d_why = _hip.DeviceBuffer(541 * n, 0)
+    p.step_n(541, 1, None, 0, None, d_rew.ptr, d_why.ptr)
+    p.sync()
+    rew, why = np.empty((541, n)), np.empty((541, n), np.uint8)
+    for dst, b in ((rew, d_rew), (why, d_why)):
+        _hip.check(_hip.runtime().hipMemcpyAsync(ctypes.c_void_p(dst.ctypes.data), ctypes.c_void_p(b.ptr), dst.nbytes, _hip.hipMemcpyDeviceToHost, ctypes.c_void_p(0)), "hipMemcpyAsync")
+    _hip.stream_sync(0)
+    assert not why[:540].any() and (why[540] == 1).all()
+    v = p.device_views()
+    term_r = _dev_array(v["terminal_return"], np.float64, n)
+    term_l = _dev_array(v["terminal_length"], np.int32, n)
+    assert (term_l == 540).all()
+    ret = np.zeros(n)
+    for t in range(541):                                  # the kernel's own accumulation order
+        ret += rew[t]
+    assert np.array_equal(ret, term_r) and 0.0 < ret.min() and ret.max() <= 541.0 / 540.0 + 1e-12
+    _, eps = p.get_terminal_obs()
+    assert (eps == 2).all()                                # reset_from_pool + the restart at the episode's end
+    for b in (d_rew, d_why):
+        b.free()
+    p.close()
+
+
+def test_rollout_is_refused_where_it_is_not_built():
+    cfg = default_config(4, GRAV_PM_J2)
+    cfg.flags |= FLAG_POWER
+    p = BatchedPropagator(cfg, 64)
+    p.reset(sample_ic_batch(64, 4, seed=1))
+    with pytest.raises(BskError) as e:
+        p.step_n(3, 1)
+    assert e.value.code == -1 and "bare propagator" in str(e.value)
+    with pytest.raises(BskError):
+        BatchedPropagator(default_config(4, GRAV_PM_J2), 64).step_n(0, 1)
+    p.close()
