@@ -1067,34 +1067,46 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     return hipGetLastError();
 }
 
-#define BSK_VARIANTS_P(X, P)                                                                                \
-    X(BSK_GRAV_SH, 0, true, P) X(BSK_GRAV_SH, 3, true, P) X(BSK_GRAV_SH, 4, true, P)                         \
-    X(BSK_GRAV_SH, 0, false, P) X(BSK_GRAV_SH, 3, false, P) X(BSK_GRAV_SH, 4, false, P)                      \
-    X(BSK_GRAV_PM, 0, true, P) X(BSK_GRAV_PM, 3, true, P) X(BSK_GRAV_PM, 4, true, P)                         \
-    X(BSK_GRAV_PM_J2, 0, true, P) X(BSK_GRAV_PM_J2, 3, true, P) X(BSK_GRAV_PM_J2, 4, true, P)                \
-    X(BSK_GRAV_PM, 0, false, P) X(BSK_GRAV_PM, 3, false, P) X(BSK_GRAV_PM, 4, false, P)                      \
-    X(BSK_GRAV_PM_J2, 0, false, P) X(BSK_GRAV_PM_J2, 3, false, P) X(BSK_GRAV_PM_J2, 4, false, P)
-#ifdef BSK_FAST_BUILD   // ISA inspection / A-B builds: only the J2 + 4-wheel (bench) and J2 + 3-wheel (env) kernels
-#undef BSK_VARIANTS_P
-#if BSK_FAST_BUILD == 2  // ... or only the harmonics kernel of the config-5 bench
-#define BSK_VARIANTS_P(X, P) X(BSK_GRAV_SH, 4, true, P)
+// ---- which instantiations this translation unit holds ----------------------------------------------------------------------
+// A cell = one (gravity model, hub kind, feature level) with its three wheel sets (and every form of it: harmonics forms 4 / 5,
+// pair / three-wave forms).  The library is built from EIGHT compilations of this file (-DBSK_TU=0..7, make -j: about one minute
+// instead of six), each holding the cells below - balanced by measured compile time, the harmonics' scenario levels being the
+// expensive ones (~45 s a cell against 2 - 15 s) - and bsk_dispatch.hip trying them in turn.  Without BSK_TU the file holds
+// everything it is asked for in ONE unit: the fast builds of the variant / probe libraries and of tests/test_dpp_build.py.
+#define BSK_CELL(X, G, D, P) X(G, 0, D, P) X(G, 3, D, P) X(G, 4, D, P)
+#define BSK_UNIT0(X) BSK_CELL(X, BSK_GRAV_SH, true, 3)
+#define BSK_UNIT1(X) BSK_CELL(X, BSK_GRAV_SH, true, 2)
+#define BSK_UNIT2(X) BSK_CELL(X, BSK_GRAV_SH, false, 3)
+#define BSK_UNIT3(X) BSK_CELL(X, BSK_GRAV_SH, false, 2)
+#define BSK_UNIT4(X) BSK_CELL(X, BSK_GRAV_SH, true, 0) BSK_CELL(X, BSK_GRAV_SH, true, 1) BSK_CELL(X, BSK_GRAV_SH, false, 0)
+#define BSK_UNIT5(X) BSK_CELL(X, BSK_GRAV_SH, false, 1) BSK_CELL(X, BSK_GRAV_PM, true, 2) BSK_CELL(X, BSK_GRAV_PM_J2, true, 2)
+#define BSK_UNIT6(X) BSK_CELL(X, BSK_GRAV_PM_J2, true, 0) BSK_CELL(X, BSK_GRAV_PM_J2, true, 1) BSK_CELL(X, BSK_GRAV_PM_J2, true, 3)   \
+                   BSK_CELL(X, BSK_GRAV_PM_J2, false, 0) BSK_CELL(X, BSK_GRAV_PM_J2, false, 1) BSK_CELL(X, BSK_GRAV_PM_J2, false, 2) \
+                   BSK_CELL(X, BSK_GRAV_PM_J2, false, 3) BSK_CELL(X, BSK_GRAV_PM_J2, true, -1) BSK_CELL(X, BSK_GRAV_PM_J2, false, -1)
+#define BSK_UNIT7(X) BSK_CELL(X, BSK_GRAV_PM, true, 0) BSK_CELL(X, BSK_GRAV_PM, true, 1) BSK_CELL(X, BSK_GRAV_PM, true, 3)            \
+                   BSK_CELL(X, BSK_GRAV_PM, false, 0) BSK_CELL(X, BSK_GRAV_PM, false, 1) BSK_CELL(X, BSK_GRAV_PM, false, 2)          \
+                   BSK_CELL(X, BSK_GRAV_PM, false, 3) BSK_CELL(X, BSK_GRAV_PM, true, -1) BSK_CELL(X, BSK_GRAV_PM, false, -1)
+#if defined(BSK_TU)
+#define BSK_TU_CAT2(a, b) a##b
+#define BSK_TU_CAT(a, b) BSK_TU_CAT2(a, b)
+#define BSK_VARIANTS(X) BSK_TU_CAT(BSK_UNIT, BSK_TU)(X)
+#define BSK_LAUNCH_UNIT BSK_TU_CAT(launch_step_tu, BSK_TU)
+#define BSK_PTR_UNIT BSK_TU_CAT(step_kernel_ptr_tu, BSK_TU)
 #else
-#define BSK_VARIANTS_P(X, P) X(BSK_GRAV_PM_J2, 4, true, P) X(BSK_GRAV_PM_J2, 3, true, P)
-#endif
-#endif
-#ifdef BSK_FAST_BUILD
-#define BSK_VARIANTS_L(X) X(BSK_GRAV_PM_J2, 4, true, -1) X(BSK_GRAV_PM_J2, 3, true, -1)
-#else
-#define BSK_VARIANTS_L(X)                                                                                   \
-    X(BSK_GRAV_PM, 0, true, -1) X(BSK_GRAV_PM, 3, true, -1) X(BSK_GRAV_PM, 4, true, -1)                      \
-    X(BSK_GRAV_PM_J2, 0, true, -1) X(BSK_GRAV_PM_J2, 3, true, -1) X(BSK_GRAV_PM_J2, 4, true, -1)             \
-    X(BSK_GRAV_PM, 0, false, -1) X(BSK_GRAV_PM, 3, false, -1) X(BSK_GRAV_PM, 4, false, -1)                   \
-    X(BSK_GRAV_PM_J2, 0, false, -1) X(BSK_GRAV_PM_J2, 3, false, -1) X(BSK_GRAV_PM_J2, 4, false, -1)
-#endif
-#if defined(BSK_FAST_BUILD) && BSK_FAST_BUILD == 3   // ... or only the kernel the drop-in env runs, in its three forms (tests/test_dpp_build.py)
+#define BSK_LAUNCH_UNIT launch_step_unit
+#define BSK_PTR_UNIT step_kernel_ptr_unit
+#if defined(BSK_ONLY)                                // whatever the command line lists: -D'BSK_ONLY(X)=X(BSK_GRAV_SH,4,true,2)'
+#define BSK_VARIANTS(X) BSK_ONLY(X)
+#elif defined(BSK_FAST_BUILD) && BSK_FAST_BUILD == 3 // only the kernel the drop-in env runs, in its three forms (tests/test_dpp_build.py)
 #define BSK_VARIANTS(X) X(BSK_GRAV_PM_J2, 3, true, 2)
-#else
-#define BSK_VARIANTS(X) BSK_VARIANTS_P(X, 0) BSK_VARIANTS_P(X, 1) BSK_VARIANTS_P(X, 2) BSK_VARIANTS_P(X, 3) BSK_VARIANTS_L(X)
+#elif defined(BSK_FAST_BUILD) && BSK_FAST_BUILD == 2 // only the harmonics kernels of the config-5 bench
+#define BSK_VARIANTS(X) X(BSK_GRAV_SH, 4, true, 0) X(BSK_GRAV_SH, 4, true, 1) X(BSK_GRAV_SH, 4, true, 2) X(BSK_GRAV_SH, 4, true, 3)
+#elif defined(BSK_FAST_BUILD)                        // ISA inspection / A-B builds: the J2 + 4-wheel (bench) and J2 + 3-wheel (env) kernels
+#define BSK_FAST_LEVELS(X, R) X(BSK_GRAV_PM_J2, R, true, 0) X(BSK_GRAV_PM_J2, R, true, 1) X(BSK_GRAV_PM_J2, R, true, 2) X(BSK_GRAV_PM_J2, R, true, 3) X(BSK_GRAV_PM_J2, R, true, -1)
+#define BSK_VARIANTS(X) BSK_FAST_LEVELS(X, 4) BSK_FAST_LEVELS(X, 3)
+#else                                                // everything in one unit
+#define BSK_VARIANTS(X) BSK_UNIT0(X) BSK_UNIT1(X) BSK_UNIT2(X) BSK_UNIT3(X) BSK_UNIT4(X) BSK_UNIT5(X) BSK_UNIT6(X) BSK_UNIT7(X)
+#endif
 #endif
 
 // pair form (SPLIT == 2): built for the power / full-scenario levels of the point-mass and J2 kernels with a diagonal hub
@@ -1108,9 +1120,6 @@ static const void* pair_ptr() {
     if constexpr (D && G != BSK_GRAV_SH && (P == FEAT_POWER || P == FEAT_FULL)) return (const void*)&step_kernel<G, R, D, P, 2>;
     else return nullptr;
 }
-bool pair_available(int grav, bool diag, int feat) {
-    return diag && grav != BSK_GRAV_SH && (feat == FEAT_POWER || feat == FEAT_FULL);
-}
 // three-wave form (SPLIT == 3): the full-scenario level of the same kernels
 template <int G, int R, bool D, int P>
 static hipError_t launch_tri(const StepParams& p, const StepBuffers& b, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
@@ -1122,10 +1131,11 @@ static const void* tri_ptr() {
     if constexpr (D && G != BSK_GRAV_SH && P == FEAT_FULL) return (const void*)&step_kernel<G, R, D, P, 3>;
     else return nullptr;
 }
-bool tri_available(int grav, bool diag, int feat) { return diag && grav != BSK_GRAV_SH && feat == FEAT_FULL; }
 
-hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams& p, const StepBuffers& b, int block,
-                       hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+// this unit's share of the dispatch: *handled says whether the configuration is one of its instantiations
+hipError_t BSK_LAUNCH_UNIT(int grav, int nrw, bool diag, int feat, const StepParams& p, const StepBuffers& b, int block,
+                           hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, bool* handled) {
+    *handled = true;
 #define CASE(G, R, D, P) \
     if (grav == G && nrw == R && diag == D && feat == P) {                                                 \
         if (p.tri) return launch_tri<G, R, D, P>(p, b, s, ev0, ev1);                                        \
@@ -1136,10 +1146,12 @@ hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams&
     }
     BSK_VARIANTS(CASE)
 #undef CASE
+    *handled = false;
     return hipErrorInvalidValue;
 }
 
-const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat, int sh_form, bool pair, bool tri) {
+const void* BSK_PTR_UNIT(int grav, int nrw, bool diag, int feat, int sh_form, bool pair, bool tri, bool* handled) {
+    *handled = true;
 #define CASE(G, R, D, P) \
     if (grav == G && nrw == R && diag == D && feat == P) {                                                                     \
         if (tri) return tri_ptr<G, R, D, P>();                                                                                 \
@@ -1150,7 +1162,23 @@ const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat, int sh_form,
     }
     BSK_VARIANTS(CASE)
 #undef CASE
+    *handled = false;
     return nullptr;
 }
+
+#ifndef BSK_TU
+// one-unit builds (variant / probe libraries): the dispatcher is this unit itself
+hipError_t launch_step(int grav, int nrw, bool diag, int feat, const StepParams& p, const StepBuffers& b, int block,
+                       hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    bool handled = false;
+    return launch_step_unit(grav, nrw, diag, feat, p, b, block, s, ev0, ev1, &handled);
+}
+const void* step_kernel_ptr(int grav, int nrw, bool diag, int feat, int sh_form, bool pair, bool tri) {
+    bool handled = false;
+    return step_kernel_ptr_unit(grav, nrw, diag, feat, sh_form, pair, tri, &handled);
+}
+bool pair_available(int grav, bool diag, int feat) { return diag && grav != BSK_GRAV_SH && (feat == FEAT_POWER || feat == FEAT_FULL); }
+bool tri_available(int grav, bool diag, int feat) { return diag && grav != BSK_GRAV_SH && feat == FEAT_FULL; }
+#endif
 
 }  // namespace bsk
