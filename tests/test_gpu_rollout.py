@@ -193,3 +193,73 @@ def test_rollout_is_refused_where_it_is_not_built():
     with pytest.raises(BskError):
         BatchedPropagator(default_config(4, GRAV_PM_J2), 64).step_n(0, 1)
     p.close()
+
+
+def test_c_program_runs_a_whole_run_in_one_launch(tmp_path):
+    """tests/c_abi/c_abi_rollout.c: bsk_step_n from plain C99 through include/bskgpu.h - the reference main's 360 steps of action 0 as
+    ONE launch - gives the numbers 360 single steps through the Python binding give."""
+    import os
+    import subprocess
+    from basilisk_env_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "c_abi_rollout"
+    libdir = os.path.dirname(_lib.lib_path())
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c_abi", "c_abi_rollout.c"), "-L", libdir, "-lbskgpu",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    n, T = 70, 360
+    cfg = default_config(3, GRAV_PM)
+    ic = sample_ic_batch(n, 3, seed=46)
+    ic_file = tmp_path / "ic.bin"
+    ic.tofile(ic_file)
+    got = subprocess.check_output([str(exe), str(ic_file), str(n), str(T)]).decode().split()
+    p = BatchedPropagator(cfg, n)
+    p.reset(ic)
+    for _ in range(T):
+        p.step(np.zeros(n, np.int32), 10)
+    obs, rew, done, why = p.get_obs()
+    st = p.get_state()
+    steps, ticks = p.get_counters()
+    rsum, ndone = p.batch_stats()
+    want = [obs[0, 0], obs[1, 0], obs[2, n - 1], rew[n - 1], st[9, 0]]
+    assert [float(v) for v in got[:5]] == want
+    assert [int(v) for v in got[5:8]] == [int(why[0]), int(steps[n - 1]), int(ticks[0])] and int(got[7]) == 3600
+    assert float(got[8]) == rsum and int(got[9]) == ndone and got[10].startswith("rollout_kernel<PM,3,diag>")
+    p.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_rollouts_equal_single_steps(seed):
+    """Seeded random configurations: batch size, wheel set, gravity model, hub kind, FSW period and task-order switches, sub-steps,
+    episode length, pool size (or none), device-resident flags, action sequences, the cut of the rollout into launches."""
+    rng = np.random.default_rng(31000 + seed)
+    n = int(rng.choice([1, 64, 65, 130, 257, 700]))
+    n_rw = int(rng.choice([0, 3, 4]))
+    cfg = default_config(n_rw, int(rng.choice([GRAV_PM, GRAV_PM_J2])))
+    general_hub(cfg, rng, inertia=bool(rng.random() < 0.3), tilt=bool(n_rw and rng.random() < 0.3))
+    cfg.fsw_every = int(rng.choice([1, 2, 10, 13]))
+    cfg.fsw_lag, cfg.nav_lag = int(rng.random() < 0.7), int(rng.random() < 0.7)
+    cfg.max_length = int(rng.integers(1, 6))
+    cfg.dt = float(rng.choice([0.1, 0.25]))
+    pool = int(rng.choice([0, 5, 64]))
+    if pool:
+        cfg.flags |= FLAG_AUTO_RESET | (FLAG_EPISODE_STATS | FLAG_OBS_ROWMAJOR if rng.random() < 0.5 else 0)
+    single, rolled = _pair(cfg, n, seed=seed, pool=pool)
+    T, k = int(rng.integers(2, 16)), int(rng.choice([1, 2, 5, 10, 23]))
+    const = int(rng.integers(0, 3)) if rng.random() < 0.3 else None
+    actions = rng.integers(0, 3, (T, n)).astype(np.int32)
+    tag = (seed, n, n_rw, int(cfg.gravity_model), int(cfg.fsw_every), int(cfg.fsw_lag), int(cfg.nav_lag), pool, T, k, const)
+    cut = int(rng.integers(1, T))
+    # the rollout in two launches, the single steps in T: histories joined, final buffers compared
+    h_obs, h_rew, h_why = np.empty((T, 5, n)), np.empty((T, n)), np.empty((T, n), np.uint8)
+    for t in range(T):
+        single.step(actions[t] if const is None else np.full(n, const, np.int32), k)
+        h_obs[t], h_rew[t], _, h_why[t] = single.get_obs()
+    parts = [rolled.rollout(cut, k, actions=None if const is not None else actions[:cut], constant_action=const or 0),
+             rolled.rollout(T - cut, k, actions=None if const is not None else actions[cut:], constant_action=const or 0)]
+    for j, ref in enumerate((h_obs, h_rew, h_why)):
+        assert np.array_equal(np.concatenate([parts[0][j], parts[1][j]]), ref), (tag, j)
+    a, b = _everything(single, pool), _everything(rolled, pool)
+    for key in a:
+        assert np.array_equal(a[key], b[key]), (tag, key)
+    single.close(); rolled.close()
