@@ -454,7 +454,7 @@ struct bsk_handle {
     // wave; full-scenario level only, preferred over the pair form where both apply (profiles/r03/tri_form.txt: -16 % against
     // the pair form up to one workgroup per CU, twice the time above).  BSKGPU_TRI=0 / 1 forces it off / on.
     bool tri_ok = false, last_tri = false;
-    bool last_rollout = false;    // the last launch was bsk_step_n's rollout kernel (bsk_kernel_info)
+    bool last_rollout = false, last_rollout_act = false;    // the last launch was bsk_step_n's rollout kernel (with per-step actions); bsk_kernel_info
     int tri_min_substeps = 16, tri_max_envs = 16384;
 };
 
@@ -967,6 +967,7 @@ int bsk_step_n(bsk_handle* h, const int32_t* d_actions, int32_t constant_action,
     { int rc = stamp_events(h, e0, e1); if (rc) return rc; }
     h->last_pair = h->last_tri = false;
     h->last_rollout = true;
+    h->last_rollout_act = d_actions != nullptr;
     HIP_TRY(bsk::launch_rollout(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp, b, r, h->block, h->stream, e0, e1));
     h->stats_fresh = false;
     h->stepped = true;
@@ -1290,13 +1291,14 @@ int bsk_kernel_info(bsk_handle* h, char* name, int name_cap, int* vgprs, int* ld
     DeviceGuard guard(h->device);
     const bool sh = h->cfg.gravity_model == BSK_GRAV_SH;
     // (the kernel of the LAST launch: the pair form is chosen per launch by its number of sub-steps)
-    const void* fp = h->last_rollout ? bsk::rollout_kernel_ptr(h->cfg.gravity_model, h->cfg.n_rw, h->diag)
+    const void* fp = h->last_rollout ? bsk::rollout_kernel_ptr(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->last_rollout_act)
                                      : bsk::step_kernel_ptr(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp.feat, h->sp.sh_form, h->last_pair, h->last_tri);
     if (!fp) return fail(BSK_EINVAL, "no kernel variant for this config");
     hipFuncAttributes at;
     HIP_TRY(hipFuncGetAttributes(&at, fp));
     if (name && name_cap > 0 && h->last_rollout)
-        std::snprintf(name, name_cap, "rollout_kernel<%s,%d,%s>", h->cfg.gravity_model == BSK_GRAV_PM ? "PM" : "PM_J2", h->cfg.n_rw, h->diag ? "diag" : "full");
+        std::snprintf(name, name_cap, "rollout_kernel<%s,%d,%s,%s>", h->cfg.gravity_model == BSK_GRAV_PM ? "PM" : "PM_J2", h->cfg.n_rw, h->diag ? "diag" : "full",
+                      h->last_rollout_act ? "actions" : "constant");
     else if (name && name_cap > 0)
         std::snprintf(name, name_cap, "step_kernel<%s,%d,%s>",
                       h->cfg.gravity_model == BSK_GRAV_PM ? "PM" : (h->cfg.gravity_model == BSK_GRAV_PM_J2 ? "PM_J2" : (h->sp.sh_form == 5 ? "SH/dpp2" : (h->sp.sh_form == 4 ? "SH/dpp" : "SH/scalar"))), h->cfg.n_rw,

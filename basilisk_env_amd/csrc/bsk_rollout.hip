@@ -35,7 +35,13 @@ struct RolloutArgs {
     int n_steps, const_action;
 };
 
-template <int GRAV, int NRW, bool DIAG>
+// ACT: the launch reads an action per env step and spacecraft (false: ONE action for the whole rollout - no load inside the step loop at
+// all).  The actions are fetched a block of ACT_BLOCK steps ahead, as plain loads that stay in flight over the whole block, and packed
+// into one register (four bits each) when the block is through: a load per step, consumed by the next step, made the compiler drain the
+// memory pipeline at every step's end (s_waitcnt vmcnt(0) at the back edge - the history's seven stores with it: SQ_WAIT_ANY 0.25 of
+// the wave's cycles, VALU-active 0.62).
+constexpr int ACT_BLOCK = 8;
+template <int GRAV, int NRW, bool DIAG, bool ACT>
 __global__ __launch_bounds__(256, 2) void rollout_kernel(const RolloutArgs<NRW, DIAG> a) {
     constexpr int FEAT = FEAT_BARE, SPLIT = 1;
     const HotCfg<NRW, DIAG>& c = a.hot;
@@ -91,11 +97,31 @@ __global__ __launch_bounds__(256, 2) void rollout_kernel(const RolloutArgs<NRW, 
     int why = 0;
     bool was_reset = false;                      // the LAST step restarted this env: the slab already holds the new episode
 
-    // the NEXT step's action is fetched while this step integrates (a load per step on the critical path cost 0.6 us of 2.3)
-    int action_next = a.actions ? a.actions[i] : a.const_action;
-    for (int es = 0; es < a.n_steps; ++es) {
-        const int action = action_next;
-        if (a.actions && es + 1 < a.n_steps) action_next = a.actions[(int64_t)(es + 1) * hist_n + i];
+    unsigned act_cur = 0;                       // this block's actions, four bits each
+    int act_raw[ACT_BLOCK];                     // the NEXT block's, as loaded
+#pragma unroll
+    for (int k = 0; k < ACT_BLOCK; ++k) act_raw[k] = 0;
+    auto fetch_block = [&](int es0) __attribute__((always_inline)) {
+        if constexpr (ACT) {
+#pragma unroll
+            for (int k = 0; k < ACT_BLOCK; ++k)
+                if (es0 + k < a.n_steps) act_raw[k] = a.actions[(int64_t)(es0 + k) * hist_n + i];
+        }
+    };
+    auto pack_block = [&]() __attribute__((always_inline)) {
+        unsigned w = 0;
+#pragma unroll
+        for (int k = 0; k < ACT_BLOCK; ++k) w |= ((unsigned)act_raw[k] & 15u) << (4 * k);
+        return w;
+    };
+    if constexpr (ACT) { fetch_block(0); act_cur = pack_block(); }
+    for (int es0 = 0; es0 < a.n_steps; es0 += ACT_BLOCK) {
+      if constexpr (ACT) fetch_block(es0 + ACT_BLOCK);
+#pragma nounroll
+      for (int kk = 0; kk < ACT_BLOCK; ++kk) {
+        const int es = es0 + kk;
+        if (es >= a.n_steps) break;
+        const int action = ACT ? (int)((act_cur >> (4 * kk)) & 15u) : a.const_action;
         // ---- one env step: the tick loop of step_kernel at the bare level
         bool z0 = false;
         if constexpr (NRW > 0) z0 = navlag && tick == 0 && substeps > 0;
@@ -242,6 +268,8 @@ __global__ __launch_bounds__(256, 2) void rollout_kernel(const RolloutArgs<NRW, 
         }
         if (a.reward_hist) a.reward_hist[row] = rew;
         if (a.reason_hist) a.reason_hist[row] = (unsigned char)why;
+      }
+      if constexpr (ACT) act_cur = pack_block();
     }
 
     // ---- the launch's results, where step_kernel leaves them: the last step's outputs, the state, the counters
@@ -277,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void rollout_kernel(const RolloutArgs<NRW, 
 #undef FLD
 }
 
-template <int GRAV, int NRW, bool DIAG>
+template <int GRAV, int NRW, bool DIAG, bool ACT>
 static hipError_t launch_r(const StepParams& p, const StepBuffers& b, const RolloutBuffers& r, int block, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     RolloutArgs<NRW, DIAG> a;
     fill_hot<GRAV, NRW, DIAG>(p, a.hot);
@@ -294,7 +322,7 @@ static hipError_t launch_r(const StepParams& p, const StepBuffers& b, const Roll
     a.actions = r.actions; a.obs_hist = r.obs_hist; a.reward_hist = r.reward_hist; a.reason_hist = r.reason_hist;
     a.n_steps = r.n_steps; a.const_action = r.const_action;
     const int grid = (b.n + block - 1) / block;
-    hipExtLaunchKernelGGL((rollout_kernel<GRAV, NRW, DIAG>), dim3(grid), dim3(block), 0, s, ev0, ev1, 0, a);
+    hipExtLaunchKernelGGL((rollout_kernel<GRAV, NRW, DIAG, ACT>), dim3(grid), dim3(block), 0, s, ev0, ev1, 0, a);
     return hipGetLastError();
 }
 
@@ -302,7 +330,7 @@ bool rollout_available(int grav, int feat) { return (grav == BSK_GRAV_PM || grav
 
 hipError_t launch_rollout(int grav, int nrw, bool diag, const StepParams& p, const StepBuffers& b, const RolloutBuffers& r, int block,
                           hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-#define CASE(G, R, D) if (grav == G && nrw == R && diag == D) return launch_r<G, R, D>(p, b, r, block, s, ev0, ev1);
+#define CASE(G, R, D) if (grav == G && nrw == R && diag == D) return r.actions ? launch_r<G, R, D, true>(p, b, r, block, s, ev0, ev1) : launch_r<G, R, D, false>(p, b, r, block, s, ev0, ev1);
     CASE(BSK_GRAV_PM, 0, true) CASE(BSK_GRAV_PM, 3, true) CASE(BSK_GRAV_PM, 4, true)
     CASE(BSK_GRAV_PM_J2, 0, true) CASE(BSK_GRAV_PM_J2, 3, true) CASE(BSK_GRAV_PM_J2, 4, true)
     CASE(BSK_GRAV_PM, 0, false) CASE(BSK_GRAV_PM, 3, false) CASE(BSK_GRAV_PM, 4, false)
@@ -311,8 +339,8 @@ hipError_t launch_rollout(int grav, int nrw, bool diag, const StepParams& p, con
     return hipErrorInvalidValue;
 }
 
-const void* rollout_kernel_ptr(int grav, int nrw, bool diag) {
-#define CASE(G, R, D) if (grav == G && nrw == R && diag == D) return (const void*)&rollout_kernel<G, R, D>;
+const void* rollout_kernel_ptr(int grav, int nrw, bool diag, bool act) {
+#define CASE(G, R, D) if (grav == G && nrw == R && diag == D) return act ? (const void*)&rollout_kernel<G, R, D, true> : (const void*)&rollout_kernel<G, R, D, false>;
     CASE(BSK_GRAV_PM, 0, true) CASE(BSK_GRAV_PM, 3, true) CASE(BSK_GRAV_PM, 4, true)
     CASE(BSK_GRAV_PM_J2, 0, true) CASE(BSK_GRAV_PM_J2, 3, true) CASE(BSK_GRAV_PM_J2, 4, true)
     CASE(BSK_GRAV_PM, 0, false) CASE(BSK_GRAV_PM, 3, false) CASE(BSK_GRAV_PM, 4, false)

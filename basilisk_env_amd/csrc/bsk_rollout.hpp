@@ -16,6 +16,6 @@ struct RolloutBuffers {
 bool rollout_available(int grav, int feat);
 hipError_t launch_rollout(int grav, int nrw, bool diag, const StepParams& p, const StepBuffers& b, const RolloutBuffers& r, int block,
                           hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
-const void* rollout_kernel_ptr(int grav, int nrw, bool diag);
+const void* rollout_kernel_ptr(int grav, int nrw, bool diag, bool act);
 
 }  // namespace bsk

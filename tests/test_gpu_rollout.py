@@ -224,7 +224,7 @@ def test_c_program_runs_a_whole_run_in_one_launch(tmp_path):
     want = [obs[0, 0], obs[1, 0], obs[2, n - 1], rew[n - 1], st[9, 0]]
     assert [float(v) for v in got[:5]] == want
     assert [int(v) for v in got[5:8]] == [int(why[0]), int(steps[n - 1]), int(ticks[0])] and int(got[7]) == 3600
-    assert float(got[8]) == rsum and int(got[9]) == ndone and got[10].startswith("rollout_kernel<PM,3,diag>")
+    assert float(got[8]) == rsum and int(got[9]) == ndone and got[10].startswith("rollout_kernel<PM,3,diag,constant>")
     p.close()
 
 

@@ -31,7 +31,7 @@ for line in open(log):
         print(line.strip())
 PY
 fi
-# stats_kernel per batch size (tools/exp/stats_trace.py under the kernel tracer): per-dispatch durations + a summary
+# stats_kernel + stats_join_kernel per batch size (tools/exp/stats_trace.py under the kernel tracer): per-dispatch durations + a summary
 python3 - $S $D <<'PY'
 import csv, glob, json, os, sys
 s, d = sys.argv[1], sys.argv[2]
@@ -40,25 +40,32 @@ for run in sorted(glob.glob(s + "/kt_stats_*")):
     if not os.path.isdir(run):
         continue
     n = run.rsplit("_", 1)[1]
-    rows = []
-    for f in glob.glob(run + "/*/*_kernel_trace.csv"):
-        for r in csv.DictReader(open(f)):
-            if "stats_kernel" in r["Kernel_Name"]:
-                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r.get("Grid_Size_X") or r.get("Grid_Size")))
-    if not rows:
+    rows = {"stats_kernel": [], "stats_join_kernel": []}
+    fs = sorted(glob.glob(run + "/*/*_kernel_trace.csv"), key=os.path.getmtime)
+    for r in csv.DictReader(open(fs[-1])) if fs else []:
+        name = r["Kernel_Name"].split("(")[0].split("::")[-1]
+        if name in rows:
+            rows[name].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r.get("Grid_Size_X") or r.get("Grid_Size")))
+    if not rows["stats_kernel"]:
         continue
-    rows.sort()
     with open(os.path.join(d, "kt_stats_%s.csv" % n), "w") as g:
-        g.write("dispatch,start_offset_us,duration_ns,grid\n")
-        for k, (t, dur, grid) in enumerate(rows):
-            g.write("%d,%.3f,%d,%s\n" % (k, (t - rows[0][0]) / 1e3, dur, grid))
-    dur = sorted(r[1] for r in rows[len(rows) // 4:])          # the first quarter set aside (clock ramp)
-    cut = len(dur) // 10
-    core = dur[cut:len(dur) - cut] or dur
-    out[n] = {"dispatches": len(rows), "median_us": dur[len(dur) // 2] / 1e3, "trimmed_mean_us": sum(core) / len(core) / 1e3, "min_us": dur[0] / 1e3, "grid": rows[0][2]}
+        g.write("kernel,dispatch,start_offset_us,duration_ns,grid\n")
+        t0 = min(v[0][0] for v in rows.values() if v)
+        for name, v in rows.items():
+            v.sort()
+            for k, (t, dur, grid) in enumerate(v):
+                g.write("%s,%d,%.3f,%d,%s\n" % (name, k, (t - t0) / 1e3, dur, grid))
+    rec = {}
+    for name, v in rows.items():
+        dur = sorted(r[1] for r in v[len(v) // 4:])          # the first quarter set aside (clock ramp)
+        cut = len(dur) // 10
+        core = dur[cut:len(dur) - cut] or dur
+        rec[name] = {"dispatches": len(v), "median_us": dur[len(dur) // 2] / 1e3, "trimmed_mean_us": sum(core) / len(core) / 1e3, "min_us": dur[0] / 1e3, "grid": v[0][2]}
+    rec["both_trimmed_mean_us"] = rec["stats_kernel"]["trimmed_mean_us"] + rec["stats_join_kernel"]["trimmed_mean_us"]
+    out[n] = rec
 if out:
     json.dump(out, open(os.path.join(d, "kt_stats.json"), "w"), indent=1)
-    print("stats_kernel:", {k: round(v["trimmed_mean_us"], 2) for k, v in out.items()})
+    print("stats kernels (level 1 + join, us):", {k: "%.2f + %.2f" % (v["stats_kernel"]["trimmed_mean_us"], v["stats_join_kernel"]["trimmed_mean_us"]) for k, v in out.items()})
 PY
 [ -f gpurun_out/isa_$TAG/isa_mix.json ] && cp gpurun_out/isa_$TAG/isa_mix.json $D/
 [ -d gpurun_out/${TAG}_lines ] && cp gpurun_out/${TAG}_lines/bench_*.json $D/ 2>/dev/null

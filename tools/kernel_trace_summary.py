@@ -78,7 +78,7 @@ def main():
     extra_boxes = {}
     for sub in sorted(os.listdir(d)):
         p = os.path.join(d, sub)
-        if not os.path.isdir(p) or not sub.startswith("kt_"):
+        if not os.path.isdir(p) or not sub.startswith("kt_") or sub.startswith("kt_stats_"):      # (kt_stats_*: stats_kernel, collect_evidence.sh)
             continue
         fs = [f for f in glob.glob(os.path.join(p, "*", "*_kernel_trace.csv")) if os.path.getsize(f) > 0]
         if not fs:
