@@ -87,3 +87,20 @@ def test_bench_collective_legs_on_rccl_single_rank(tmp_path):
     assert "1048576" not in x["config3"]["workload"] and "131072 per GPU" in x["config3"]["workload"]
     assert x["config3"]["gather"]["shard_bytes"] == 5 * 131072 * 8
     assert x["strong_65536_total"]["k1800_env_steps_per_s"] > 1e6
+
+
+def test_a_hung_leg_under_the_launcher_still_yields_the_line_and_a_failure():
+    """The watchdog's failure path end to end (rehearsal: two ranks on this one card over gloo, the auxiliary leg replaced by one that
+    never returns): rank 0 prints the ONE JSON line with the timeout recorded in it, both ranks end with status 3, and the launcher -
+    hence `python bench.py --gpus 2` as typed - reports a failure instead of a clean exit."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, BENCH_REHEARSAL="1", BENCH_FAULT_HANG_LEG="1", BENCH_LEG_DEADLINE_S="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "50", "--warmup", "5", "--no-extra", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode != 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (lines, res.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "timeout after 2 s" in d["gather"]["direct_rccl"]
+    assert [r["rank"] for r in d["ranks"]] == [0, 1] and all(r["process_group_size"] == 2 for r in d["ranks"])
