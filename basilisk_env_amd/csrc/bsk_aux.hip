@@ -13,26 +13,7 @@
 
 namespace bsk {
 
-// Sum over the 64 lanes of a wave in the order of the xor butterfly v += v[lane ^ off], off = 32, 16, ..., 1 - as far as lane 0 is
-// concerned, which is the only lane whose result is used: at every level the lanes below `off` add the value `off` lanes up
-// (lane ^ off = lane + off there, and the addition commutes bit for bit).  The two upper levels cross 16-lane rows (ds_bpermute),
-// the four lower ones stay inside a row: DPP row shifts, no trip through the LDS crossbar.
-template <int CTRL>
-__device__ __forceinline__ double dpp_pull(double v) {
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, true);
-    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ double wave_sum(double v) {
-    v += __shfl_down(v, 32, 64);
-    v += __shfl_down(v, 16, 64);
-    v += dpp_pull<0x108>(v);      // row_shl:8  lane i <- lane i + 8
-    v += dpp_pull<0x104>(v);      // row_shl:4
-    v += dpp_pull<0x102>(v);      // row_shl:2
-    v += dpp_pull<0x101>(v);      // row_shl:1
-    return v;                     // (lane 0)
-}
+// (wave_sum(): bsk_device.hpp - the one definition the step kernel's optional in-launch sums share)
 
 // Deterministic batch scalars of the last step: sum of its rewards and number of finished envs (SURVEY.md section 8 row a7:
 // "batch sum-reward / sum-done via wave reductions"; reward semantics: reference envs/leoPowerAttitudeEnvironment.py:161-170).
@@ -84,11 +65,25 @@ __global__ __launch_bounds__(256) void stats_kernel(const double* __restrict__ r
     __syncthreads();
     if (threadIdx.x == 0) sc.done_part[blockIdx.x] = sdone[0] + sdone[1] + sdone[2] + sdone[3];
 }
-__global__ __launch_bounds__(256) void stats_join_kernel(StatsScratch sc, int n_waves, int n_parts, double* out_sum, long long* out_done, double* out2) {
+// `done_mask` != NULL (the step kernel formed the wave sums itself: bsk_set_step_stats): the done count comes from the waves' ballots
+__global__ __launch_bounds__(256) void stats_join_kernel(StatsScratch sc, int n_waves, int n_parts, const unsigned long long* __restrict__ done_mask,
+                                                         double* out_sum, long long* out_done, double* out2) {
     __shared__ double sr[256];
     __shared__ long long sd[256];
     long long nd = 0;
-    for (int g = (int)threadIdx.x; g < n_parts; g += 256) nd += (long long)sc.done_part[g];
+    if (done_mask) {
+        int g = (int)threadIdx.x;
+        for (; g + 15 * 256 < n_waves; g += 16 * 256) {
+            unsigned long long m[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) m[k] = done_mask[g + 256 * k];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) nd += __popcll(m[k]);
+        }
+        for (; g < n_waves; g += 256) nd += __popcll(done_mask[g]);
+    } else {
+        for (int g = (int)threadIdx.x; g < n_parts; g += 256) nd += (long long)sc.done_part[g];
+    }
     sd[threadIdx.x] = nd;
     const double* __restrict__ ws = sc.wave_sum;
     double acc = 0.0;
@@ -256,11 +251,16 @@ hipError_t launch_init_outputs(const double* st, int64_t stride, const int* idx,
 }
 
 hipError_t launch_stats(const double* reward, int n, const unsigned long long* done_mask, int n_waves, double* wsum,
-                        unsigned* done_part, double* out_sum, long long* out_done, double* out2, hipStream_t s) {
+                        unsigned* done_part, double* out_sum, long long* out_done, double* out2, bool have_wave_sums, hipStream_t s) {
+    if (have_wave_sums) {     // the step kernel wrote wave_sum[] itself: the second level alone
+        hipLaunchKernelGGL(stats_join_kernel, dim3(1), dim3(256), 0, s, StatsScratch{wsum, done_part}, n_waves, 0, done_mask, out_sum, out_done, out2);
+        return hipGetLastError();
+    }
     // one 256-thread workgroup per four waves of rewards, at most STATS_MAX_GRID of them
     const int grid = std::max(1, std::min((n_waves + 3) / 4, STATS_MAX_GRID));
     hipLaunchKernelGGL(stats_kernel, dim3(grid), dim3(256), 0, s, reward, n, done_mask, n_waves, StatsScratch{wsum, done_part});
-    hipLaunchKernelGGL(stats_join_kernel, dim3(1), dim3(256), 0, s, StatsScratch{wsum, done_part}, n_waves, grid, out_sum, out_done, out2);
+    hipLaunchKernelGGL(stats_join_kernel, dim3(1), dim3(256), 0, s, StatsScratch{wsum, done_part}, n_waves, grid, (const unsigned long long*)nullptr,
+                       out_sum, out_done, out2);
     return hipGetLastError();
 }
 

@@ -434,6 +434,8 @@ struct bsk_handle {
     unsigned long long* d_dbg = nullptr;   // one word per wave for probe builds (bsk_probes.hpp)
     double* d_stats2 = nullptr;   // {sum of rewards, number of done envs} of the last step, as two doubles (all-reduce operand)
     bool stats_fresh = false;     // d_stat_sum / d_stat_done / d_stats2 hold the LAST STEP's batch scalars (snapshot_stats)
+    bool step_stats = false;      // bsk_set_step_stats: step launches write d_wave_sum themselves (a request = the join kernel alone)
+    bool wave_sums_fresh = false; // ... and the last launch that wrote rewards did so
     bool stepped = false;         // some step has run since the handle was created
     // A launch of this handle has been recorded into a HIP graph (note_capture): replays advance the device without this
     // host-side state, so from then on nothing evaluated at enqueue time is trusted - the batch scalars are formed again
@@ -535,7 +537,7 @@ static bool note_capture(bsk_handle* h) {
 static int snapshot_stats(bsk_handle* h) {
     if (h->stats_fresh && !note_capture(h)) return BSK_OK;
     HIP_TRY(bsk::launch_stats(h->d_reward, h->n, h->d_done_mask, (h->n + 63) / 64, h->d_wave_sum, h->d_done_part,
-                              h->d_stat_sum, h->d_stat_done, h->d_stats2, h->stream));
+                              h->d_stat_sum, h->d_stat_done, h->d_stats2, h->wave_sums_fresh, h->stream));
     h->stats_fresh = true;
     return BSK_OK;
 }
@@ -562,6 +564,7 @@ void fill_buffers(bsk_handle* h, bsk::StepBuffers& b, const void* d_actions, int
     b.static_charge = static_charge ? 1 : 0;
     b.ep_return = h->d_ep_return; b.term_return = h->d_term_return; b.term_len = h->d_term_len; b.done = h->d_done;
     b.obs_rm = h->d_obs_rm; b.err = h->h_err; b.dbg = h->d_dbg;
+    b.wave_sum = h->step_stats ? h->d_wave_sum : nullptr;
     b.obs = h->d_obs;
     b.reward = h->d_reward;
     b.done_mask = h->d_done_mask;
@@ -620,6 +623,7 @@ int do_step(bsk_handle* h, const void* d_actions, int substeps, int act_shift) {
     h->last_rollout = false;
     HIP_TRY(bsk::launch_step(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp.feat, h->sp, b, h->block, h->stream, e0, e1));
     h->stats_fresh = false;
+    h->wave_sums_fresh = h->step_stats;
     h->stepped = true;
     return BSK_OK;
 }
@@ -970,6 +974,7 @@ int bsk_step_n(bsk_handle* h, const int32_t* d_actions, int32_t constant_action,
     h->last_rollout_act = d_actions != nullptr;
     HIP_TRY(bsk::launch_rollout(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp, b, r, h->block, h->stream, e0, e1));
     h->stats_fresh = false;
+    h->wave_sums_fresh = false;
     h->stepped = true;
     return BSK_OK;
 }
@@ -1176,6 +1181,12 @@ int bsk_get_episode_device(bsk_handle* h, double** d_ep_return, double** d_term_
     if (d_term_len) *d_term_len = h->d_term_len;
     if (d_done) *d_done = h->d_done;
     if (d_obs_rowmajor) *d_obs_rowmajor = h->d_obs_rm;
+    return BSK_OK;
+}
+
+int bsk_set_step_stats(bsk_handle* h, int on) {
+    if (!h) return fail(BSK_EINVAL, "handle is NULL");
+    h->step_stats = on != 0;
     return BSK_OK;
 }
 

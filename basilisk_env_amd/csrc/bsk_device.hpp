@@ -1871,4 +1871,25 @@ __device__ __forceinline__ void desat_tick(const ColdCfg* __restrict__ cc, const
     }
 }
 
+// Sum over the 64 lanes of a wave in the order of the xor butterfly v += v[lane ^ off], off = 32, 16, ..., 1 - as far as lane 0 is
+// concerned, which is the only lane whose result is used: at every level the lanes below `off` add the value `off` lanes up
+// (lane ^ off = lane + off there, and the addition commutes bit for bit).  The two upper levels cross 16-lane rows (ds_bpermute),
+// the four lower ones stay inside a row: DPP row shifts, no trip through the LDS crossbar.
+template <int CTRL>
+__device__ __forceinline__ double dpp_pull(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v += __shfl_down(v, 32, 64);
+    v += __shfl_down(v, 16, 64);
+    v += dpp_pull<0x108>(v);      // row_shl:8  lane i <- lane i + 8
+    v += dpp_pull<0x104>(v);      // row_shl:4
+    v += dpp_pull<0x102>(v);      // row_shl:2
+    v += dpp_pull<0x101>(v);      // row_shl:1
+    return v;                     // (lane 0)
+}
+
 }  // namespace bsk

@@ -1014,6 +1014,12 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
         stf(uniform_ptr(ta.ep_return), bo, ep_ret);
         ta.done[i] = why != 0 ? 1 : 0;
     }
+    if (BSK_UNLIKELY(ta.wave_sum != nullptr)) {
+        // bsk_set_step_stats: the first level of the batch reduction (stats_kernel, bsk_aux.hip) done here, behind every store of
+        // the launch - the same butterfly over the same 64 rewards, so the scalars do not depend on who formed the wave sums
+        const double ws = wave_sum(valid2 ? rew : 0.0);
+        if ((threadIdx.x & 63) == 0) ta.wave_sum[gid >> 6] = ws;
+    }
 }
 
 template <int GRAV, int NRW, bool DIAG, int FEAT, int SPLIT>
@@ -1036,7 +1042,7 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     a.tail.fsw_lag = p.fsw_lag; a.tail.nav_lag = p.nav_lag;
     a.tail.env_base = b.env_base; a.tail.static_charge = b.static_charge;
     a.tail.ep_return = b.ep_return; a.tail.term_return = b.term_return; a.tail.term_len = b.term_len; a.tail.done = b.done;
-    a.tail.obs_rm = b.obs_rm; a.tail.err = b.err; a.tail.dbg = b.dbg;
+    a.tail.obs_rm = b.obs_rm; a.tail.err = b.err; a.tail.dbg = b.dbg; a.tail.wave_sum = b.wave_sum;
     if (SPLIT == 5) block = 256;
     if (SPLIT == 2) block = 128;      // pair form: dynamics wave + FSW / environment wave of the same 64 spacecraft
     if (SPLIT == 3) block = 192;      // three-wave form: rotational, FSW / environment and translational wave

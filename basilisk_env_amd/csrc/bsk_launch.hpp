@@ -39,6 +39,8 @@ struct TailArgs {
     double* obs_rm;                // [n][5] row-major copy of the observation
     int* err;                      // device-visible error word of the handle (page-locked host memory; rarely written)
     unsigned long long* dbg;       // [stride/64] one word per wave, written by probe builds only (bsk_probes.hpp)
+    double* wave_sum;              // [stride/64] NULL: off.  bsk_set_step_stats: the wave's reward sum in stats_kernel's order, so that
+                                   // a request for the batch scalars behind this launch costs the join kernel alone
 };
 
 // Passed by value to step_kernel (kernarg segment -> SGPRs).
@@ -117,6 +119,7 @@ struct StepBuffers {
     double* obs_rm;
     int* err;
     unsigned long long* dbg;
+    double* wave_sum;
 };
 
 // the loop's constants as the kernels take them (by value in the kernarg segment)

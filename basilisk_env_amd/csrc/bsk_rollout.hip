@@ -318,7 +318,7 @@ static hipError_t launch_r(const StepParams& p, const StepBuffers& b, const Roll
     a.tail.fsw_lag = p.fsw_lag; a.tail.nav_lag = p.nav_lag;
     a.tail.env_base = b.env_base; a.tail.static_charge = 0;
     a.tail.ep_return = b.ep_return; a.tail.term_return = b.term_return; a.tail.term_len = b.term_len; a.tail.done = b.done;
-    a.tail.obs_rm = b.obs_rm; a.tail.err = b.err; a.tail.dbg = b.dbg;
+    a.tail.obs_rm = b.obs_rm; a.tail.err = b.err; a.tail.dbg = b.dbg; a.tail.wave_sum = nullptr;
     a.actions = r.actions; a.obs_hist = r.obs_hist; a.reward_hist = r.reward_hist; a.reason_hist = r.reason_hist;
     a.n_steps = r.n_steps; a.const_action = r.const_action;
     const int grid = (b.n + block - 1) / block;

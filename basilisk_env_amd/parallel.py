@@ -203,7 +203,9 @@ class DirectRcclGather(object):
     def all_reduce_stats(self):
         """{sum of rewards, number of done envs} of the whole batch on every rank's GPU: the device-side partial of this rank
         (bsk_get_batch_stats_device; untouched by the collective) all-reduced OUT OF PLACE on the handle's stream into a
-        result block of this object's own - calling it again before the next step gives the same sums again.
+        result block of this object's own - calling it again before the next step gives the same sums again.  A loop that calls it
+        after EVERY step switches prop.set_step_stats(True) on first: the step launch then forms the per-wave sums itself and the
+        operand costs one small launch (the join) instead of two.
         -> device pointer of the result f64[2]."""
         from . import _hip, rccl
         if self._stats_out is None:

@@ -254,6 +254,12 @@ class ShardedPropagator(object):
         """The observation part of gather_step_outputs_device (rewards and reasons travel in the same group)."""
         return self.gather_step_outputs_device(root)["obs"]
 
+    def set_step_stats(self, on=True):
+        """Every shard's step launches form the per-wave reward sums themselves (bsk_set_step_stats): for loops that call
+        all_reduce_stats_device / batch_stats after every step."""
+        for p in self.shards:
+            p.set_step_stats(on)
+
     def all_reduce_stats_device(self):
         """Batch scalars of the last step on EVERY shard's GPU: one ncclAllReduce of two doubles {sum of rewards, number of done
         envs} on the handles' streams, operands produced on the device (bsk_get_batch_stats_device) - no host value involved.

@@ -331,6 +331,11 @@ class BatchedPropagator(object):
         check(self._lib.bsk_get_batch_stats_device(self._handle(), C.byref(p)))
         return p.value
 
+    def set_step_stats(self, on=True):
+        """Every step launch forms the per-64-env reward sums in its own epilogue, so that batch_stats() / batch_stats_device()
+        behind it cost one small launch instead of two (same bits).  For loops that ask after every step; default off."""
+        check(self._lib.bsk_set_step_stats(self._handle(), 1 if on else 0))
+
     def get_terminal_obs(self):
         """-> terminal observations (5, N) (valid where the last step reported done), finished-episode
         counts (N,) int32."""

@@ -581,9 +581,10 @@ def fp64_point(key, mix_key, prop, d_ptr, n, substeps, steps, warmup, stamped, b
 
 
 def batch_stats_point(torch, cfg, n, n_rw, local, sample_ic_batch, BatchedPropagator, steps):
-    """What asking for the batch scalars after EVERY step costs (bsk_get_batch_stats_device: stats_kernel enqueued behind the
-    step kernel, no synchronisation): wall time per step of a back-to-back loop with and without the request.  The kernel's own
-    duration is in the committed rocprofv3 trace (profiles/r05/kt_stats_*.csv)."""
+    """What asking for the batch scalars after EVERY step costs (bsk_get_batch_stats_device: stats_kernel + stats_join_kernel
+    enqueued behind the step kernel, no synchronisation): wall time per step of a back-to-back loop with and without the request,
+    then the same with bsk_set_step_stats (the step launch forms the per-wave sums, a request is the join kernel alone).  The
+    kernels' own durations are in the committed rocprofv3 traces (profiles/r05/kt_stats_*.csv)."""
     p = BatchedPropagator(cfg, n, device=local)
     p.reset(sample_ic_batch(n, n_rw, seed=5))
     act = torch.zeros(n, dtype=torch.int32, device="cuda")
@@ -606,11 +607,17 @@ def batch_stats_point(torch, cfg, n, n_rw, local, sample_ic_batch, BatchedPropag
     base = min(loop(False) for _ in range(3))
     both = min(loop(True) for _ in range(3))
     rsum, ndone = p.batch_stats()
+    # bsk_set_step_stats: the first level inside the step launch (what a consumer that asks after EVERY step switches on)
+    p.set_step_stats(True)
+    fused_alone = min(loop(False) for _ in range(3))
+    fused = min(loop(True) for _ in range(3))
     rew = p.get_obs()[1]
-    ok = abs(rsum - float(rew.sum())) < 1e-9 * max(1.0, abs(float(rew.sum())))
+    rsum2 = p.batch_stats()[0]
+    ok = abs(rsum2 - float(rew.sum())) < 1e-9 * max(1.0, abs(float(rew.sum())))
     p.close()
     return {"envs": n, "step_us": base, "step_plus_stats_us": both, "added_us_per_step": both - base, "matches_host_sum": bool(ok),
-            "stats_grid": max(1, min((((n + 63) // 64) + 3) // 4, 2048))}
+            "stats_grid": max(1, min((((n + 63) // 64) + 3) // 4, 2048)),
+            "in_launch_wave_sums": {"step_us": fused_alone, "step_plus_stats_us": fused, "added_us_per_step": fused - base}}
 
 
 def rollout_point(torch, cfg, n, n_rw, local, sample_ic_batch, BatchedPropagator, T=541, reps=5, warm=1):
@@ -855,7 +862,7 @@ def main():
                                   a.substeps),
                    "envs_per_gpu": n, "substeps": a.substeps, "scenario": a.scenario, "lds_scratch": bool(a.lds_scratch), "fsw_timing": a.fsw_timing, "features": a.features,
                    "sharding": "env ranges, no step-path collective", "kernel_fingerprint": fp,
-                   "batch_stats": "on demand (bsk_get_batch_stats*: one launch of stats_kernel; a step produces the per-wave done ballot, no reward reduction)"},
+                   "batch_stats": "on demand (bsk_get_batch_stats*: stats_kernel + stats_join_kernel; a step produces the per-wave done ballot and no reward reduction unless bsk_set_step_stats asks for the per-wave sums: extra.batch_stats_us)"},
         "roofline": fp64 if fp64_bound else hbm,
         "rk4_substeps_per_s": value * a.substeps,
     }

@@ -273,14 +273,19 @@ int bsk_get_state_device(bsk_handle* h, double** d_state, int64_t* stride);
 
 /* Batch scalars of the LAST STEP: sum of its rewards and number of done envs, formed in a fixed order (bitwise
  * reproducible: per 64 envs an xor butterfly, the wave sums w = t mod 256 added in ascending order by thread t, a halving tree
- * over the 256 partials) from the reward buffer and the per-wave done ballots by ONE launch of a kernel of their own (a
- * multi-workgroup first level, the last workgroup to finish joins the partials) - once, when first asked for, or just before a
- * reset entry point zeroes the restarted envs' rewards.  A step does NOT produce them: its epilogue carries the done ballot
- * (one 64-bit mask per wave) and no reward reduction.  (Synchronises.) */
+ * over the 256 partials) from the reward buffer and the per-wave done ballots by two small launches of their own (a
+ * multi-workgroup first level: one sum per 64 envs; a single workgroup joins them) - once, when first asked for, or just before
+ * a reset entry point zeroes the restarted envs' rewards.  A step does NOT produce them unless bsk_set_step_stats says so: its
+ * epilogue carries the done ballot (one 64-bit mask per wave) and no reward reduction.  (Synchronises.) */
 int bsk_get_batch_stats(bsk_handle* h, double* reward_sum, int64_t* n_done);
 /* The same two scalars left ON the device as f64[2] = {sum of rewards, number of done envs}, enqueued on the handle's stream
  * without synchronising: the operand of the one all-reduce a sharded batch needs. */
 int bsk_get_batch_stats_device(bsk_handle* h, double** d_stats2);
+/* For consumers that ask for the batch scalars after EVERY step (the per-step all-reduce of a sharded batch, a monitor): on != 0
+ * makes every step launch (bsk_step*, not bsk_step_n) form the first level - the sum per 64 envs, same butterfly - in its own
+ * epilogue, behind its stores, so that a request costs the join launch alone.  Same bits either way.  Default off: a step that
+ * nobody asks about pays nothing.  (Takes effect with the next launch; a captured HIP graph keeps what it was captured with.) */
+int bsk_set_step_stats(bsk_handle* h, int on);
 
 /* Full state read-back / injection, host SoA [n_fields][n_envs] (parity tests, reset_init). */
 int bsk_n_fields(const bsk_handle* h);

@@ -302,6 +302,94 @@ def test_batch_stats_order_holds_at_every_scale(n):
     p.close()
 
 
+@pytest.mark.parametrize("case", ["bare-1", "bare-65", "bare-1000", "bare-65536", "bare-1048653", "scenario-1000", "general-1000", "pair-2000", "tri-1000",
+                                  "sh-300"])
+def test_wave_sums_formed_inside_the_step_launch_give_the_same_bits(case):
+    """bsk_set_step_stats: the step kernel's epilogue forms the first level of the batch reduction itself (every kernel form: one
+    wave, pair, three waves, harmonics pairs, general inertia, the scenario levels) and a request behind it runs the join kernel
+    alone.  Same tree, same bits as the two-launch form and as the documented order; switching it off, a rollout launch or a masked
+    reset in between fall back / keep the snapshot as before."""
+    from basilisk_env_amd._lib import FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY, GRAV_SH
+    from helpers import general_hub
+    kind, n = case.split("-")
+    n = int(n)
+    cfg = default_config(4, GRAV_SH if kind == "sh" else GRAV_PM_J2)
+    cfg.max_length = 2
+    sub = 1
+    if kind in ("scenario", "general", "pair", "tri"):
+        cfg.flags |= FLAG_POWER | FLAG_SUN_THIRD_BODY | FLAG_DRAG
+        cfg.base_density, cfg.scale_height = 1e-9, 100e3
+        if kind == "general":
+            general_hub(cfg)
+    if kind == "sh":
+        cfg.sh_degree = 8
+    if kind in ("pair", "tri"):
+        sub = 64
+    import os
+    old = {k: os.environ.get(k) for k in ("BSKGPU_PAIR", "BSKGPU_TRI")}
+    os.environ["BSKGPU_PAIR"], os.environ["BSKGPU_TRI"] = "1" if kind == "pair" else "0", "1" if kind == "tri" else "0"
+    try:
+        p = BatchedPropagator(cfg, n)
+        os.environ["BSKGPU_PAIR"] = os.environ["BSKGPU_TRI"] = "0"
+        twin = BatchedPropagator(cfg, n)                  # (always the single-wave form, sums formed by stats_kernel)
+    finally:
+        for k_, v_ in old.items():
+            if v_ is None:
+                del os.environ[k_]
+            else:
+                os.environ[k_] = v_
+    if kind == "sh":
+        from basilisk_env_amd.simulators.dynamics.gravity_sh import synthetic_sh_coefficients
+        cbar, sbar = synthetic_sh_coefficients(8, seed=3)
+        p.set_gravity_sh(8, cbar, sbar)
+        twin.set_gravity_sh(8, cbar, sbar)
+    ic = sample_ic_batch(n, 4, seed=31)
+    p.reset(ic)
+    twin.reset(ic)
+    p.set_step_stats(True)
+    rng = np.random.default_rng(n)
+    for k in range(4):
+        act = rng.integers(0, 3, n).astype(np.int32)
+        if k == 3:
+            p.set_step_stats(False)                      # off again: the two-launch form describes this step
+        p.step(act, sub)
+        twin.step(act, sub)
+        if kind in ("pair", "tri"):
+            assert kind in p.kernel_info()["name"]
+        if kind == "general":
+            assert "diag" not in p.kernel_info()["name"]
+        s, d = p.batch_stats()
+        obs, rew, done, why = p.get_obs()
+        assert (s, d) == twin.batch_stats() and s == _stats_order(rew) and d == int((why != 0).sum()), (case, k)
+        assert np.array_equal(rew, twin.get_obs()[1])
+        assert (d > 0) == (k >= 2)
+        if k == 1:                                       # a masked reset zeroes rewards: the snapshot (join alone) came first
+            mask = (rng.random(n) < 0.5).astype(np.uint8)
+            p.reset(sample_ic_batch(n, 4, seed=32), mask)
+            twin.reset(sample_ic_batch(n, 4, seed=32), mask)
+            assert p.batch_stats() == (s, d)
+    p.close()
+    twin.close()
+
+
+def test_a_rollout_launch_between_steps_does_not_leave_stale_wave_sums():
+    """bsk_step_n writes rewards of its last env step but no wave sums: the request behind it must run both levels."""
+    n = 3000
+    cfg = default_config(4, GRAV_PM_J2)
+    p = BatchedPropagator(cfg, n)
+    p.reset(sample_ic_batch(n, 4, seed=33))
+    p.set_step_stats(True)
+    p.step(np.zeros(n, np.int32), 1)
+    s0 = p.batch_stats()
+    out = p.rollout(5, 1, constant_action=1)
+    s, d = p.batch_stats()
+    rew = p.get_obs()[1]
+    assert s == _stats_order(rew) and (s, d) != s0
+    p.step(np.ones(n, np.int32), 1)
+    assert p.batch_stats()[0] == _stats_order(p.get_obs()[1])
+    p.close()
+
+
 def test_a_captured_graph_stays_correct_after_the_host_state_it_was_recorded_under_has_changed():
     """host-side decisions evaluated at enqueue time (the bare levels' static_charge, the batch scalars' freshness)
     would be frozen into a captured launch.  A step of the BARE kernel and a batch-stats request are captured while every

@@ -39,14 +39,14 @@ out = {}
 for run in sorted(glob.glob(s + "/kt_stats_*")):
     if not os.path.isdir(run):
         continue
-    n = run.rsplit("_", 1)[1]
+    n = os.path.basename(run)[len("kt_stats_"):]           # "65536", or "fused_65536": bsk_set_step_stats, the join kernel alone
     rows = {"stats_kernel": [], "stats_join_kernel": []}
     fs = sorted(glob.glob(run + "/*/*_kernel_trace.csv"), key=os.path.getmtime)
     for r in csv.DictReader(open(fs[-1])) if fs else []:
         name = r["Kernel_Name"].split("(")[0].split("::")[-1]
         if name in rows:
             rows[name].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r.get("Grid_Size_X") or r.get("Grid_Size")))
-    if not rows["stats_kernel"]:
+    if not rows["stats_join_kernel"]:
         continue
     with open(os.path.join(d, "kt_stats_%s.csv" % n), "w") as g:
         g.write("kernel,dispatch,start_offset_us,duration_ns,grid\n")
@@ -57,15 +57,17 @@ for run in sorted(glob.glob(s + "/kt_stats_*")):
                 g.write("%s,%d,%.3f,%d,%s\n" % (name, k, (t - t0) / 1e3, dur, grid))
     rec = {}
     for name, v in rows.items():
+        if not v:
+            continue
         dur = sorted(r[1] for r in v[len(v) // 4:])          # the first quarter set aside (clock ramp)
         cut = len(dur) // 10
         core = dur[cut:len(dur) - cut] or dur
         rec[name] = {"dispatches": len(v), "median_us": dur[len(dur) // 2] / 1e3, "trimmed_mean_us": sum(core) / len(core) / 1e3, "min_us": dur[0] / 1e3, "grid": v[0][2]}
-    rec["both_trimmed_mean_us"] = rec["stats_kernel"]["trimmed_mean_us"] + rec["stats_join_kernel"]["trimmed_mean_us"]
+    rec["both_trimmed_mean_us"] = sum(rec[k]["trimmed_mean_us"] for k in ("stats_kernel", "stats_join_kernel") if k in rec)
     out[n] = rec
 if out:
     json.dump(out, open(os.path.join(d, "kt_stats.json"), "w"), indent=1)
-    print("stats kernels (level 1 + join, us):", {k: "%.2f + %.2f" % (v["stats_kernel"]["trimmed_mean_us"], v["stats_join_kernel"]["trimmed_mean_us"]) for k, v in out.items()})
+    print("stats kernels (level 1 + join, us):", {k: "%.2f + %.2f" % (v.get("stats_kernel", {}).get("trimmed_mean_us", 0.0), v["stats_join_kernel"]["trimmed_mean_us"]) for k, v in out.items()})
 PY
 [ -f gpurun_out/isa_$TAG/isa_mix.json ] && cp gpurun_out/isa_$TAG/isa_mix.json $D/
 [ -d gpurun_out/${TAG}_lines ] && cp gpurun_out/${TAG}_lines/bench_*.json $D/ 2>/dev/null

@@ -1,6 +1,7 @@
-"""A step + a batch-scalars request per iteration, for `rocprofv3 --kernel-trace` (tools/round.sh: kt_stats_<n>): the duration of
-stats_kernel (bsk_kernels.hip: a multi-workgroup first level, the last workgroup joins the wave sums) at one batch size.
-usage: stats_trace.py N_ENVS [ITERATIONS]"""
+"""A step + a batch-scalars request per iteration, for `rocprofv3 --kernel-trace` (tools/round.sh: kt_stats_<n>): the durations of
+stats_kernel and stats_join_kernel (bsk_aux.hip) at one batch size; with `fused` the step launches form the wave sums themselves
+(bsk_set_step_stats) and a request is the join kernel alone.
+usage: stats_trace.py N_ENVS [ITERATIONS [fused]]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -11,6 +12,8 @@ from basilisk_env_amd.simulators.initial_conditions.batch import sample_ic_batch
 n = int(sys.argv[1]); iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
 p = BatchedPropagator(default_config(4, GRAV_PM_J2), n)
 p.reset(sample_ic_batch(n, 4, seed=1))
+if len(sys.argv) > 3 and sys.argv[3] == "fused":
+    p.set_step_stats(True)
 act = _hip.DeviceBuffer(4 * n, 0)
 _hip.check(_hip.runtime().hipMemsetAsync(act.ptr, 0, 4 * n, None), "hipMemsetAsync")
 _hip.stream_sync(0)

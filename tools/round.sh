@@ -46,6 +46,7 @@ prof sq_sh --pmc $SQ --output-format csv -d $O/sq_sh -- $BS
 # the batch scalars on demand (row a7): stats_kernel's own duration at four batch sizes, a request after every step
 for ns in 65536 131072 1048576 4194304; do
   prof kt_stats_$ns --kernel-trace --stats --output-format csv -d $O/kt_stats_$ns -- python3 $R/tools/exp/stats_trace.py $ns
+  prof kt_stats_fused_$ns --kernel-trace --stats --output-format csv -d $O/kt_stats_fused_$ns -- python3 $R/tools/exp/stats_trace.py $ns 3000 fused
 done
 cd $R
 python3 tools/prof_summary.py $O > $O/summary_latest.json 2>/dev/null && echo summary ok
