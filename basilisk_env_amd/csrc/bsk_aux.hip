@@ -65,49 +65,61 @@ __global__ __launch_bounds__(256) void stats_kernel(const double* __restrict__ r
     __syncthreads();
     if (threadIdx.x == 0) sc.done_part[blockIdx.x] = sdone[0] + sdone[1] + sdone[2] + sdone[3];
 }
-// `done_mask` != NULL (the step kernel formed the wave sums itself: bsk_set_step_stats): the done count comes from the waves' ballots
-__global__ __launch_bounds__(256) void stats_join_kernel(StatsScratch sc, int n_waves, int n_parts, const unsigned long long* __restrict__ done_mask,
-                                                         double* out_sum, long long* out_done, double* out2) {
+// `done_mask` != NULL (the step kernel formed the wave sums itself: bsk_set_step_stats): the done count comes from the waves' ballots.
+// 1 024 threads: the first 256 own the reward chains (their order is the documented one and cannot be cut), the other 768 count the
+// done bits - integers, any order - beside them, so that the second stream costs the launch no time of its own (one workgroup is
+// latency-bound: at 4 Mi spacecraft the masks are another 512 KB).
+constexpr int JOIN_THREADS = 1024;
+__global__ __launch_bounds__(JOIN_THREADS) void stats_join_kernel(StatsScratch sc, int n_waves, int n_parts, const unsigned long long* __restrict__ done_mask,
+                                                                  double* out_sum, long long* out_done, double* out2) {
     __shared__ double sr[256];
-    __shared__ long long sd[256];
+    __shared__ long long sd[JOIN_THREADS];
     long long nd = 0;
-    if (done_mask) {
-        int g = (int)threadIdx.x;
-        for (; g + 15 * 256 < n_waves; g += 16 * 256) {
-            unsigned long long m[16];
+    double acc = 0.0;
+    if (threadIdx.x >= 256) {
+        constexpr int H = JOIN_THREADS - 256;
+        int g = (int)threadIdx.x - 256;
+        if (done_mask) {
+            for (; g + 15 * H < n_waves; g += 16 * H) {
+                unsigned long long m[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) m[k] = done_mask[g + 256 * k];
+                for (int k = 0; k < 16; ++k) m[k] = done_mask[g + H * k];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) nd += __popcll(m[k]);
+                for (int k = 0; k < 16; ++k) nd += __popcll(m[k]);
+            }
+            for (; g < n_waves; g += H) nd += __popcll(done_mask[g]);
+        } else {
+            for (; g < n_parts; g += H) nd += (long long)sc.done_part[g];
         }
-        for (; g < n_waves; g += 256) nd += __popcll(done_mask[g]);
     } else {
-        for (int g = (int)threadIdx.x; g < n_parts; g += 256) nd += (long long)sc.done_part[g];
+        const double* __restrict__ ws = sc.wave_sum;
+        int w = (int)threadIdx.x;
+        // a row of 256 wave sums per trip (2 KB, coalesced); up to 32 rows in flight (16 waves on the CU: 128 registers each), added in
+        // ascending order
+        for (; w + 31 * 256 < n_waves; w += 32 * 256) {
+            double v[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) v[k] = ws[w + 256 * k];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) acc += v[k];
+        }
+        for (; w + 15 * 256 < n_waves; w += 16 * 256) {
+            double v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = ws[w + 256 * k];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc += v[k];
+        }
+        for (; w < n_waves; w += 256) acc += ws[w];
+        sr[threadIdx.x] = acc;
     }
     sd[threadIdx.x] = nd;
-    const double* __restrict__ ws = sc.wave_sum;
-    double acc = 0.0;
-    int w = (int)threadIdx.x;
-    // a row of 256 wave sums per trip (2 KB, coalesced); up to 64 rows in flight, added in ascending order
-    for (; w + 63 * 256 < n_waves; w += 64 * 256) {
-        double v[64];
-#pragma unroll
-        for (int k = 0; k < 64; ++k) v[k] = ws[w + 256 * k];
-#pragma unroll
-        for (int k = 0; k < 64; ++k) acc += v[k];
-    }
-    for (; w + 15 * 256 < n_waves; w += 16 * 256) {
-        double v[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = ws[w + 256 * k];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc += v[k];
-    }
-    for (; w < n_waves; w += 256) acc += ws[w];
-    sr[threadIdx.x] = acc;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) { sr[threadIdx.x] += sr[threadIdx.x + off]; sd[threadIdx.x] += sd[threadIdx.x + off]; }
+    for (int off = JOIN_THREADS / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            sd[threadIdx.x] += sd[threadIdx.x + off];
+            if (off < 256) sr[threadIdx.x] += sr[threadIdx.x + off];
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -253,13 +265,13 @@ hipError_t launch_init_outputs(const double* st, int64_t stride, const int* idx,
 hipError_t launch_stats(const double* reward, int n, const unsigned long long* done_mask, int n_waves, double* wsum,
                         unsigned* done_part, double* out_sum, long long* out_done, double* out2, bool have_wave_sums, hipStream_t s) {
     if (have_wave_sums) {     // the step kernel wrote wave_sum[] itself: the second level alone
-        hipLaunchKernelGGL(stats_join_kernel, dim3(1), dim3(256), 0, s, StatsScratch{wsum, done_part}, n_waves, 0, done_mask, out_sum, out_done, out2);
+        hipLaunchKernelGGL(stats_join_kernel, dim3(1), dim3(JOIN_THREADS), 0, s, StatsScratch{wsum, done_part}, n_waves, 0, done_mask, out_sum, out_done, out2);
         return hipGetLastError();
     }
     // one 256-thread workgroup per four waves of rewards, at most STATS_MAX_GRID of them
     const int grid = std::max(1, std::min((n_waves + 3) / 4, STATS_MAX_GRID));
     hipLaunchKernelGGL(stats_kernel, dim3(grid), dim3(256), 0, s, reward, n, done_mask, n_waves, StatsScratch{wsum, done_part});
-    hipLaunchKernelGGL(stats_join_kernel, dim3(1), dim3(256), 0, s, StatsScratch{wsum, done_part}, n_waves, grid, (const unsigned long long*)nullptr,
+    hipLaunchKernelGGL(stats_join_kernel, dim3(1), dim3(JOIN_THREADS), 0, s, StatsScratch{wsum, done_part}, n_waves, grid, (const unsigned long long*)nullptr,
                        out_sum, out_done, out2);
     return hipGetLastError();
 }

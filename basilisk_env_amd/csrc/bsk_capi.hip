@@ -564,7 +564,8 @@ void fill_buffers(bsk_handle* h, bsk::StepBuffers& b, const void* d_actions, int
     b.static_charge = static_charge ? 1 : 0;
     b.ep_return = h->d_ep_return; b.term_return = h->d_term_return; b.term_len = h->d_term_len; b.done = h->d_done;
     b.obs_rm = h->d_obs_rm; b.err = h->h_err; b.dbg = h->d_dbg;
-    b.wave_sum = h->step_stats ? h->d_wave_sum : nullptr;
+    // (above 2 Mi spacecraft one workgroup joining 32 768+ wave sums AND as many done ballots is no faster than the two-level form)
+    b.wave_sum = (h->step_stats && h->n <= (1 << 21)) ? h->d_wave_sum : nullptr;
     b.obs = h->d_obs;
     b.reward = h->d_reward;
     b.done_mask = h->d_done_mask;
@@ -623,7 +624,7 @@ int do_step(bsk_handle* h, const void* d_actions, int substeps, int act_shift) {
     h->last_rollout = false;
     HIP_TRY(bsk::launch_step(h->cfg.gravity_model, h->cfg.n_rw, h->diag, h->sp.feat, h->sp, b, h->block, h->stream, e0, e1));
     h->stats_fresh = false;
-    h->wave_sums_fresh = h->step_stats;
+    h->wave_sums_fresh = b.wave_sum != nullptr;
     h->stepped = true;
     return BSK_OK;
 }

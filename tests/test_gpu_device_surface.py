@@ -302,13 +302,13 @@ def test_batch_stats_order_holds_at_every_scale(n):
     p.close()
 
 
-@pytest.mark.parametrize("case", ["bare-1", "bare-65", "bare-1000", "bare-65536", "bare-1048653", "scenario-1000", "general-1000", "pair-2000", "tri-1000",
+@pytest.mark.parametrize("case", ["bare-1", "bare-65", "bare-1000", "bare-65536", "bare-1048653", "bare-2500000", "scenario-1000", "general-1000", "pair-2000", "tri-1000",
                                   "sh-300"])
 def test_wave_sums_formed_inside_the_step_launch_give_the_same_bits(case):
     """bsk_set_step_stats: the step kernel's epilogue forms the first level of the batch reduction itself (every kernel form: one
     wave, pair, three waves, harmonics pairs, general inertia, the scenario levels) and a request behind it runs the join kernel
-    alone.  Same tree, same bits as the two-launch form and as the documented order; switching it off, a rollout launch or a masked
-    reset in between fall back / keep the snapshot as before."""
+    alone (up to 2 Mi spacecraft; above, the two-level form stays).  Same tree, same bits as the two-launch form and as the documented
+    order; switching it off, a rollout launch or a masked reset in between fall back / keep the snapshot as before."""
     from basilisk_env_amd._lib import FLAG_DRAG, FLAG_POWER, FLAG_SUN_THIRD_BODY, GRAV_SH
     from helpers import general_hub
     kind, n = case.split("-")

@@ -41,15 +41,17 @@ txt = """# Round 5 profiles (MI355X, gfx950, ROCm 7.2 rocprofv3)
 
 Everything here was taken on the FINAL sources of the stepping path (`bench.py: kernel_fingerprint()` = `%s`, recorded in
 `kernel_trace.json` and `isa_mix.json`; `bench.py` prices its rooflines on these files only while the fingerprint of the tree it runs in
-agrees).  ONE evidence pass this round: `tools/round.sh r05` (GPU tests: 446 passed, 12 skipped; kernel traces; HBM traffic and issue
+agrees).  The evidence pass of the round, on the final sources: `tools/round.sh r05` (the whole GPU suite - 458 passed, 12 skipped -; kernel traces; HBM traffic and issue
 counter passes; the batch-scalars kernels at four sizes; the device-resident loop under the copy tracer; plain A/B lines; latency),
 `tools/kt_boxes.sh r05 2|3` (every trace again on two more boxes), `tools/isa_mix.sh r05`, then `tools/bench_lines.sh r05` with the
 summaries in place; summarised by `tools/kernel_trace_summary.py`, `tools/prof_summary.py`, `tools/isa_mix_summary.py`,
 `tools/collect_evidence.sh`.  Kernel traces and every `--pmc` set are separate runs.
 
-The step kernel's arithmetic did not change this round (the code objects are round 4's instruction streams, now spread over eight
-translation units: 194 096 DPP instructions and 256 `s_nop` in sum, as before); what is new is measured in the sections "Batch
-scalars", "Rollouts", "VecEnv" and `rejected/`.
+The step kernel's arithmetic did not change this round: the code objects are round 4's instruction streams spread over eight translation
+units, plus one optional block at the end of the epilogue (the per-wave reward sums of `bsk_set_step_stats`, skipped by a scalar branch when
+off: 195 296 DPP instructions and 253 `s_nop` in sum) - a same-box A/B of the K = 1 launch with and without the block reads 6.34 against
+6.34 us wall per launch (`ab_step_stats_block.txt`).  What is new is measured in the sections "Batch scalars", "Rollouts", "VecEnv" and
+`rejected/`.
 
 ## Kernel durations: rocprofv3 per-dispatch traces in steady state on THREE boxes, beside the same commands un-profiled
 
@@ -79,8 +81,8 @@ Other lines: `bench_steps20_warmup5.json` (the driver's window: 20 launches), `b
 
 ## Batch scalars on demand (`kt_stats.json`, `kt_stats_<N>.csv`; `tools/exp/stats_trace.py N`: a K = 1 step + a request per iteration, 3 000 iterations)
 
-| spacecraft | `stats_kernel` (level 1) | `stats_join_kernel` | both | added per step in the stepping loop (`extra.batch_stats_us`) |
-|---|---|---|---|---|
+| spacecraft | `stats_kernel` (level 1) | `stats_join_kernel` | both | added per step in the stepping loop (`extra.batch_stats_us`) | with `bsk_set_step_stats`: join alone | added per step |
+|---|---|---|---|---|---|---|
 """ % ((kt["fingerprint"], tab, bd["value"], bd["ms_per_step"] * 1e3, r["kernel_us"], r["achieved"], r["frac"], r["kernel_us_stamped"], r["wall_us_per_launch"],
         r["kernel_us_rocprof"], r["frac_on_bytes_moved"], r["traffic"] / 1e6, r["traffic"] / r["algorithmic_bytes"], r["algorithmic_bytes"] / 1e6, r["working_set"])
        + tuple(x[k]["kernel_ms"] for k in K) + tuple(x[k]["roofline"]["frac"] for k in K) + tuple(x[k]["roofline"]["frac_of_measured_fma_ceiling"] for k in K)
@@ -91,13 +93,17 @@ Other lines: `bench_steps20_warmup5.json` (the driver's window: 20 launches), `b
           bd["cpu_baseline"]["value"], bd["cpu_baseline"]["cores"], bd["cpu_baseline"]["single_thread"]["value"], x["full_k1800"]["cpu_baseline"]["value"],
           x["full_k1800"]["cpu_baseline"]["single_thread"]["value"]))
 for n in ("65536", "131072", "1048576", "4194304"):
-    v = st[n]
-    txt += "| %s | %.2f us | %.2f | **%.2f** | %.2f us |\n" % ("{:,}".format(int(n)).replace(",", " "), v["stats_kernel"]["trimmed_mean_us"], v["stats_join_kernel"]["trimmed_mean_us"],
-                                                              v["both_trimmed_mean_us"], x["batch_stats_us"][n]["added_us_per_step"])
+    v, f = st[n], st["fused_" + n]
+    fused = "%.2f us" % f["stats_join_kernel"]["trimmed_mean_us"] if "stats_kernel" not in f else "(two-level form kept: %.2f)" % f["both_trimmed_mean_us"]
+    txt += "| %s | %.2f us | %.2f | **%.2f** | %.2f us | %s | **%.2f us** |\n" % ("{:,}".format(int(n)).replace(",", " "), v["stats_kernel"]["trimmed_mean_us"], v["stats_join_kernel"]["trimmed_mean_us"],
+                                                                            v["both_trimmed_mean_us"], x["batch_stats_us"][n]["added_us_per_step"], fused, x["batch_stats_us"][n]["in_launch_wave_sums"]["added_us_per_step"])
 ro, ve = x["rollout"], x["vecenv_episode_end_ms"]
 txt += """
 Round 4's kernel (one workgroup walking everything) was never measured.  The three single-launch forms built first and their numbers:
-`rejected/stats_forms.txt`.  The order of the sum is unchanged (tests/test_gpu_device_surface.py: bit for bit from 1 to 4 Mi spacecraft).
+`rejected/stats_forms.txt`.  `bsk_set_step_stats` (for consumers that ask after every step): the step launch forms the per-wave sums in its
+epilogue (+0.02 ... 0.06 us on the K = 1 launch, nothing when off) and a request is the join kernel alone, up to 2 Mi spacecraft
+(`kt_stats_fused_<N>.csv`).  The order of the sum is unchanged either way (tests/test_gpu_device_surface.py: bit for bit from 1 to 4 Mi
+spacecraft, in every kernel form).
 
 ## Rollouts (`rollout_time.txt`, `pmc_rollout.txt`; `tools/exp/rollout_time.py`, `extra.rollout` of the default line)
 
@@ -131,6 +137,7 @@ step (two of the policy's, one step kernel), the library's own counters 0 copies
 | `tiled_layout.txt` (+ `.diff`) | wave-tiled state layout for the K = 1 launch, plain and pair-interleaved (`global_load_dwordx4`) | -3.0 %% at 65 536 (4 %% asked), pairs slower than plain tiles, +1 ... 12 %% / +25 %% at 4 Mi: the layout stays |
 | `sh_three_waves.txt` | a third wave per SIMD for config 5 (168-VGPR build, RK4 state parked around the walks) | 3.99 ns per spacecraft against 3.86 / 3.88 with two waves: not built |
 | `stats_forms.txt` | single-launch forms of the batch-scalars reduction (fences; write-through + ticket), an atomic done counter | 24 - 236 us, 7.6 - 99 us, 28 us when every env is done: two launches with per-workgroup partials shipped |
+| `rollout_fsw_lds.txt` | rollout kernel: FSW constants in LDS for the launch + an explicit wait in the restart branch (so that no load queues behind the history stores), with and without a one-wave register budget | 1.95 / 1.68 us per env step against 1.58: the loop does not wait for memory (counters in the file) |
 """ % (ro["65536"]["constant_action"]["us_per_env_step"], ro["65536"]["constant_action"]["env_steps_per_s"], ro["65536"]["device_actions"]["us_per_env_step"],
        ro["4194304"]["constant_action"]["us_per_env_step"], ro["4194304"]["constant_action"]["env_steps_per_s"],
        ve["device_pool"]["all_done_step_wait_ms"], ve["device_pool"]["ordinary_step_wait_ms"], ve["host_resets"]["all_done_step_wait_ms"],
