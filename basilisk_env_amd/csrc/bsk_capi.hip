@@ -564,8 +564,10 @@ void fill_buffers(bsk_handle* h, bsk::StepBuffers& b, const void* d_actions, int
     b.static_charge = static_charge ? 1 : 0;
     b.ep_return = h->d_ep_return; b.term_return = h->d_term_return; b.term_len = h->d_term_len; b.done = h->d_done;
     b.obs_rm = h->d_obs_rm; b.err = h->h_err; b.dbg = h->d_dbg;
-    // (above 2 Mi spacecraft one workgroup joining 32 768+ wave sums AND as many done ballots is no faster than the two-level form)
-    b.wave_sum = (h->step_stats && h->n <= (1 << 21)) ? h->d_wave_sum : nullptr;
+    // (above 2 Mi spacecraft one workgroup joining 32 768+ wave sums AND as many done ballots is no faster than the two-level form; a
+    // handle whose launches have been captured keeps the two-level form too: "the last launch wrote the wave sums" is host-side
+    // knowledge, and a replayed graph steps without telling the host)
+    b.wave_sum = (h->step_stats && !h->replayable && h->n <= (1 << 21)) ? h->d_wave_sum : nullptr;
     b.obs = h->d_obs;
     b.reward = h->d_reward;
     b.done_mask = h->d_done_mask;

@@ -284,7 +284,8 @@ int bsk_get_batch_stats_device(bsk_handle* h, double** d_stats2);
 /* For consumers that ask for the batch scalars after EVERY step (the per-step all-reduce of a sharded batch, a monitor): on != 0
  * makes every step launch (bsk_step*, not bsk_step_n) form the first level - the sum per 64 envs, same butterfly - in its own
  * epilogue, behind its stores, so that a request costs the join launch alone (batches of up to 2 Mi spacecraft; larger ones keep the
- * two-level form, which is as fast there).  Same bits either way.  Default off: a step that nobody asks about pays nothing.  (Takes effect with the next launch; a captured HIP graph keeps what it was captured with.) */
+ * two-level form, which is as fast there).  Same bits either way.  Default off: a step that nobody asks about pays nothing.  (Takes effect with the next launch; a handle whose launches have been captured into a HIP graph keeps
+ * the two-level form - replays step without the host's knowledge.) */
 int bsk_set_step_stats(bsk_handle* h, int on);
 
 /* Full state read-back / injection, host SoA [n_fields][n_envs] (parity tests, reset_init). */

@@ -429,6 +429,36 @@ def test_a_captured_graph_stays_correct_after_the_host_state_it_was_recorded_und
         p.close()
 
 
+def test_in_launch_wave_sums_are_not_trusted_once_a_graph_steps_the_handle():
+    """"The last launch wrote the per-wave sums" is host-side knowledge and a replayed graph steps without telling the host: a handle
+    whose launches have been captured forms the batch scalars from the reward buffer again (two-level form), whatever
+    bsk_set_step_stats says - an eager step with the sums followed by a replayed step without them must not join stale sums."""
+    import torch
+    n = 5000
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        p = BatchedPropagator(default_config(4, GRAV_PM_J2), n, stream=side.cuda_stream)
+        p.reset(sample_ic_batch(n, 4, seed=41))
+        a0 = torch.zeros(n, dtype=torch.int32, device="cuda")
+        a1 = torch.ones(n, dtype=torch.int32, device="cuda")
+        p.step_device(a0.data_ptr(), 1)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            p.step_device(a1.data_ptr(), 1)                # captured WITHOUT the sums
+        p.set_step_stats(True)
+        p.step_device(a0.data_ptr(), 1)                    # eager, action 0: rewards > 0
+        s0, _ = p.batch_stats()
+        assert s0 == _stats_order(p.get_obs()[1]) and s0 > 0.0
+        graph.replay()                                     # action 1: every reward is 0
+        torch.cuda.synchronize()
+        s1, _ = p.batch_stats()
+        rew = p.get_obs()[1]
+        assert np.all(rew == 0.0) and s1 == 0.0 == _stats_order(rew)
+        del graph
+        p.close()
+
+
 def test_step_tensors_loop_is_hip_graph_capturable():
     """The device-resident loop - policy kernels + step kernel + device-side auto-reset - captured in a HIP graph and replayed
     gives exactly what the eager loop gives: step_tensors launches on the capturing stream and issues nothing a capture
