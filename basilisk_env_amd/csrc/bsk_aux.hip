@@ -276,6 +276,27 @@ hipError_t launch_stats(const double* reward, int n, const unsigned long long* d
     return hipGetLastError();
 }
 
+// One row of a rollout's history from the handle's output buffers (bsk_step_n where the env steps are separate launches): what
+// bsk_get_obs would return now, left in row t of f64[T][5][n] / f64[T][n] / u8[T][n] (any of them may be NULL).
+__global__ void hist_row_kernel(const double* __restrict__ obs, const double* __restrict__ reward, const unsigned char* __restrict__ reason,
+                                int64_t stride, int n, double* __restrict__ obs_row, double* __restrict__ reward_row,
+                                unsigned char* __restrict__ reason_row) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (obs_row) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) obs_row[(int64_t)k * n + i] = obs[(int64_t)k * stride + i];
+    }
+    if (reward_row) reward_row[i] = reward[i];
+    if (reason_row) reason_row[i] = reason[i];
+}
+hipError_t launch_hist_row(const double* obs, const double* reward, const unsigned char* reason, int64_t stride, int n, double* obs_row,
+                           double* reward_row, unsigned char* reason_row, hipStream_t s) {
+    if (!obs_row && !reward_row && !reason_row) return hipSuccess;
+    hipLaunchKernelGGL(hist_row_kernel, dim3((n + 255) / 256), dim3(256), 0, s, obs, reward, reason, stride, n, obs_row, reward_row, reason_row);
+    return hipGetLastError();
+}
+
 int stats_done_parts() { return STATS_MAX_GRID; }
 
 hipError_t launch_scatter_reset(double* st, int64_t stride, int nf, const double* ic, const int* idx, int m, int2* cnt,

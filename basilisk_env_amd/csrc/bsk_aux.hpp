@@ -31,6 +31,10 @@ hipError_t launch_stats(const double* reward, int n, const unsigned long long* d
 hipError_t launch_scatter_reset(double* st, int64_t stride, int nf, const double* ic, const int* idx, int m, int2* cnt,
                                 hipStream_t s);
 
+// row t of a rollout's history from the handle's output buffers (bsk_step_n at the levels whose env steps stay separate launches)
+hipError_t launch_hist_row(const double* obs, const double* reward, const unsigned char* reason, int64_t stride, int n, double* obs_row,
+                           double* reward_row, unsigned char* reason_row, hipStream_t s);
+
 // first-level workgroups of stats_kernel at most = entries of the `done_part` scratch
 int stats_done_parts();
 

@@ -959,11 +959,23 @@ int bsk_step_n(bsk_handle* h, const int32_t* d_actions, int32_t constant_action,
     if (!h) return fail(BSK_EINVAL, "handle is NULL");
     if (substeps < 1 || n_steps < 1) return fail(BSK_EINVAL, "substeps and n_steps must be >= 1");
     if (!d_actions && (constant_action < 0 || constant_action > 2)) return fail(BSK_EINVAL, "constant_action must be 0, 1 or 2");
-    if (!bsk::rollout_available(h->cfg.gravity_model, h->sp.feat))
-        return fail(BSK_EINVAL, "bsk_step_n is built for the bare propagator (point mass / J2 without BSK_FLAG_POWER / BSK_FLAG_LDS_SCRATCH)");
     if ((h->cfg.flags & BSK_FLAG_AUTO_RESET) && h->n_pool == 0)
         return fail(BSK_EINVAL, "BSK_FLAG_AUTO_RESET: call bsk_set_ic_pool before stepping");
     DeviceGuard guard(h->device);
+    if (!bsk::rollout_available(h->cfg.gravity_model, h->sp.feat)) {
+        // The scenario levels, the harmonics, the LDS-scratch level: the env steps stay separate launches of step_kernel (at the
+        // reference's 1 800 sub-steps per env step a launch's overhead is 0.2 % of the step; the fused kernel exists where it is not),
+        // each followed by a row of the history - all enqueued here, no host visit in between.  Same results by construction.
+        if (!d_actions) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)h->d_act, constant_action, (size_t)h->n, h->stream));
+        for (int t = 0; t < n_steps; ++t) {
+            int rc = do_step(h, d_actions ? (const void*)(d_actions + (size_t)t * h->n) : (const void*)h->d_act, substeps, 1);
+            if (rc) return rc;
+            HIP_TRY(bsk::launch_hist_row(h->d_obs, h->d_reward, h->d_reason, h->stride, h->n,
+                                         d_obs_hist ? d_obs_hist + (size_t)t * 5 * h->n : nullptr, d_reward_hist ? d_reward_hist + (size_t)t * h->n : nullptr,
+                                         d_reason_hist ? d_reason_hist + (size_t)t * h->n : nullptr, h->stream));
+        }
+        return BSK_OK;
+    }
     bsk::StepBuffers b;
     (void)note_capture(h);
     fill_buffers(h, b, nullptr, substeps, 1, false);

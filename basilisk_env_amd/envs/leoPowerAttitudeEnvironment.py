@@ -204,6 +204,26 @@ def demo(episodes=2, action=0, seed=12345, plot=False):
     return histories
 
 
+def demo_batch(num_envs=1024, episodes=2, action=0, seed=12345, **vec_env_kwargs):
+    """The script's loop (:218-231: whole episodes of one action) for a BATCH of spacecraft: one ``LeoPowerAttVecEnv.rollout`` call per
+    episode - ``max_length + 1`` env steps enqueued by one library call, no host visit per step - instead of 541 ``step`` calls.
+    -> per episode (observations (steps, num_envs, 5), returns (num_envs,), lengths (num_envs,)) up to each spacecraft's first done;
+    prints one line per episode."""
+    from .leoPowerAttitudeVecEnv import LeoPowerAttVecEnv
+    env = LeoPowerAttVecEnv(num_envs, seed=seed, auto_reset=False, **vec_env_kwargs)
+    out = []
+    for ep in range(episodes):
+        env.reset()
+        obs, rew, dones, _ = env.rollout(env.max_length + 1, constant_action=action)
+        first = np.where(dones.any(axis=0), dones.argmax(axis=0), dones.shape[0] - 1)          # each spacecraft's terminal step
+        alive = np.arange(dones.shape[0])[:, None] <= first[None, :]
+        ret = (rew * alive).sum(axis=0)
+        out.append((obs[..., 0], ret, first + 1))
+        print("episode %d: %d spacecraft, steps %d ... %d, mean return %.4f" % (ep, num_envs, (first + 1).min(), (first + 1).max(), ret.mean()))
+    env.close()
+    return out
+
+
 if __name__ == "__main__":
     import sys
     demo(plot="--plot" in sys.argv)

@@ -358,6 +358,39 @@ class LeoPowerAttVecEnv(_Base):
         self.step_async(actions)
         return self.step_wait()
 
+    def rollout(self, n_steps, actions=None, constant_action=0):
+        """Open-loop evaluation: ``n_steps`` env steps under a fixed action sequence (``actions`` int (n_steps, N)) or ONE action -
+        what the reference's own mains do with one env (envs/leoPowerAttitudeEnvironment.py:218-231: whole episodes of action 0) -
+        enqueued by one library call (``bsk_step_n``: one launch at the bare level, one launch per env step at the scenario levels)
+        with no host visit per step.  -> obs (n_steps, N, 5, 1), rewards (n_steps, N), dones (n_steps, N) bool, reasons (n_steps, N)
+        uint8: row t is what ``step()`` number t would have returned (with a device reset pool, the restarted envs' observation is
+        the new episode's first one; without one, finished envs simply keep stepping - a host-side reset cannot happen inside the
+        call, so ``auto_reset`` without ``device_reset_pool`` is refused).  The env's own bookkeeping (episode returns and lengths,
+        the running episodes' initial conditions) ends as after those ``n_steps`` calls of ``step()``."""
+        T = int(n_steps)
+        if self.auto_reset and not self.device_reset:
+            raise ValueError("rollout(): host-side auto-reset cannot run inside the call; use device_reset_pool or auto_reset=False")
+        a = None
+        if actions is not None:
+            a = np.ascontiguousarray(actions, dtype=np.int32).reshape(T, self.num_envs)
+            if a.min() < 0 or a.max() > 2:
+                raise ValueError("actions must be in {0, 1, 2}")
+        elif not 0 <= int(constant_action) <= 2:
+            raise ValueError("actions must be in {0, 1, 2}")
+        obs, rew, why = self.propagator.rollout(T, self.substeps, actions=a, constant_action=int(constant_action))
+        dones = why != 0
+        for t in range(T):                             # (array work per step: the bookkeeping of step_wait)
+            self.episode_returns += rew[t]
+            if self.device_reset:
+                d = dones[t]
+                if d.any():
+                    self.episode_returns[d] = 0
+                    self.episode_lengths[d] = -1
+                    if self._ic_stale is not None:
+                        self._ic_stale[d] = True
+            self.episode_lengths += 1
+        return obs.transpose(0, 2, 1)[..., None], rew, dones, why
+
     # ------------------------------------------------------------------ device-resident surface (row f4)
     def _torch_views(self):
         """torch tensors over the library's device buffers (zero copy, made once)."""

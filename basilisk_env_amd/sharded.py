@@ -254,6 +254,13 @@ class ShardedPropagator(object):
         """The observation part of gather_step_outputs_device (rewards and reasons travel in the same group)."""
         return self.gather_step_outputs_device(root)["obs"]
 
+    def rollout(self, n_steps, substeps, actions=None, constant_action=0):
+        """``BatchedPropagator.rollout`` on every shard (one thread per device), histories joined in env order."""
+        acts = None if actions is None else np.ascontiguousarray(actions, dtype=np.int32)
+        res = self._each(lambda p, lo, hi: p.rollout(n_steps, substeps, None if acts is None else acts[:, lo:hi], constant_action))
+        return (np.concatenate([r[0] for r in res], axis=2), np.concatenate([r[1] for r in res], axis=1),
+                np.concatenate([r[2] for r in res], axis=1))
+
     def set_step_stats(self, on=True):
         """Every shard's step launches form the per-wave reward sums themselves (bsk_set_step_stats): for loops that call
         all_reduce_stats_device / batch_stats after every step."""

@@ -204,8 +204,9 @@ int bsk_step_device(bsk_handle* h, const int32_t* d_actions, int substeps);
  * the kernel reads the low word of each little-endian element. */
 int bsk_step_device_i64(bsk_handle* h, const int64_t* d_actions, int substeps);
 
-/* Open-loop rollout: `n_steps` env steps of `substeps` RK4 sub-steps each in ONE launch, the spacecraft's state kept in registers
- * across the steps.  What the reference's own mains do - whole episodes under one constant action
+/* Open-loop rollout: `n_steps` env steps of `substeps` RK4 sub-steps each, enqueued by ONE call - at the bare level (point mass / J2, no
+ * BSK_FLAG_POWER) as ONE launch with the spacecraft's state kept in registers across the steps; at the scenario levels and with the
+ * harmonics, where an env step is milliseconds of arithmetic, as one step launch + one history-row launch per env step.  What the reference's own mains do - whole episodes under one constant action
  * (envs/leoPowerAttitudeEnvironment.py:218-231; ...Simulator.py:657-694: 360 steps of action 0) - and what evaluating a fixed action
  * sequence does, without a launch, a state round trip through memory and a host visit per env step.
  *   d_actions   int32[n_steps][n_envs] in DEVICE memory, or NULL: `constant_action` at every step
@@ -215,8 +216,8 @@ int bsk_step_device_i64(bsk_handle* h, const int64_t* d_actions, int substeps);
  *               in the observation buffers), reward and reason are the finished step's.
  * Afterwards every buffer of the handle - state, counters, observation / reward / reason / done mask, terminal observations,
  * episode counts and statistics - holds, bit for bit, what `n_steps` calls of bsk_step_device with the same actions leave.
- * Per env step the launch reads 4 bytes (none for a constant action) and writes 49.  Asynchronous on the handle's stream.
- * Built for the bare propagator (point mass / J2, no BSK_FLAG_POWER): BSK_EINVAL otherwise. */
+ * Per env step the fused launch reads 4 bytes (none for a constant action) and writes 49.  Asynchronous on the handle's stream (a
+ * constant action at the unfused levels goes through the handle's own action buffer, the one bsk_step stages host actions in). */
 int bsk_step_n(bsk_handle* h, const int32_t* d_actions, int32_t constant_action, int substeps, int n_steps,
                double* d_obs_hist, double* d_reward_hist, uint8_t* d_reason_hist);
 

@@ -67,6 +67,15 @@ class OraclePropagator(object):
         if self._pool is not None:
             self._auto_reset()
 
+    def rollout(self, n_steps, substeps, actions=None, constant_action=0):
+        """BatchedPropagator.rollout's contract, by its definition: the histories of n_steps single steps."""
+        T, n = int(n_steps), self.n_envs
+        obs, rew, why = np.empty((T, 5, n)), np.empty((T, n)), np.empty((T, n), dtype=np.uint8)
+        for t in range(T):
+            self.step(np.full(n, constant_action, np.int32) if actions is None else actions[t], substeps)
+            obs[t], rew[t], _, why[t] = self.get_obs()
+        return obs, rew, why
+
     def set_ic_pool(self, ic_pool):
         self._pool = np.array(ic_pool, dtype=np.float64)
 

@@ -480,3 +480,46 @@ def test_all_done_step_with_host_resets_is_array_work_too():
     assert np.array_equal(obs[:, 0, 0], np.linalg.norm(env._ic[6:9], axis=0))      # the new episodes' first observations
     assert infos[4242]["episode"]["l"] == 1 and "terminal_observation" in infos[4242]
     env.close()
+
+
+@pytest.mark.parametrize("pool", [0, 8])
+@pytest.mark.parametrize("const", [None, 0])
+def test_rollout_is_n_steps_of_step_including_the_bookkeeping(pool, const):
+    """LeoPowerAttVecEnv.rollout (the reference's mains for a whole batch, envs/leoPowerAttitudeEnvironment.py:218-231): rows = what
+    step() number t returns, and episode returns / lengths / the running episodes' initial conditions end as after those steps."""
+    n, T = 12, 7
+    kw = dict(KW, n_rw=3, step_duration=1.0, seed=3, device_reset_pool=pool, auto_reset=bool(pool))
+    probe = LeoPowerAttVecEnv(n, **kw)
+    cfg = probe.cfg
+    probe.close()
+    cfg.max_length = 2
+    a, b = (LeoPowerAttVecEnv(n, cfg=cfg, step_duration=1.0, seed=3, device_reset_pool=pool, auto_reset=bool(pool), propagator_factory=OraclePropagator)
+            for _ in range(2))
+    a.reset(); b.reset()
+    rng = np.random.default_rng(5)
+    acts = rng.integers(0, 3, (T, n))
+    rows = [a.step(acts[t] if const is None else np.full(n, const)) for t in range(T)]
+    obs, rew, dones, why = b.rollout(T, actions=acts if const is None else None, constant_action=const or 0)
+    assert obs.shape == (T, n, 5, 1) and dones.any() and not dones.all()
+    for t in range(T):
+        assert np.array_equal(obs[t], rows[t][0]) and np.array_equal(rew[t], rows[t][1]) and np.array_equal(dones[t], rows[t][2])
+    assert np.array_equal(a.episode_returns, b.episode_returns) and np.array_equal(a.episode_lengths, b.episode_lengths)
+    if pool:
+        assert np.array_equal(a._ic, b._ic)
+    with pytest.raises(ValueError):
+        b.rollout(2, constant_action=5)
+    host = LeoPowerAttVecEnv(n, n_rw=3, step_duration=1.0, propagator_factory=OraclePropagator)      # host-side auto-reset
+    host.reset()
+    with pytest.raises(ValueError):
+        host.rollout(2)
+    for e in (a, b, host):
+        e.close()
+
+
+def test_demo_batch_runs_whole_episodes_in_one_call_each(capsys):
+    from basilisk_env_amd.envs.leoPowerAttitudeEnvironment import demo_batch
+    out = demo_batch(num_envs=5, episodes=2, n_rw=3, step_duration=1.0, propagator_factory=OraclePropagator, power=False)
+    assert len(out) == 2
+    obs, ret, length = out[0]
+    assert obs.shape[1:] == (5, 5) and ret.shape == (5,) and np.all(length >= 1) and np.all(ret > 0.0)       # (action 0 earns the nadir reward)
+    assert capsys.readouterr().out.count("episode") == 2

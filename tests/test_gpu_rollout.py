@@ -182,16 +182,94 @@ def test_whole_episode_in_one_launch_at_full_size():
     p.close()
 
 
-def test_rollout_is_refused_where_it_is_not_built():
-    cfg = default_config(4, GRAV_PM_J2)
-    cfg.flags |= FLAG_POWER
-    p = BatchedPropagator(cfg, 64)
-    p.reset(sample_ic_batch(64, 4, seed=1))
-    with pytest.raises(BskError) as e:
-        p.step_n(3, 1)
-    assert e.value.code == -1 and "bare propagator" in str(e.value)
+@pytest.mark.parametrize("level", ["power", "full", "full-desat", "general-full", "sh8", "ldss"])
+@pytest.mark.parametrize("const", [None, 0, 2])
+def test_rollout_at_the_levels_that_keep_one_launch_per_env_step(level, const):
+    """bsk_step_n where the fused kernel is not built (scenario levels, harmonics, LDS scratch): the call enqueues one step launch
+    + one history-row launch per env step - histories and every buffer bit for bit as T single steps, device-side restarts and the
+    handle's own action buffer (constant action) included; the reference's mains run exactly this level (1 800 sub-steps under one
+    action, envs/leoPowerAttitudeEnvironment.py:218-231)."""
+    from basilisk_env_amd._lib import FLAG_DESAT, FLAG_DRAG, FLAG_LDS_SCRATCH, FLAG_SUN_THIRD_BODY
+    from basilisk_env_amd.simulators.dynamics.gravity_sh import synthetic_sh_coefficients
+    n, T, pool = 333, 7, 16
+    cfg = default_config(4, GRAV_SH if level == "sh8" else GRAV_PM_J2)
+    cfg.max_length = 3
+    cfg.flags |= FLAG_AUTO_RESET | FLAG_EPISODE_STATS
+    if level == "power":
+        cfg.flags |= FLAG_POWER
+    if level in ("full", "full-desat", "general-full"):
+        cfg.flags |= FLAG_POWER | FLAG_SUN_THIRD_BODY | FLAG_DRAG | (FLAG_DESAT if level == "full-desat" else 0)
+        cfg.base_density, cfg.scale_height = 1e-9, 100e3
+    if level == "general-full":
+        general_hub(cfg)
+    if level == "ldss":
+        cfg.flags |= FLAG_LDS_SCRATCH
+    if level == "sh8":
+        cfg.sh_degree = 8
+    single, rolled = _pair(cfg, n, seed=500, pool=pool) if level != "sh8" else (None, None)
+    if level == "sh8":
+        cbar, sbar = synthetic_sh_coefficients(8, seed=8)
+        ic = sample_ic_batch(n, 4, seed=500)
+        props = []
+        for _ in range(2):
+            q = BatchedPropagator(cfg, n)
+            q.set_gravity_sh(8, cbar, sbar)
+            q.set_ic_pool(sample_ic_batch(pool, 4, seed=501))
+            q.reset(ic)
+            props.append(q)
+        single, rolled = props
+    rng = np.random.default_rng(17)
+    k = 25
+    actions = rng.integers(0, 3 if level == "full-desat" else 2, (T, n)).astype(np.int32)
+    h_obs, h_rew, h_why = np.empty((T, 5, n)), np.empty((T, n)), np.empty((T, n), np.uint8)
+    for t in range(T):
+        single.step(actions[t] if const is None else np.full(n, const, np.int32), k)
+        h_obs[t], h_rew[t], _, h_why[t] = single.get_obs()
+    r_obs, r_rew, r_why = rolled.rollout(T, k, actions=None if const is not None else actions, constant_action=const or 0)
+    assert np.array_equal(r_why, h_why) and np.array_equal(r_rew, h_rew) and np.array_equal(r_obs, h_obs), level
+    assert (h_why != 0).any() and (h_why == 0).any()
+    a, b = _everything(single, pool), _everything(rolled, pool)
+    for key in a:
+        assert np.array_equal(a[key], b[key]), (level, key)
+    assert rolled.kernel_info()["name"].startswith("step_kernel<")           # (no fused kernel at this level)
+    single.close(); rolled.close()
+
+
+@pytest.mark.parametrize("power", [False, True])
+def test_vec_env_rollout_equals_stepping_the_vec_env(power):
+    """LeoPowerAttVecEnv.rollout on the GPU engine - the fused kernel at the bare level, one launch per env step at the full scenario -
+    against a twin env stepped call by call: rows, episode bookkeeping, the running episodes' initial conditions."""
+    from basilisk_env_amd.envs import LeoPowerAttVecEnv
+    n, T = 300, 9
+    kw = dict(n_rw=4, gravity_model=GRAV_PM_J2, step_duration=2.0, seed=11, device_reset_pool=32, power=power)
+    probe = LeoPowerAttVecEnv(n, **kw)
+    cfg = probe.cfg
+    probe.close()
+    cfg.max_length = 3
+    a, b = (LeoPowerAttVecEnv(n, cfg=cfg, step_duration=2.0, seed=11, device_reset_pool=32) for _ in range(2))
+    a.reset(); b.reset()
+    acts = np.random.default_rng(2).integers(0, 3 if power else 2, (T, n))
+    rows = [a.step(acts[t]) for t in range(T)]
+    obs, rew, dones, why = b.rollout(T, actions=acts)
+    for t in range(T):
+        assert np.array_equal(obs[t], rows[t][0]) and np.array_equal(rew[t], rows[t][1]) and np.array_equal(dones[t], rows[t][2]), t
+    assert dones.any() and np.array_equal(a.episode_returns, b.episode_returns) and np.array_equal(a.episode_lengths, b.episode_lengths)
+    assert np.array_equal(a._ic, b._ic)
+    assert b.propagator.kernel_info()["name"].startswith("step_kernel<" if power else "rollout_kernel<")
+    o1, r1, d1, _ = b.rollout(2, constant_action=0)
+    ra = [a.step(np.zeros(n, np.int64)) for _ in range(2)]
+    assert np.array_equal(o1[1], ra[1][0]) and np.array_equal(r1[1], ra[1][1])
+    a.close(); b.close()
+
+
+def test_rollout_argument_checks():
+    p = BatchedPropagator(default_config(4, GRAV_PM_J2), 64)
     with pytest.raises(BskError):
-        BatchedPropagator(default_config(4, GRAV_PM_J2), 64).step_n(0, 1)
+        p.step_n(0, 1)
+    with pytest.raises(BskError):
+        p.step_n(3, 0)
+    with pytest.raises(BskError):
+        p.step_n(3, 1, None, 7)
     p.close()
 
 
