@@ -374,3 +374,24 @@ def test_all_reduce_stats_twice_between_steps_gives_the_same_sums(monkeypatch):
     for _ in range(2):
         for p in sp.all_reduce_stats_device():
             assert np.array_equal(np.ctypeslib.as_array((ctypes.c_double * 2).from_address(p)), want)
+
+
+def test_sharded_rollout_joins_the_shards_histories_in_env_order():
+    cfg = default_config(4, GRAV_PM_J2)
+    cfg.flags |= FLAG_AUTO_RESET
+    cfg.max_length = 2
+    n, T = 13, 5
+    ic = sample_ic_batch(n, 4, seed=1)
+    pool = sample_ic_batch(7, 4, seed=2)
+    one = OraclePropagator(cfg, n)
+    many = ShardedPropagator(cfg, n, devices=[0, 1, 2], propagator_factory=OraclePropagator)
+    for p in (one, many):
+        p.set_ic_pool(pool)
+        p.reset(ic)
+    acts = np.random.default_rng(4).integers(0, 3, (T, n)).astype(np.int32)
+    for x, y in zip(one.rollout(T, 5, actions=acts), many.rollout(T, 5, actions=acts)):
+        assert x.shape == y.shape and np.array_equal(x, y)
+    for x, y in zip(one.rollout(2, 5, constant_action=1), many.rollout(2, 5, constant_action=1)):
+        assert np.array_equal(x, y)
+    assert np.array_equal(one.get_state(), many.get_state())
+    many.close()
