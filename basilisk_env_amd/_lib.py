@@ -65,7 +65,7 @@ class BskConfig(C.Structure):
 
 EXPORTS = [
     "bsk_default_config", "bsk_create", "bsk_destroy", "bsk_set_gravity_sh", "bsk_reset", "bsk_step",
-    "bsk_step_device", "bsk_step_device_i64", "bsk_step_n", "bsk_get_episode_device", "bsk_get_batch_stats_device", "bsk_set_step_stats", "bsk_reset_from_pool_device", "bsk_debug_counters", "bsk_debug_words", "bsk_get_obs", "bsk_get_obs_device", "bsk_get_obs_state", "bsk_get_stream", "bsk_get_terminal_obs_device", "bsk_get_state_device", "bsk_get_batch_stats", "bsk_n_fields",
+    "bsk_step_device", "bsk_step_device_i64", "bsk_step_n", "bsk_get_episode_device", "bsk_get_batch_stats_device", "bsk_set_step_stats", "bsk_reset_from_pool_device", "bsk_debug_counters", "bsk_debug_words", "bsk_get_obs", "bsk_get_obs_rowmajor", "bsk_get_obs_device", "bsk_get_obs_state", "bsk_get_stream", "bsk_get_terminal_obs_device", "bsk_get_state_device", "bsk_get_batch_stats", "bsk_n_fields",
     "bsk_get_state", "bsk_set_state", "bsk_get_counters", "bsk_set_counters", "bsk_set_ic_pool", "bsk_sample_ic_pool", "bsk_reset_from_pool", "bsk_get_ic_pool", "bsk_get_terminal_obs", "bsk_set_env_base", "bsk_set_sim_time", "bsk_sync",
     "bsk_profile_begin", "bsk_profile_set_stride", "bsk_profile_end", "bsk_profile_end_samples", "bsk_calibrate_fp64", "bsk_kernel_info", "bsk_last_error", "bsk_version",
 ]
@@ -127,7 +127,7 @@ def load():
     lib.bsk_step.argtypes = [vp, vp, C.c_int]
     lib.bsk_step_device.argtypes = [vp, vp, C.c_int]
     for name, args in (("bsk_step_device_i64", [vp, vp, C.c_int]), ("bsk_get_episode_device", [vp, P(vp), P(vp), P(vp), P(vp), P(vp)]),
-                       ("bsk_get_batch_stats_device", [vp, P(vp)]), ("bsk_set_step_stats", [vp, C.c_int]), ("bsk_reset_from_pool_device", [vp, vp]),
+                       ("bsk_get_batch_stats_device", [vp, P(vp)]), ("bsk_set_step_stats", [vp, C.c_int]), ("bsk_get_obs_rowmajor", [vp, vp, vp, vp]), ("bsk_reset_from_pool_device", [vp, vp]),
                        ("bsk_debug_counters", [P(C.c_int64), P(C.c_int64)]), ("bsk_debug_words", [vp, vp]),
                        ("bsk_step_n", [vp, vp, C.c_int32, C.c_int, C.c_int, vp, vp, vp])):
         # (a BSKGPU_LIB variant built from an older tree - kernel A/B against a previous round - may predate these)

@@ -1023,6 +1023,18 @@ int bsk_get_obs_state(bsk_handle* h, double* obs, double* reward, uint8_t* done_
     return BSK_OK;
 }
 
+int bsk_get_obs_rowmajor(bsk_handle* h, double* obs_n5, double* reward, uint8_t* done_reason) {
+    if (!h) return fail(BSK_EINVAL, "handle is NULL");
+    if (!h->d_obs_rm) return fail(BSK_EINVAL, "bsk_get_obs_rowmajor needs BSK_FLAG_OBS_ROWMAJOR");
+    DeviceGuard guard(h->device);
+    const size_t row = (size_t)h->n * sizeof(double);
+    if (obs_n5) HIP_COPY(hipMemcpyAsync(obs_n5, h->d_obs_rm, 5 * row, hipMemcpyDeviceToHost, h->stream));
+    if (reward) HIP_COPY(hipMemcpyAsync(reward, h->d_reward, row, hipMemcpyDeviceToHost, h->stream));
+    if (done_reason) HIP_COPY(hipMemcpyAsync(done_reason, h->d_reason, (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+    SYNC_CHECKED(h);
+    return BSK_OK;
+}
+
 int bsk_get_obs_device(bsk_handle* h, double** d_obs, double** d_reward, uint64_t** d_done_mask, uint8_t** d_done_reason,
                        int64_t* stride) {
     if (!h) return fail(BSK_EINVAL, "handle is NULL");

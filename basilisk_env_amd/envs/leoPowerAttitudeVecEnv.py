@@ -308,15 +308,22 @@ class LeoPowerAttVecEnv(_Base):
         if self._actions is None:
             raise RuntimeError("step_wait() without a pending step_async()")
         self._actions = None
-        if getattr(self.propagator, "pinned_read_back", False):
-            # views of the propagator's page-locked read-back buffers (overwritten by the next step): everything this
-            # method returns is laid out afresh below
+        rm = self.propagator.get_obs_rowmajor() if self.device_reset and hasattr(self.propagator, "get_obs_rowmajor") else None
+        if rm is not None:
+            # the kernel's own row-major (N, 5) block in one contiguous copy: no transposition on the host (views of page-locked
+            # buffers the next step overwrites - everything this method returns is laid out afresh)
+            obs_nm, rew, done, why = rm
+            rew = rew.copy()
+            obs = None
+            obs_out = obs_nm.reshape(self.num_envs, 5, 1).copy()
+        elif getattr(self.propagator, "pinned_read_back", False):
             obs, rew, done, why = self.propagator.get_obs(copy=False)
             rew = rew.copy()
+            obs_out = obs.T.reshape(self.num_envs, 5, 1).copy()
         else:                                          # sharded engine (pinned fan-in of its own), the tests' oracle stand-in
             obs, rew, done, why = self.propagator.get_obs()
+            obs_out = obs.T.reshape(self.num_envs, 5, 1).copy()
         self.episode_returns += rew
-        obs_out = obs.T.reshape(self.num_envs, 5, 1).copy()
         idx = np.flatnonzero(done)
         terminal = None
         if idx.size:

@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from ... import _lib
-from ..._lib import BskConfig, check, n_fields
+from ..._lib import FLAG_OBS_ROWMAJOR, BskConfig, check, n_fields
 
 
 def pack_ic(n_rw, rN, vN, sigma, omega, wheelSpeeds=None, lext=None, charge=None, ucmd=None):
@@ -90,11 +90,12 @@ class BatchedPropagator(object):
         if getattr(self, "_h", None):
             self._lib.bsk_destroy(self._h)
             self._h = None
-        pin = getattr(self, "_pin", None)
-        if pin is not None:
-            for b in pin["bufs"]:
-                b.free()
-            self._pin = None
+        for name in ("_pin", "_pin_rm"):
+            pin = getattr(self, name, None)
+            if pin is not None:
+                for b in pin["bufs"]:
+                    b.free()
+                setattr(self, name, None)
 
     def __del__(self):
         try:
@@ -234,6 +235,23 @@ class BatchedPropagator(object):
         why = np.empty(self.n_envs, dtype=np.uint8)
         check(self._lib.bsk_get_obs(self._handle(), obs.ctypes.data, rew.ctypes.data, done.ctypes.data, why.ctypes.data))
         return obs, rew, done.astype(bool), why
+
+    def get_obs_rowmajor(self):
+        """-> obs (N, 5) f64, reward (N,), done (N,) bool, reason (N,) uint8 as views of page-locked buffers the NEXT call overwrites:
+        the row-major observation block the kernel writes under ``FLAG_OBS_ROWMAJOR``, in one contiguous copy (what a VecEnv hands
+        out as (N, 5, 1) without a host-side transposition).  None without the flag."""
+        if not (self.cfg.flags & FLAG_OBS_ROWMAJOR):
+            return None
+        pin = getattr(self, "_pin_rm", None)
+        if pin is None:
+            from ... import _hip
+            n = self.n_envs
+            f64, u8 = _hip.PinnedBuffer(6 * n * 8), _hip.PinnedBuffer(max(n, 1))
+            flat = f64.array.view(np.float64)
+            pin = self._pin_rm = {"bufs": [f64, u8], "obs": flat[:5 * n].reshape(n, 5), "rew": flat[5 * n:6 * n], "why": u8.array[:n],
+                                  "p_obs": f64.ptr, "p_rew": f64.ptr + 5 * n * 8, "p_why": u8.ptr}
+        check(self._lib.bsk_get_obs_rowmajor(self._handle(), pin["p_obs"], pin["p_rew"], pin["p_why"]))
+        return pin["obs"], pin["rew"], pin["why"] != 0, pin["why"]
 
     def get_obs_state(self):
         """-> obs (5, N), state (n_fields, N) with one stream synchronisation (what the single-env mirror reads per step)."""

@@ -235,6 +235,10 @@ int bsk_get_obs(bsk_handle* h, double* obs, double* reward, uint8_t* done, uint8
  * …Simulator.py:598-619 pulls the same quantities from the message logs).  Any pointer may be NULL. */
 int bsk_get_obs_state(bsk_handle* h, double* obs, double* reward, uint8_t* done_reason, double* state);
 
+/* The same read-back with the observation as the row-major f64[n_envs][5] block the kernel writes under BSK_FLAG_OBS_ROWMAJOR (one
+ * contiguous copy; the layout a VecEnv hands out as (N, 5, 1): no transposition on the host).  BSK_EINVAL without the flag.  Any
+ * pointer may be NULL.  Synchronises. */
+int bsk_get_obs_rowmajor(bsk_handle* h, double* obs_n5, double* reward, uint8_t* done_reason);
 /* Device pointers of the output buffers (for the RCCL gather / zero-copy hand-off).
  * obs stride (envs per field) is returned in *stride; done_mask is uint64[ceil(n/64)]. */
 int bsk_get_obs_device(bsk_handle* h, double** d_obs, double** d_reward, uint64_t** d_done_mask,
