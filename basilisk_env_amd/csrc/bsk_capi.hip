@@ -998,9 +998,17 @@ int bsk_get_obs(bsk_handle* h, double* obs, double* reward, uint8_t* done, uint8
     if (!h) return fail(BSK_EINVAL, "handle is NULL");
     DeviceGuard guard(h->device);
     const size_t row = (size_t)h->n * sizeof(double);
-    if (obs)
-        HIP_COPY(hipMemcpy2DAsync(obs, row, h->d_obs, (size_t)h->stride * sizeof(double), row, 5, hipMemcpyDeviceToHost, h->stream));
-    if (reward) HIP_COPY(hipMemcpyAsync(reward, h->d_reward, row, hipMemcpyDeviceToHost, h->stream));
+    if (obs && h->n == h->stride) {
+        // a batch that fills its stride: the five observation rows are one contiguous block, and the reward row sits right behind them
+        // on the device (one allocation) - one plain copy when the host arrays are laid out the same way, two otherwise
+        const bool with_reward = reward == obs + 5 * (size_t)h->n;
+        HIP_COPY(hipMemcpyAsync(obs, h->d_obs, (with_reward ? 6 : 5) * row, hipMemcpyDeviceToHost, h->stream));
+        if (reward && !with_reward) HIP_COPY(hipMemcpyAsync(reward, h->d_reward, row, hipMemcpyDeviceToHost, h->stream));
+    } else {
+        if (obs)
+            HIP_COPY(hipMemcpy2DAsync(obs, row, h->d_obs, (size_t)h->stride * sizeof(double), row, 5, hipMemcpyDeviceToHost, h->stream));
+        if (reward) HIP_COPY(hipMemcpyAsync(reward, h->d_reward, row, hipMemcpyDeviceToHost, h->stream));
+    }
     std::vector<unsigned char> why;
     unsigned char* wp = done_reason;
     if (done && !done_reason) { why.resize(h->n); wp = why.data(); }
