@@ -213,7 +213,7 @@ __device__ __forceinline__ void init_outputs(const ResetOut& ro, const double* _
                          st[(int64_t)(BSK_NF_BASE + ro.n_rw + BSK_T_CHARGE) * stride + i] * ro.charge_scale, 1.0};
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-        ro.obs[(int64_t)k * stride + i] = o[k];
+        ro.obs[(int64_t)k * ro.ostride + i] = o[k];
         if (ro.obs_rm) ro.obs_rm[(int64_t)i * 5 + k] = o[k];
     }
     ro.reward[i] = 0.0;

@@ -8,7 +8,8 @@ namespace bsk {
 
 // what a reset leaves in the output buffers of the envs it restarts (init_outputs_kernel)
 struct ResetOut {
-    double* obs;                   // [5][stride]
+    double* obs;                   // [5][ostride]
+    int64_t ostride;
     double* obs_rm;                // [n][5] or NULL
     double* reward;                // [stride]
     unsigned char* reason;         // [stride]

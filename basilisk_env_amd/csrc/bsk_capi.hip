@@ -392,7 +392,8 @@ struct bsk_handle {
     bool diag = false;
     bsk::ColdCfg* d_cold = nullptr;
     int n = 0, nf = 0, device = 0, block = 64;
-    int64_t stride = 0;
+    int64_t stride = 0;      // of the state slab's field rows (padded: bsk_create)
+    int64_t ostride = 0;     // of the observation / terminal-observation rows and the size of every per-env array
     hipStream_t stream = nullptr;
     bool own_stream = false;
     double* d_state = nullptr;
@@ -518,7 +519,7 @@ int ensure_stage(bsk_handle* h, size_t m) {
 
 bsk::ResetOut reset_out(const bsk_handle* h) {
     bsk::ResetOut ro;
-    ro.obs = h->d_obs; ro.obs_rm = h->d_obs_rm; ro.reward = h->d_reward; ro.reason = h->d_reason; ro.done = h->d_done;
+    ro.obs = h->d_obs; ro.ostride = h->ostride; ro.obs_rm = h->d_obs_rm; ro.reward = h->d_reward; ro.reason = h->d_reason; ro.done = h->d_done;
     ro.ep_return = h->d_ep_return;
     ro.inv_wheel_limit = h->sp.obs.inv_wheel_limit; ro.charge_scale = h->sp.obs.charge_scale;
     ro.n_rw = h->cfg.n_rw;
@@ -573,6 +574,7 @@ void fill_buffers(bsk_handle* h, bsk::StepBuffers& b, const void* d_actions, int
     b.done_mask = h->d_done_mask;
     b.reason = h->d_reason;
     b.stride = h->stride;
+    b.ostride = h->ostride;
     b.n = h->n;
     b.substeps = substeps;
     b.pool = h->d_pool;
@@ -762,7 +764,18 @@ int bsk_create(const bsk_config* cfg, int n_envs, int device_id, void* stream, b
     h->n = n_envs;
     h->nf = BSK_NF_BASE + cfg->n_rw + BSK_NF_TAIL;
     h->device = device_id;
-    h->stride = ((int64_t)n_envs + 255) / 256 * 256;
+    // Rows of N rounded up to 256 elements for everything a consumer sees (observation / reward rows, per-env arrays: a shard that
+    // fills its rows is one contiguous block for the exchange step) - and 256 B MORE per field row of the state slab: at a power-of-two
+    // distance the ~46 rows a wave loads at one lane offset all fall into the same L2 channel (the channel is picked from address bits
+    // 8 and up) and queue behind each other; an odd multiple of 256 B walks them round the channels.  K = 1 launch, same box: 6.36 ->
+    // 6.13 us at 65 536 spacecraft, 8.44 -> 8.26 at 131 072, no change where the slab streams from HBM (4 Mi); 512 B buys a third of
+    // it, 4 KB nothing (profiles/r05/stride_pad.txt).
+    h->ostride = ((int64_t)n_envs + 255) / 256 * 256;
+    h->stride = h->ostride + 32;
+    if (const char* sp = std::getenv("BSKGPU_STRIDE_PAD")) {   // measurement override: the slab's extra elements per row (multiples of 32)
+        const int v = std::atoi(sp);
+        if (v >= 0 && v % 32 == 0) h->stride = h->ostride + v;
+    }
     // 64-lane workgroups spread a small batch over more CUs (65 536 envs = 1 024 waves = 4 per CU);
     // large batches use 256 so the dispatcher has fewer workgroups to place.
     h->block = n_envs >= (1 << 20) ? 256 : 64;
@@ -795,14 +808,14 @@ int bsk_create(const bsk_config* cfg, int n_envs, int device_id, void* stream, b
         if (e != hipSuccess) { delete h; return fail(BSK_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
         h->own_stream = true;
     }
-    const int64_t S = h->stride;
+    const int64_t S = h->ostride;
     auto alloc = [&](void** p, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(p, bytes);
         if (e == hipSuccess) e = hipMemsetAsync(*p, 0, bytes, h->stream);
         return e;
     };
     hipError_t e = hipSuccess;
-    if (e == hipSuccess) e = alloc((void**)&h->d_state, (size_t)h->nf * S * sizeof(double));
+    if (e == hipSuccess) e = alloc((void**)&h->d_state, (size_t)h->nf * h->stride * sizeof(double));
     if (e == hipSuccess) e = alloc((void**)&h->d_cnt, (size_t)S * sizeof(int2));
     if (e == hipSuccess) e = alloc((void**)&h->d_act, (size_t)S * sizeof(int));
     // observation rows and the reward row in ONE allocation, f64[6][stride]: a shard whose size equals its stride hands the
@@ -909,7 +922,7 @@ int bsk_reset(bsk_handle* h, const uint8_t* mask, const double* ic) {
         for (int i = 0; i < h->n; ++i) h->charge_pos = h->charge_pos && ic_charge[i] > 0.0;
         HIP_COPY(hipMemcpy2DAsync(h->d_state, (size_t)h->stride * sizeof(double), ic, row, row, h->nf,
                                  hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipMemsetAsync(h->d_cnt, 0, (size_t)h->stride * sizeof(int2), h->stream));
+        HIP_TRY(hipMemsetAsync(h->d_cnt, 0, (size_t)h->ostride * sizeof(int2), h->stream));
         HIP_TRY(bsk::launch_init_outputs(h->d_state, h->stride, nullptr, h->n, reset_out(h), h->stream));
         HIP_SYNC(hipStreamSynchronize(h->stream));
         return BSK_OK;
@@ -970,7 +983,7 @@ int bsk_step_n(bsk_handle* h, const int32_t* d_actions, int32_t constant_action,
         for (int t = 0; t < n_steps; ++t) {
             int rc = do_step(h, d_actions ? (const void*)(d_actions + (size_t)t * h->n) : (const void*)h->d_act, substeps, 1);
             if (rc) return rc;
-            HIP_TRY(bsk::launch_hist_row(h->d_obs, h->d_reward, h->d_reason, h->stride, h->n,
+            HIP_TRY(bsk::launch_hist_row(h->d_obs, h->d_reward, h->d_reason, h->ostride, h->n,
                                          d_obs_hist ? d_obs_hist + (size_t)t * 5 * h->n : nullptr, d_reward_hist ? d_reward_hist + (size_t)t * h->n : nullptr,
                                          d_reason_hist ? d_reason_hist + (size_t)t * h->n : nullptr, h->stream));
         }
@@ -998,7 +1011,7 @@ int bsk_get_obs(bsk_handle* h, double* obs, double* reward, uint8_t* done, uint8
     if (!h) return fail(BSK_EINVAL, "handle is NULL");
     DeviceGuard guard(h->device);
     const size_t row = (size_t)h->n * sizeof(double);
-    if (obs && h->n == h->stride) {
+    if (obs && h->n == h->ostride) {
         // a batch that fills its stride: the five observation rows are one contiguous block, and the reward row sits right behind them
         // on the device (one allocation) - one plain copy when the host arrays are laid out the same way, two otherwise
         const bool with_reward = reward == obs + 5 * (size_t)h->n;
@@ -1006,7 +1019,7 @@ int bsk_get_obs(bsk_handle* h, double* obs, double* reward, uint8_t* done, uint8
         if (reward && !with_reward) HIP_COPY(hipMemcpyAsync(reward, h->d_reward, row, hipMemcpyDeviceToHost, h->stream));
     } else {
         if (obs)
-            HIP_COPY(hipMemcpy2DAsync(obs, row, h->d_obs, (size_t)h->stride * sizeof(double), row, 5, hipMemcpyDeviceToHost, h->stream));
+            HIP_COPY(hipMemcpy2DAsync(obs, row, h->d_obs, (size_t)h->ostride * sizeof(double), row, 5, hipMemcpyDeviceToHost, h->stream));
         if (reward) HIP_COPY(hipMemcpyAsync(reward, h->d_reward, row, hipMemcpyDeviceToHost, h->stream));
     }
     std::vector<unsigned char> why;
@@ -1022,8 +1035,8 @@ int bsk_get_obs(bsk_handle* h, double* obs, double* reward, uint8_t* done, uint8
 int bsk_get_obs_state(bsk_handle* h, double* obs, double* reward, uint8_t* done_reason, double* state) {
     if (!h) return fail(BSK_EINVAL, "handle is NULL");
     DeviceGuard guard(h->device);
-    const size_t row = (size_t)h->n * sizeof(double), pitch = (size_t)h->stride * sizeof(double);
-    if (obs) HIP_COPY(hipMemcpy2DAsync(obs, row, h->d_obs, pitch, row, 5, hipMemcpyDeviceToHost, h->stream));
+    const size_t row = (size_t)h->n * sizeof(double), pitch = (size_t)h->stride * sizeof(double), opitch = (size_t)h->ostride * sizeof(double);
+    if (obs) HIP_COPY(hipMemcpy2DAsync(obs, row, h->d_obs, opitch, row, 5, hipMemcpyDeviceToHost, h->stream));
     if (reward) HIP_COPY(hipMemcpyAsync(reward, h->d_reward, row, hipMemcpyDeviceToHost, h->stream));
     if (done_reason) HIP_COPY(hipMemcpyAsync(done_reason, h->d_reason, (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
     if (state) HIP_COPY(hipMemcpy2DAsync(state, row, h->d_state, pitch, row, h->nf, hipMemcpyDeviceToHost, h->stream));
@@ -1050,7 +1063,7 @@ int bsk_get_obs_device(bsk_handle* h, double** d_obs, double** d_reward, uint64_
     if (d_reward) *d_reward = h->d_reward;
     if (d_done_mask) *d_done_mask = (uint64_t*)h->d_done_mask;
     if (d_done_reason) *d_done_reason = h->d_reason;
-    if (stride) *stride = h->stride;
+    if (stride) *stride = h->ostride;
     return BSK_OK;
 }
 
@@ -1156,10 +1169,10 @@ static int ensure_pool_buffers(bsk_handle* h, int n_pool) {
         h->pool_cap = n_pool;
     }
     if (!h->d_term_obs) {
-        HIP_TRY(hipMalloc(&h->d_term_obs, (size_t)5 * h->stride * sizeof(double)));
-        HIP_TRY(hipMemset(h->d_term_obs, 0, (size_t)5 * h->stride * sizeof(double)));
-        HIP_TRY(hipMalloc(&h->d_episodes, (size_t)h->stride * sizeof(int)));
-        HIP_TRY(hipMemset(h->d_episodes, 0, (size_t)h->stride * sizeof(int)));
+        HIP_TRY(hipMalloc(&h->d_term_obs, (size_t)5 * h->ostride * sizeof(double)));
+        HIP_TRY(hipMemset(h->d_term_obs, 0, (size_t)5 * h->ostride * sizeof(double)));
+        HIP_TRY(hipMalloc(&h->d_episodes, (size_t)h->ostride * sizeof(int)));
+        HIP_TRY(hipMemset(h->d_episodes, 0, (size_t)h->ostride * sizeof(int)));
     }
     return BSK_OK;
 }
@@ -1186,7 +1199,7 @@ int bsk_reset_from_pool(bsk_handle* h, const uint8_t* mask) {
     if (h->stepped) { int rc = snapshot_stats(h); if (rc) return rc; }   // the last step's batch scalars, before its rewards are overwritten
     unsigned char* d_mask = nullptr;
     if (mask) {
-        if (!h->d_mask_stage) HIP_TRY(hipMalloc(&h->d_mask_stage, (size_t)h->stride));   // kept for the handle's lifetime
+        if (!h->d_mask_stage) HIP_TRY(hipMalloc(&h->d_mask_stage, (size_t)h->ostride));   // kept for the handle's lifetime
         d_mask = h->d_mask_stage;
         HIP_COPY(hipMemcpyAsync(d_mask, mask, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
     }
@@ -1262,7 +1275,7 @@ int bsk_get_terminal_obs(bsk_handle* h, double* term_obs, int32_t* episodes) {
     DeviceGuard guard(h->device);
     const size_t row = (size_t)h->n * sizeof(double);
     if (term_obs)
-        HIP_COPY(hipMemcpy2DAsync(term_obs, row, h->d_term_obs, (size_t)h->stride * sizeof(double), row, 5, hipMemcpyDeviceToHost, h->stream));
+        HIP_COPY(hipMemcpy2DAsync(term_obs, row, h->d_term_obs, (size_t)h->ostride * sizeof(double), row, 5, hipMemcpyDeviceToHost, h->stream));
     if (episodes) HIP_COPY(hipMemcpyAsync(episodes, h->d_episodes, (size_t)h->n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     SYNC_CHECKED(h);
     return BSK_OK;

@@ -857,6 +857,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
     TailArgs ta;
     __builtin_memcpy(&ta, (const TailArgs*)tp, sizeof(TailArgs));
     const int64_t S2 = uniform64(ta.stride);
+    const int64_t SO = uniform64(ta.ostride);      // observation rows: unpadded (the slab's rows are: bsk_capi.hip, bsk_create)
     const int n2 = ta.n;
     const bool valid2 = gid < n2;
     if constexpr (TRI) {
@@ -929,9 +930,9 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
         // Device-side auto-reset (rare, divergent): reload this env from the staged IC pool, keep the
         // finished episode's observation as terminal observation, report the new episode's first one.
         gptr<double> tob = uniform_ptr(ta.term_obs);
-        if (static_o3) o3 = *(gptr<double>)((gptr<char>)(ob + 3 * S2) + bo);      // (rare path: the finished episode's constant obs[3])
-        stf(tob + 0 * S2, bo, o0); stf(tob + 1 * S2, bo, o1); stf(tob + 2 * S2, bo, o2); stf(tob + 3 * S2, bo, o3);
-        stf(tob + 4 * S2, bo, o4);
+        if (static_o3) o3 = *(gptr<double>)((gptr<char>)(ob + 3 * SO) + bo);      // (rare path: the finished episode's constant obs[3])
+        stf(tob + 0 * SO, bo, o0); stf(tob + 1 * SO, bo, o1); stf(tob + 2 * SO, bo, o2); stf(tob + 3 * SO, bo, o3);
+        stf(tob + 4 * SO, bo, o4);
         const int ep = ta.episodes[i];
         ta.episodes[i] = ep + 1;
         const unsigned slot = (((unsigned)i + ta.env_base) * 2654435761u + (unsigned)ep * 40503u + 12345u) % (unsigned)n_pool;
@@ -950,8 +951,8 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
         }
         const double n0 = sqrt_nr(dot(ps, ps)), n1 = sqrt_nr(dot(pw, pw)), n2 = sqrt_nr(pom2) * ta.obs_cfg.inv_wheel_limit;
         const double n3 = pool[(int64_t)(TAIL + BSK_T_CHARGE) * n_pool + slot] * ta.obs_cfg.charge_scale;
-        stf(ob + 0 * S2, bo, n0); stf(ob + 1 * S2, bo, n1); stf(ob + 2 * S2, bo, n2); stf(ob + 3 * S2, bo, n3);
-        stf(ob + 4 * S2, bo, 1.0);
+        stf(ob + 0 * SO, bo, n0); stf(ob + 1 * SO, bo, n1); stf(ob + 2 * SO, bo, n2); stf(ob + 3 * SO, bo, n3);
+        stf(ob + 4 * SO, bo, 1.0);
         if (ta.obs_rm) {
             double* __restrict__ rm = ta.obs_rm + (int64_t)i * 5;
             rm[0] = n0; rm[1] = n1; rm[2] = n2; rm[3] = n3; rm[4] = 1.0;
@@ -990,9 +991,9 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
         const unsigned long long packed = (unsigned long long)(unsigned)(min(steps0 + 1, 0xFFFFF) | (phase << 20)) |
                                           ((unsigned long long)(unsigned)(cnt.y + ta.substeps) << 32);
         *(gptr<unsigned long long>)((gptr<char>)uniform_ptr(ta.cnt) + bo) = packed;
-        stf(ob + 0 * S2, bo, o0); stf(ob + 1 * S2, bo, o1); stf(ob + 2 * S2, bo, o2);
-        if (!static_o3) stf(ob + 3 * S2, bo, o3);
-        stf(ob + 4 * S2, bo, o4);
+        stf(ob + 0 * SO, bo, o0); stf(ob + 1 * SO, bo, o1); stf(ob + 2 * SO, bo, o2);
+        if (!static_o3) stf(ob + 3 * SO, bo, o3);
+        stf(ob + 4 * SO, bo, o4);
         if (ta.obs_rm) {       // optional row-major copy (N, 5): what a torch policy reshapes without a copy kernel
             double* __restrict__ rm = ta.obs_rm + (int64_t)i * 5;
             rm[0] = o0; rm[1] = o1; rm[2] = o2; rm[4] = o4;
@@ -1036,7 +1037,7 @@ static hipError_t launch_t(const StepParams& p, const StepBuffers& b, int block,
     a.extra = p.ex;
     a.tail.obs_cfg = p.obs; a.tail.st = b.st; a.tail.cnt = b.cnt; a.tail.obs = b.obs; a.tail.reward = b.reward;
     a.tail.done_mask = b.done_mask; a.tail.reason = b.reason;
-    a.tail.stride = b.stride; a.tail.n = b.n; a.tail.substeps = b.substeps;
+    a.tail.stride = b.stride; a.tail.ostride = b.ostride; a.tail.n = b.n; a.tail.substeps = b.substeps;
     a.tail.pool = b.pool; a.tail.term_obs = b.term_obs; a.tail.episodes = b.episodes;
     a.tail.n_pool = b.n_pool; a.tail.n_fields = b.n_fields;
     a.tail.fsw_lag = p.fsw_lag; a.tail.nav_lag = p.nav_lag;

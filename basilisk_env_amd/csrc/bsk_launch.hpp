@@ -19,7 +19,8 @@ struct TailArgs {
     double* reward;                // [stride]
     unsigned long long* done_mask; // [stride/64], one 64-bit ballot per wavefront
     unsigned char* reason;         // [stride]
-    int64_t stride;
+    int64_t stride;                // of the state slab's field rows
+    int64_t ostride;               // of the observation / terminal-observation rows (bsk_capi.hip: the two differ by the slab's padding)
     int n;
     int substeps;
     // device-side auto-reset (n_pool == 0: off)
@@ -102,6 +103,7 @@ struct StepBuffers {
     unsigned long long* done_mask;
     unsigned char* reason;
     int64_t stride;
+    int64_t ostride;
     int n;
     int substeps;
     const double* pool;

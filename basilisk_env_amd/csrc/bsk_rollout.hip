@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256, 2) void rollout_kernel(const RolloutArgs<NRW, 
     const bool valid = gid < n;
     const int i = valid ? gid : n - 1;    // tail lanes shadow the last env (identical inputs, identical results, identical stores)
     const int64_t S = ta.stride;
+    const int64_t SO = ta.ostride;
     gptr<double> so = uniform_ptr(ta.st);
     const uint32_t bo = (uint32_t)i * 8u;
     constexpr int TAIL = BSK_NF_BASE + NRW;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void rollout_kernel(const RolloutArgs<NRW, 
             // continues from pool slot ((env_base + env) 2654435761 + episode 40503 + 12345) mod 2^32 mod n_pool - in the slab (every
             // field, as step_kernel writes it) AND in this lane's registers
             gptr<double> tob = uniform_ptr(ta.term_obs);
-            stf(tob + 0 * S, bo, o0); stf(tob + 1 * S, bo, o1); stf(tob + 2 * S, bo, o2); stf(tob + 3 * S, bo, o3); stf(tob + 4 * S, bo, o4);
+            stf(tob + 0 * SO, bo, o0); stf(tob + 1 * SO, bo, o1); stf(tob + 2 * SO, bo, o2); stf(tob + 3 * SO, bo, o3); stf(tob + 4 * SO, bo, o4);
             const unsigned slot = (((unsigned)i + ta.env_base) * 2654435761u + (unsigned)ep * 40503u + 12345u) % (unsigned)n_pool;
             ep += 1;
             if (valid) ta.episodes[i] = ep;
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void rollout_kernel(const RolloutArgs<NRW, 
     const unsigned long long dmask = __ballot(valid && why != 0);
     if ((threadIdx.x & 63) == 0) ta.done_mask[gid >> 6] = dmask;
     gptr<double> ob = uniform_ptr(ta.obs);
-    stf(ob + 0 * S, bo, o0); stf(ob + 1 * S, bo, o1); stf(ob + 2 * S, bo, o2); stf(ob + 3 * S, bo, o3); stf(ob + 4 * S, bo, o4);
+    stf(ob + 0 * SO, bo, o0); stf(ob + 1 * SO, bo, o1); stf(ob + 2 * SO, bo, o2); stf(ob + 3 * SO, bo, o3); stf(ob + 4 * SO, bo, o4);
     if (ta.obs_rm) {
         double* __restrict__ rm = ta.obs_rm + (int64_t)i * 5;
         rm[0] = o0; rm[1] = o1; rm[2] = o2; rm[3] = o3; rm[4] = o4;
@@ -312,7 +313,7 @@ static hipError_t launch_r(const StepParams& p, const StepBuffers& b, const Roll
     a.cold = b.cold;
     a.tail.obs_cfg = p.obs; a.tail.st = b.st; a.tail.cnt = b.cnt; a.tail.obs = b.obs; a.tail.reward = b.reward;
     a.tail.done_mask = b.done_mask; a.tail.reason = b.reason;
-    a.tail.stride = b.stride; a.tail.n = b.n; a.tail.substeps = b.substeps;
+    a.tail.stride = b.stride; a.tail.ostride = b.ostride; a.tail.n = b.n; a.tail.substeps = b.substeps;
     a.tail.pool = b.pool; a.tail.term_obs = b.term_obs; a.tail.episodes = b.episodes;
     a.tail.n_pool = b.n_pool; a.tail.n_fields = b.n_fields;
     a.tail.fsw_lag = p.fsw_lag; a.tail.nav_lag = p.nav_lag;

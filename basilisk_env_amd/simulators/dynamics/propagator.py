@@ -287,9 +287,10 @@ class BatchedPropagator(object):
             "reason": _DevArray(pw.value, (n,), "|u1", **kw),
             "stride": st.value,
         }
-        ps = C.c_void_p()
-        check(self._lib.bsk_get_state_device(self._handle(), C.byref(ps), None))
-        out["state"] = _DevArray(ps.value, (self.n_fields, n), "<f8", strides=(st.value * 8, 8), **kw)
+        ps, sst = C.c_void_p(), C.c_int64()
+        check(self._lib.bsk_get_state_device(self._handle(), C.byref(ps), C.byref(sst)))      # (the slab's rows have a stride of their own)
+        out["state"] = _DevArray(ps.value, (self.n_fields, n), "<f8", strides=(sst.value * 8, 8), **kw)
+        out["state_stride"] = sst.value
         pt, pe = C.c_void_p(), C.c_void_p()
         check(self._lib.bsk_get_terminal_obs_device(self._handle(), C.byref(pt), C.byref(pe)))
         if pt.value:
