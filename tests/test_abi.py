@@ -84,6 +84,11 @@ def test_abi_rejects_bad_config():
     assert lib.bsk_create(ctypes.byref(c), 4, 0, None, ctypes.byref(h)) == -1
     c = default_config(3, _lib.GRAV_PM)
     assert lib.bsk_create(ctypes.byref(c), 0, 0, None, ctypes.byref(h)) == -1
+    assert lib.bsk_create(ctypes.byref(c), (1 << 28) + 1, 0, None, ctypes.byref(h)) == -1      # per-lane byte offsets are 32-bit: 2^28 envs at most
+    assert b"2^28" in lib.bsk_last_error()
+    assert lib.bsk_create(ctypes.byref(c), 1 << 28, 0, None, ctypes.byref(h)) == -2           # (a valid size: refused for want of a GPU here)
+    for fn, args in (("bsk_set_step_stats", (None, 1)), ("bsk_get_obs_rowmajor", (None, None, None, None)), ("bsk_step_n", (None, None, 0, 1, 1, None, None, None))):
+        assert getattr(lib, fn)(*args) == -1
     assert lib.bsk_step(None, None, 1) == -1 and lib.bsk_get_obs(None, None, None, None, None) == -1
     assert lib.bsk_version().startswith(b"bskgpu")
 
