@@ -765,11 +765,13 @@ int bsk_create(const bsk_config* cfg, int n_envs, int device_id, void* stream, b
     h->nf = BSK_NF_BASE + cfg->n_rw + BSK_NF_TAIL;
     h->device = device_id;
     // Rows of N rounded up to 256 elements for everything a consumer sees (observation / reward rows, per-env arrays: a shard that
-    // fills its rows is one contiguous block for the exchange step) - and 256 B MORE per field row of the state slab: at a power-of-two
-    // distance the ~46 rows a wave loads at one lane offset all fall into the same L2 channel (the channel is picked from address bits
-    // 8 and up) and queue behind each other; an odd multiple of 256 B walks them round the channels.  K = 1 launch, same box: 6.36 ->
-    // 6.13 us at 65 536 spacecraft, 8.44 -> 8.26 at 131 072, no change where the slab streams from HBM (4 Mi); 512 B buys a third of
-    // it, 4 KB nothing (profiles/r05/stride_pad.txt).
+    // fills its rows is one contiguous block for the exchange step) - and 256 B MORE per field row of the state slab.  Measured, not
+    // derived: with the slab's rows at a power-of-two distance the K = 1 launch of 65 536 spacecraft takes 6.33 - 6.38 us wall per
+    // launch, with an odd multiple of 256 B between them 6.20 - 6.22 (same-box sweep and three boxes' plain lines; 512 B buys a third
+    // of it, 4 KB nothing; no change at 131 072, at 4 Mi or at K = 1 800: profiles/r05/stride_pad.txt).  A micro-benchmark of the bare
+    // access pattern does NOT reproduce it (tools/micro/row_channels.hip: there the power-of-two stride is the fastest), with or
+    // without the launch's other per-env arrays beside the slab), so "all of a wave's rows queue in one L2 channel" is not the
+    // explanation; the mechanism is not established, the effect is (ten alternations on one box: 6.39 -> 6.22 us, stride_pad_ab.txt).
     h->ostride = ((int64_t)n_envs + 255) / 256 * 256;
     h->stride = h->ostride + 32;
     if (const char* sp = std::getenv("BSKGPU_STRIDE_PAD")) {   // measurement override: the slab's extra elements per row (multiples of 32)

@@ -69,8 +69,8 @@ bounds the kernel's true average from above; `bench.py` nevertheless keeps its c
 launch, median trace over the boxes) - so the headline is priced on %.2f us = %.3f of 8 TB/s where its own launches average <= %.2f us (%.3f).
 The fp64-bound keys agree with round 4 within 1 %%.
 
-**The slab's padding** (the round's one change to the K = 1 launch: 256 B more per field row, so that the ~46 rows a wave loads do not share one
-L2 channel): same-box un-profiled sweep `stride_pad.txt` 6.33 - 6.38 -> 6.21 us wall per launch (6.36 -> 6.13 with every row of the handle padded; 512 B a
+**The slab's padding** (the round's one change to the K = 1 launch: 256 B more per field row; measured, the mechanism not established - the
+micro-benchmark of the bare access pattern, `row_channels.txt`, is FASTEST at the power-of-two stride, so it is not "46 rows in one L2 channel"): same-box un-profiled sweep `stride_pad.txt` 6.33 - 6.38 -> 6.21 us wall per launch (6.36 -> 6.13 with every row of the handle padded; 512 B a
 third of it, 4 KB nothing); the three boxes' plain lines 6.33 - 6.36 (previous pass) -> 6.19 - 6.23; nothing at 131 072, 4 Mi or K = 1 800.  The tracer
 does not resolve it (`trace_modes.txt`).
 
