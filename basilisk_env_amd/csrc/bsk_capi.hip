@@ -774,9 +774,9 @@ int bsk_create(const bsk_config* cfg, int n_envs, int device_id, void* stream, b
     // explanation; the mechanism is not established, the effect is (ten alternations on one box: 6.39 -> 6.22 us, stride_pad_ab.txt).
     h->ostride = ((int64_t)n_envs + 255) / 256 * 256;
     h->stride = h->ostride + 32;
-    if (const char* sp = std::getenv("BSKGPU_STRIDE_PAD")) {   // measurement override: the slab's extra elements per row (multiples of 32)
+    if (const char* sp = std::getenv("BSKGPU_STRIDE_PAD")) {   // measurement override: the slab's extra elements per row (multiples of 16)
         const int v = std::atoi(sp);
-        if (v >= 0 && v % 32 == 0) h->stride = h->ostride + v;
+        if (v >= 0 && v % 16 == 0) h->stride = h->ostride + v;
     }
     // 64-lane workgroups spread a small batch over more CUs (65 536 envs = 1 024 waves = 4 per CU);
     // large batches use 256 so the dispatcher has fewer workgroups to place.
