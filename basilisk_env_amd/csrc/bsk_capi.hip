@@ -773,10 +773,14 @@ int bsk_create(const bsk_config* cfg, int n_envs, int device_id, void* stream, b
     // without the launch's other per-env arrays beside the slab), so "all of a wave's rows queue in one L2 channel" is not the
     // explanation; the mechanism is not established, the effect is (ten alternations on one box: 6.39 -> 6.22 us, stride_pad_ab.txt).
     h->ostride = ((int64_t)n_envs + 255) / 256 * 256;
-    h->stride = h->ostride + 32;
+    if (const char* sp = std::getenv("BSKGPU_OSTRIDE_PAD")) {  // measurement override: extra elements per observation / reward row too
+        const int v = std::atoi(sp);
+        if (v > 0 && v % 16 == 0) h->ostride += v;
+    }
+    h->stride = ((int64_t)n_envs + 255) / 256 * 256 + 32;
     if (const char* sp = std::getenv("BSKGPU_STRIDE_PAD")) {   // measurement override: the slab's extra elements per row (multiples of 16)
         const int v = std::atoi(sp);
-        if (v >= 0 && v % 16 == 0) h->stride = h->ostride + v;
+        if (v >= 0 && v % 16 == 0) h->stride = ((int64_t)n_envs + 255) / 256 * 256 + v;
     }
     // 64-lane workgroups spread a small batch over more CUs (65 536 envs = 1 024 waves = 4 per CU);
     // large batches use 256 so the dispatcher has fewer workgroups to place.
