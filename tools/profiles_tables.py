@@ -146,6 +146,7 @@ step (two of the policy's, one step kernel), the library's own counters 0 copies
 | `sh_three_waves.txt` | a third wave per SIMD for config 5 (168-VGPR build, RK4 state parked around the walks) | 3.99 ns per spacecraft against 3.86 / 3.88 with two waves: not built |
 | `stats_forms.txt` | single-launch forms of the batch-scalars reduction (fences; write-through + ticket), an atomic done counter | 24 - 236 us, 7.6 - 99 us, 28 us when every env is done: two launches with per-workgroup partials shipped |
 | `../stride_pad.txt` (end) | the observation / reward rows padded like the slab's | at most 1 %% on the K = 1 launch, costs the contiguity of everything a consumer sees: not adopted |
+| `buffer_io.txt` | the slab through buffer instructions (32-bit scalar row offsets: 48 fewer scalar, 75 fewer instructions in the K = 1 kernel) | 6.18 - 6.21 against 6.20 - 6.21 us: the launch is not bound by its wave's instruction count |
 | `rollout_fsw_lds.txt` | rollout kernel: FSW constants in LDS for the launch + an explicit wait in the restart branch (so that no load queues behind the history stores), with and without a one-wave register budget; a K = 1 body of its own | 1.95 / 1.68 us per env step against 1.58, the K = 1 body 1.81 (1.56 without history): the loop does not wait for memory or for its branches (counters in the file) |
 """ % (ro["65536"]["constant_action"]["us_per_env_step"], ro["65536"]["constant_action"]["env_steps_per_s"], ro["65536"]["device_actions"]["us_per_env_step"],
        ro["4194304"]["constant_action"]["us_per_env_step"], ro["4194304"]["constant_action"]["env_steps_per_s"],
