@@ -43,6 +43,34 @@ __global__ void k_stream(const double* __restrict__ in, double* __restrict__ out
     out[(size_t)21 * stride + i] = s[1];
 }
 
+// the same with 1 280 bytes of constants every wave needs before its first load (as the step kernel's HotCfg / pointers): by value in the
+// kernarg segment - a fresh location per launch, written by the host - against a pointer to a block that stays put in device memory
+struct BigArgs {
+    const double* in;
+    double* out;
+    int stride;
+    double c[157];
+};
+__device__ __forceinline__ void stream_body(const BigArgs& a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double k = 0.0;
+#pragma unroll
+    for (int j = 0; j < 157; j += 13) k += a.c[j];          // (the constants are used: spread over the whole block)
+    double s[20];
+#pragma unroll
+    for (int f = 0; f < 20; ++f) s[f] = a.in[(size_t)f * a.stride + i];
+#pragma unroll
+    for (int f = 0; f < 20; ++f) a.out[(size_t)f * a.stride + i] = s[f] + k;
+    a.out[(size_t)20 * a.stride + i] = s[0];
+    a.out[(size_t)21 * a.stride + i] = s[1];
+}
+__global__ void k_stream_byvalue(const BigArgs a) { stream_body(a); }
+__global__ void k_stream_indirect(const BigArgs* __restrict__ p) {
+    BigArgs a;
+    __builtin_memcpy(&a, (const __attribute__((address_space(4))) void*)(unsigned long long)p, sizeof(BigArgs));      // constant address space: scalar loads
+    stream_body(a);
+}
+
 template <class F>
 void timeit(const char* name, F launch) {
     hipEvent_t e0, e1;
@@ -95,5 +123,39 @@ int main() {
         hipExtLaunchKernelGGL(k_stream, dim3(1024), dim3(64), 0, 0, nullptr, nullptr, 0, in, out, stride);
         hipExtLaunchKernelGGL(k_stream, dim3(1024), dim3(64), 0, 0, a, b, 0, in, out, stride);
     });
+    // ... and WITHOUT stamps: wall time per launch of 4 000 back-to-back launches on the null stream (what a stepping loop pays per launch;
+    // the stamped figures above include the events' own packets)
+    auto wall = [&](const char* name, auto&& launch) {
+        double best = 1e9;
+        for (int burst = 0; burst < 5; ++burst) {
+            for (int k = 0; k < 200; ++k) launch();
+            hipDeviceSynchronize();
+            hipEvent_t a, b;
+            hipEventCreate(&a); hipEventCreate(&b);
+            hipEventRecord(a, 0);
+            for (int k = 0; k < 4000; ++k) launch();
+            hipEventRecord(b, 0);
+            hipDeviceSynchronize();
+            float ms;
+            hipEventElapsedTime(&ms, a, b);
+            best = std::min(best, (double)ms * 1e3 / 4000);
+            hipEventDestroy(a); hipEventDestroy(b);
+        }
+        printf("%-58s wall %6.2f us per launch (un-stamped, back to back)\n", name, best);
+    };
+    wall("empty 1024 x 64", [&] { hipLaunchKernelGGL(k_empty, dim3(1024), dim3(64), 0, 0); });
+    wall("empty 256 x 256", [&] { hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, 0); });
+    wall("empty + 1 280 B kernarg 1024 x 64", [&] { hipLaunchKernelGGL(k_empty_big, dim3(1024), dim3(64), 0, 0, big, out); });
+    wall("stream 20 in / 22 out doubles per lane: 1024 x 64", [&] { hipLaunchKernelGGL(k_stream, dim3(1024), dim3(64), 0, 0, in, out, stride); });
+    BigArgs ba;
+    ba.in = in; ba.out = out; ba.stride = stride;
+    for (int j = 0; j < 157; ++j) ba.c[j] = 1e-3 * j;
+    BigArgs* dba;
+    hipMalloc(&dba, sizeof(BigArgs));
+    hipMemcpy(dba, &ba, sizeof(BigArgs), hipMemcpyHostToDevice);
+    wall("stream + 1 280 B of constants by value (kernarg)", [&] { hipLaunchKernelGGL(k_stream_byvalue, dim3(1024), dim3(64), 0, 0, ba); });
+    wall("stream + the same constants behind a device pointer", [&] { hipLaunchKernelGGL(k_stream_indirect, dim3(1024), dim3(64), 0, 0, dba); });
+    wall("stream + 1 280 B of constants by value (kernarg)", [&] { hipLaunchKernelGGL(k_stream_byvalue, dim3(1024), dim3(64), 0, 0, ba); });
+    wall("stream + the same constants behind a device pointer", [&] { hipLaunchKernelGGL(k_stream_indirect, dim3(1024), dim3(64), 0, 0, dba); });
     return 0;
 }
