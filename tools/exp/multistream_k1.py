@@ -2,7 +2,8 @@
 """Experiment: one batch of 65 536 spacecraft stepped (K = 1) as 1 / 2 / 4 / 8 concurrent launches on as many streams of ONE
 card (ShardedPropagator(devices=[0]*s)).  The K = 1 launch is a latency chain (launch, loads, 0.9 us of arithmetic, stores,
 release); independent chains on separate hardware queues can overlap.  Wall time per env step of the whole batch."""
-import sys, time, json
+import os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from basilisk_env_amd._lib import GRAV_PM_J2
