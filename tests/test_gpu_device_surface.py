@@ -590,6 +590,32 @@ def test_get_obs_state_is_the_two_read_backs_in_one():
     p.close()
 
 
+@pytest.mark.parametrize("n", [500, 512, 65536])
+def test_read_back_forms_agree(n):
+    """bsk_get_obs into fresh arrays, into the propagator's page-locked block (one contiguous copy when the batch fills its rows:
+    n a multiple of 256), bsk_get_obs_rowmajor (the kernel's own (N, 5) block) and bsk_get_obs_state: the same numbers."""
+    from basilisk_env_amd._lib import FLAG_OBS_ROWMAJOR
+    cfg = default_config(4, GRAV_PM_J2)
+    cfg.flags |= FLAG_OBS_ROWMAJOR
+    cfg.max_length = 2
+    p = BatchedPropagator(cfg, n)
+    p.reset(sample_ic_batch(n, 4, seed=51))
+    rng = np.random.default_rng(n)
+    for _ in range(3):
+        p.step(rng.integers(0, 3, n).astype(np.int32), 2)
+        obs, rew, done, why = p.get_obs()
+        o2, r2, d2, w2 = p.get_obs(copy=False)
+        assert np.array_equal(obs, o2) and np.array_equal(rew, r2) and np.array_equal(done, d2) and np.array_equal(why, w2)
+        o3, r3, d3, w3 = p.get_obs_rowmajor()
+        assert np.array_equal(obs.T, o3) and np.array_equal(rew, r3) and np.array_equal(done, d3) and np.array_equal(why, w3)
+        o4, st = p.get_obs_state()
+        assert np.array_equal(obs, o4) and np.array_equal(st, p.get_state())
+    assert done.any()
+    q = BatchedPropagator(default_config(4, GRAV_PM_J2), 64)
+    assert q.get_obs_rowmajor() is None                     # (no row-major block without the flag)
+    p.close(); q.close()
+
+
 def test_fp64_calibration_reports_a_plausible_sustained_rate():
     """bsk_calibrate_fp64: independent v_fma_f64 chains; two waves per SIMD issue faster than one, and neither exceeds
     the nominal 78.6 TFLOP/s of the part."""
