@@ -69,9 +69,24 @@ __global__ __launch_bounds__(256) void stats_kernel(const double* __restrict__ r
 // 1 024 threads: the first 256 own the reward chains (their order is the documented one and cannot be cut), the other 768 count the
 // done bits - integers, any order - beside them, so that the second stream costs the launch no time of its own (one workgroup is
 // latency-bound: at 4 Mi spacecraft the masks are another 512 KB).
+//
+// `seal`: a reset entry point snapshots the last step's scalars and then zeroes the restarted envs' rewards; on a handle whose launches
+// live in a HIP graph the host cannot know whether a step has run since, so the device decides: seal_kernel records env 0's counter
+// word and episode number behind the reset, every step launch changes one of the two (the step kernel stores cnt[0] on every launch; an
+// in-kernel auto-reset zeroes it and increments episodes[0]), and a join that finds them unchanged leaves the snapshot alone.
 constexpr int JOIN_THREADS = 1024;
+__device__ __forceinline__ bool stats_sealed(const StatsSeal& seal) {
+    if (!seal.word || seal.word[2] != 1ull) return false;
+    const unsigned long long ep = seal.episodes ? (unsigned long long)(unsigned)seal.episodes[0] : 0ull;
+    return seal.word[0] == seal.cnt0[0] && seal.word[1] == ep;
+}
+__global__ void seal_kernel(StatsSeal seal, unsigned long long* word) {
+    word[0] = seal.cnt0[0];
+    word[1] = seal.episodes ? (unsigned long long)(unsigned)seal.episodes[0] : 0ull;
+    word[2] = 1ull;
+}
 __global__ __launch_bounds__(JOIN_THREADS) void stats_join_kernel(StatsScratch sc, int n_waves, int n_parts, const unsigned long long* __restrict__ done_mask,
-                                                                  double* out_sum, long long* out_done, double* out2) {
+                                                                  double* out_sum, long long* out_done, double* out2, const StatsSeal seal) {
     __shared__ double sr[256];
     __shared__ long long sd[JOIN_THREADS];
     long long nd = 0;
@@ -122,7 +137,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void stats_join_kernel(StatsScratch s
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && !stats_sealed(seal)) {
         *out_sum = sr[0];
         *out_done = sd[0];
         out2[0] = sr[0]; out2[1] = (double)sd[0];      // {sum reward, #done} as two doubles: one all-reduce operand
@@ -262,17 +277,23 @@ hipError_t launch_init_outputs(const double* st, int64_t stride, const int* idx,
     return hipGetLastError();
 }
 
+hipError_t launch_seal(const StatsSeal& seal, hipStream_t s) {
+    hipLaunchKernelGGL(seal_kernel, dim3(1), dim3(1), 0, s, seal, const_cast<unsigned long long*>(seal.word));
+    return hipGetLastError();
+}
+
 hipError_t launch_stats(const double* reward, int n, const unsigned long long* done_mask, int n_waves, double* wsum,
-                        unsigned* done_part, double* out_sum, long long* out_done, double* out2, bool have_wave_sums, hipStream_t s) {
+                        unsigned* done_part, double* out_sum, long long* out_done, double* out2, bool have_wave_sums, const StatsSeal& seal,
+                        hipStream_t s) {
     if (have_wave_sums) {     // the step kernel wrote wave_sum[] itself: the second level alone
-        hipLaunchKernelGGL(stats_join_kernel, dim3(1), dim3(JOIN_THREADS), 0, s, StatsScratch{wsum, done_part}, n_waves, 0, done_mask, out_sum, out_done, out2);
+        hipLaunchKernelGGL(stats_join_kernel, dim3(1), dim3(JOIN_THREADS), 0, s, StatsScratch{wsum, done_part}, n_waves, 0, done_mask, out_sum, out_done, out2, seal);
         return hipGetLastError();
     }
     // one 256-thread workgroup per four waves of rewards, at most STATS_MAX_GRID of them
     const int grid = std::max(1, std::min((n_waves + 3) / 4, STATS_MAX_GRID));
     hipLaunchKernelGGL(stats_kernel, dim3(grid), dim3(256), 0, s, reward, n, done_mask, n_waves, StatsScratch{wsum, done_part});
     hipLaunchKernelGGL(stats_join_kernel, dim3(1), dim3(JOIN_THREADS), 0, s, StatsScratch{wsum, done_part}, n_waves, grid, (const unsigned long long*)nullptr,
-                       out_sum, out_done, out2);
+                       out_sum, out_done, out2, seal);
     return hipGetLastError();
 }
 

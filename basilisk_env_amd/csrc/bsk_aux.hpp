@@ -25,10 +25,19 @@ hipError_t launch_reset_from_pool(double* st, int64_t stride, int nf, const doub
 // first observation [|sigma_BN|, |omega|, |Omega|/limit, charge/3600/power_max, 1], zero reward / reason / done / episode
 // return of freshly reset envs: all n (idx == NULL) or the m listed ones
 hipError_t launch_init_outputs(const double* st, int64_t stride, const int* idx, int m, const ResetOut& ro, hipStream_t s);
+// "no step since the last reset entry point" as the device sees it (bsk_aux.hip: stats_sealed): env 0's counter word and episode
+// number as seal_kernel recorded them behind the reset, compared by the join kernel before it stores
+struct StatsSeal {
+    const unsigned long long* cnt0;     // the handle's counters (env 0's {steps | phase << 20, ticks} word first)
+    const int* episodes;                // [n] or NULL (no IC pool staged)
+    const unsigned long long* word;     // [3] {cnt0, episodes[0], 1} at the seal; NULL: never sealed
+};
+hipError_t launch_seal(const StatsSeal& seal, hipStream_t s);
 // batch scalars of the last step (stats_kernel + stats_join_kernel): scratch wave_sum f64[n_waves], done_part u32[stats_done_parts()];
 // have_wave_sums: the step kernel filled wave_sum[] (StepBuffers::wave_sum) - the join kernel alone
 hipError_t launch_stats(const double* reward, int n, const unsigned long long* done_mask, int n_waves, double* wsum,
-                        unsigned* done_part, double* out_sum, long long* out_done, double* out2, bool have_wave_sums, hipStream_t s);
+                        unsigned* done_part, double* out_sum, long long* out_done, double* out2, bool have_wave_sums, const StatsSeal& seal,
+                        hipStream_t s);
 hipError_t launch_scatter_reset(double* st, int64_t stride, int nf, const double* ic, const int* idx, int m, int2* cnt,
                                 hipStream_t s);
 

@@ -433,6 +433,7 @@ struct bsk_handle {
     unsigned char* d_done = nullptr;
     double* d_obs_rm = nullptr;
     unsigned long long* d_dbg = nullptr;   // one word per wave for probe builds (bsk_probes.hpp)
+    unsigned long long* d_seal = nullptr;   // [3] what env 0's counters were behind the last reset entry point (bsk_aux.hip: stats_sealed)
     double* d_stats2 = nullptr;   // {sum of rewards, number of done envs} of the last step, as two doubles (all-reduce operand)
     bool stats_fresh = false;     // d_stat_sum / d_stat_done / d_stats2 hold the LAST STEP's batch scalars (snapshot_stats)
     bool step_stats = false;      // bsk_set_step_stats: step launches write d_wave_sum themselves (a request = the join kernel alone)
@@ -535,11 +536,27 @@ static bool note_capture(bsk_handle* h) {
     return h->replayable;
 }
 
+static bsk::StatsSeal stats_seal(const bsk_handle* h) {
+    return bsk::StatsSeal{(const unsigned long long*)h->d_cnt, h->d_episodes, h->d_seal};
+}
+
 static int snapshot_stats(bsk_handle* h) {
-    if (h->stats_fresh && !note_capture(h)) return BSK_OK;
+    const bool replayable = note_capture(h);
+    if (h->stats_fresh && !replayable) return BSK_OK;
+    // (a request that is itself being captured must not freeze "the last launch wrote the wave sums" into the graph: a replay may
+    // follow steps that did not - the two-level form whenever the handle is replayable)
     HIP_TRY(bsk::launch_stats(h->d_reward, h->n, h->d_done_mask, (h->n + 63) / 64, h->d_wave_sum, h->d_done_part,
-                              h->d_stat_sum, h->d_stat_done, h->d_stats2, h->wave_sums_fresh, h->stream));
+                              h->d_stat_sum, h->d_stat_done, h->d_stats2, h->wave_sums_fresh && !replayable, stats_seal(h), h->stream));
     h->stats_fresh = true;
+    return BSK_OK;
+}
+
+// A reset entry point has taken the snapshot and enqueued the kernels that zero the restarted envs' rewards: from here until the
+// next step launch the snapshot is what bsk_get_batch_stats* report, also on a handle whose launches replay from a HIP graph
+// (bsk_aux.hip: stats_sealed).
+static int seal_stats(bsk_handle* h) {
+    if (!h->stepped) return BSK_OK;
+    HIP_TRY(bsk::launch_seal(stats_seal(h), h->stream));
     return BSK_OK;
 }
 
@@ -833,6 +850,7 @@ int bsk_create(const bsk_config* cfg, int n_envs, int device_id, void* stream, b
     if (e == hipSuccess) e = alloc((void**)&h->d_stat_sum, sizeof(double));
     if (e == hipSuccess) e = alloc((void**)&h->d_stat_done, sizeof(long long));
     if (e == hipSuccess) e = alloc((void**)&h->d_stats2, 2 * sizeof(double));
+    if (e == hipSuccess) e = alloc((void**)&h->d_seal, 3 * sizeof(unsigned long long));
     if (e == hipSuccess) e = alloc((void**)&h->d_wave_sum, (size_t)(S / 64) * sizeof(double));
     if (e == hipSuccess) e = alloc((void**)&h->d_done_part, (size_t)bsk::stats_done_parts() * sizeof(unsigned));
     if (e == hipSuccess) e = alloc((void**)&h->d_dbg, (size_t)(S / 64) * sizeof(unsigned long long));
@@ -868,7 +886,7 @@ void bsk_destroy(bsk_handle* h) {
         if (ev) (void)hipEventDestroy(ev);
     void* bufs[] = {h->d_state, h->d_cnt, h->d_act, h->d_obs /* + d_reward: one block */, h->d_done_mask, h->d_reason,
                     h->d_stat_sum, h->d_stat_done, h->d_ic_stage, h->d_idx_stage, h->d_mask_stage, h->d_cold, h->d_sh_tab, h->d_sh_tab4, h->d_pool, h->d_term_obs, h->d_episodes,
-                    h->d_ep_return, h->d_term_return, h->d_term_len, h->d_done, h->d_obs_rm, h->d_stats2, h->d_dbg, h->d_wave_sum, h->d_done_part};
+                    h->d_ep_return, h->d_term_return, h->d_term_len, h->d_done, h->d_obs_rm, h->d_stats2, h->d_dbg, h->d_wave_sum, h->d_done_part, h->d_seal};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (h->h_err) (void)hipHostFree(h->h_err);
@@ -930,6 +948,7 @@ int bsk_reset(bsk_handle* h, const uint8_t* mask, const double* ic) {
                                  hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipMemsetAsync(h->d_cnt, 0, (size_t)h->ostride * sizeof(int2), h->stream));
         HIP_TRY(bsk::launch_init_outputs(h->d_state, h->stride, nullptr, h->n, reset_out(h), h->stream));
+        { int rc = seal_stats(h); if (rc) return rc; }
         HIP_SYNC(hipStreamSynchronize(h->stream));
         return BSK_OK;
     }
@@ -947,6 +966,7 @@ int bsk_reset(bsk_handle* h, const uint8_t* mask, const double* ic) {
     HIP_COPY(hipMemcpyAsync(h->d_idx_stage, idx.data(), m * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(bsk::launch_scatter_reset(h->d_state, h->stride, h->nf, h->d_ic_stage, h->d_idx_stage, (int)m, h->d_cnt, h->stream));
     HIP_TRY(bsk::launch_init_outputs(h->d_state, h->stride, h->d_idx_stage, (int)m, reset_out(h), h->stream));
+    { int rc = seal_stats(h); if (rc) return rc; }
     HIP_SYNC(hipStreamSynchronize(h->stream));
     return BSK_OK;
 }
@@ -1212,6 +1232,7 @@ int bsk_reset_from_pool(bsk_handle* h, const uint8_t* mask) {
     HIP_TRY(bsk::launch_reset_from_pool(h->d_state, h->stride, h->nf, h->d_pool, h->n_pool, d_mask, h->n, h->d_cnt,
                                         h->d_episodes, h->env_base, reset_out(h), h->stream));
     h->charge_pos = (mask ? h->charge_pos : true) && h->pool_charge_pos;
+    { int rc = seal_stats(h); if (rc) return rc; }
     HIP_SYNC(hipStreamSynchronize(h->stream));
     return BSK_OK;
 }
@@ -1224,6 +1245,7 @@ int bsk_reset_from_pool_device(bsk_handle* h, const uint8_t* d_mask) {
     HIP_TRY(bsk::launch_reset_from_pool(h->d_state, h->stride, h->nf, h->d_pool, h->n_pool, d_mask, h->n, h->d_cnt,
                                         h->d_episodes, h->env_base, reset_out(h), h->stream));
     h->charge_pos = (d_mask ? h->charge_pos : true) && h->pool_charge_pos;
+    { int rc = seal_stats(h); if (rc) return rc; }
     return BSK_OK;       // asynchronous on the handle's stream: no host data, no copy, no synchronisation
 }
 

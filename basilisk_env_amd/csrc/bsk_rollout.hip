@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256, 2) void rollout_kernel(const RolloutArgs<NRW, 
     const int gid = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const int n = ta.n;
     const bool valid = gid < n;
-    const int i = valid ? gid : n - 1;    // tail lanes shadow the last env (identical inputs, identical results, identical stores)
+    const int i = valid ? gid : n - 1;    // tail lanes shadow the last env in registers (identical inputs, identical results); every global store is predicated on `valid`
     const int64_t S = ta.stride;
     const int64_t SO = ta.ostride;
     gptr<double> so = uniform_ptr(ta.st);
@@ -112,7 +112,8 @@ __global__ __launch_bounds__(256, 2) void rollout_kernel(const RolloutArgs<NRW, 
     auto pack_block = [&]() __attribute__((always_inline)) {
         unsigned w = 0;
 #pragma unroll
-        for (int k = 0; k < ACT_BLOCK; ++k) w |= ((unsigned)act_raw[k] & 15u) << (4 * k);
+        // (four bits each; anything outside 0..14 becomes 15, which no mode test matches - what step_kernel makes of the raw integer)
+        for (int k = 0; k < ACT_BLOCK; ++k) w |= ((unsigned)act_raw[k] > 14u ? 15u : (unsigned)act_raw[k]) << (4 * k);
         return w;
     };
     if constexpr (ACT) { fetch_block(0); act_cur = pack_block(); }
@@ -218,8 +219,10 @@ __global__ __launch_bounds__(256, 2) void rollout_kernel(const RolloutArgs<NRW, 
         if (ta.ep_return) {
             ep_ret += rew;
             if (why != 0) {
-                stf(uniform_ptr(ta.term_return), bo, ep_ret);
-                ta.term_len[i] = steps0;
+                if (valid) {
+                    stf(uniform_ptr(ta.term_return), bo, ep_ret);
+                    ta.term_len[i] = steps0;
+                }
                 if (n_pool > 0) ep_ret = 0.0;
             }
         }
@@ -228,14 +231,16 @@ __global__ __launch_bounds__(256, 2) void rollout_kernel(const RolloutArgs<NRW, 
             // device-side restart (rare, divergent): the finished episode's observation is kept as terminal observation, the env
             // continues from pool slot ((env_base + env) 2654435761 + episode 40503 + 12345) mod 2^32 mod n_pool - in the slab (every
             // field, as step_kernel writes it) AND in this lane's registers
+            // (shadow lanes of the tail follow env n-1 in registers only: every global store of the restart is its own lane's)
             gptr<double> tob = uniform_ptr(ta.term_obs);
-            stf(tob + 0 * SO, bo, o0); stf(tob + 1 * SO, bo, o1); stf(tob + 2 * SO, bo, o2); stf(tob + 3 * SO, bo, o3); stf(tob + 4 * SO, bo, o4);
+            if (valid) { stf(tob + 0 * SO, bo, o0); stf(tob + 1 * SO, bo, o1); stf(tob + 2 * SO, bo, o2); stf(tob + 3 * SO, bo, o3); stf(tob + 4 * SO, bo, o4); }
             const unsigned slot = (((unsigned)i + ta.env_base) * 2654435761u + (unsigned)ep * 40503u + 12345u) % (unsigned)n_pool;
             ep += 1;
             if (valid) ta.episodes[i] = ep;
             const double* __restrict__ pool = ta.pool;
             const int nf = ta.n_fields;
-            for (int f = 0; f < nf; ++f) stf(FLD(f), bo, pool[(int64_t)f * n_pool + slot]);
+            if (valid)
+                for (int f = 0; f < nf; ++f) stf(FLD(f), bo, pool[(int64_t)f * n_pool + slot]);
             auto pl = [&](int f) { return pool[(int64_t)f * n_pool + slot]; };
             x.r = mk(pl(BSK_F_R + 0), pl(BSK_F_R + 1), pl(BSK_F_R + 2));
             x.v = mk(pl(BSK_F_V + 0), pl(BSK_F_V + 1), pl(BSK_F_V + 2));
@@ -263,12 +268,12 @@ __global__ __launch_bounds__(256, 2) void rollout_kernel(const RolloutArgs<NRW, 
         }
         // ---- this step's row of the history: 49 bytes per spacecraft
         const int64_t row = (int64_t)es * hist_n + i;
-        if (a.obs_hist) {
+        if (valid && a.obs_hist) {
             double* __restrict__ oh = a.obs_hist + (int64_t)es * 5 * hist_n + i;
             oh[0] = o0; oh[(int64_t)hist_n] = o1; oh[2 * (int64_t)hist_n] = o2; oh[3 * (int64_t)hist_n] = o3; oh[4 * (int64_t)hist_n] = o4;
         }
-        if (a.reward_hist) a.reward_hist[row] = rew;
-        if (a.reason_hist) a.reason_hist[row] = (unsigned char)why;
+        if (valid && a.reward_hist) a.reward_hist[row] = rew;
+        if (valid && a.reason_hist) a.reason_hist[row] = (unsigned char)why;
       }
       if constexpr (ACT) act_cur = pack_block();
     }
@@ -276,6 +281,7 @@ __global__ __launch_bounds__(256, 2) void rollout_kernel(const RolloutArgs<NRW, 
     // ---- the launch's results, where step_kernel leaves them: the last step's outputs, the state, the counters
     const unsigned long long dmask = __ballot(valid && why != 0);
     if ((threadIdx.x & 63) == 0) ta.done_mask[gid >> 6] = dmask;
+    if (!valid) return;      // (after the ballot: tail lanes shadowed env n-1 in registers; its own lane stores)
     gptr<double> ob = uniform_ptr(ta.obs);
     stf(ob + 0 * SO, bo, o0); stf(ob + 1 * SO, bo, o1); stf(ob + 2 * SO, bo, o2); stf(ob + 3 * SO, bo, o3); stf(ob + 4 * SO, bo, o4);
     if (ta.obs_rm) {

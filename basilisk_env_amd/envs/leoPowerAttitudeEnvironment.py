@@ -170,12 +170,23 @@ class leoPowerAttEnv(spaces.Env):
 
 
 
-def demo(episodes=2, action=0, seed=12345, plot=False):
+def make_env(**kwargs):
+    """The environment the way the reference's main obtains it (:219): ``gym.make('leo_power_att_env-v0')`` through the id this
+    package registers when gym imports; the class itself where gym is absent."""
+    if spaces.HAVE_GYM:
+        import gym
+
+        from .. import ENV_ID
+        return gym.make(ENV_ID, **kwargs)
+    return leoPowerAttEnv(**kwargs)
+
+
+def demo(episodes=2, action=0, seed=12345, plot=False, env_kwargs=None):
     """What the reference module does when run as a script (:218-244): roll whole episodes with one fixed
     action and keep the observation history.  Returns the per-episode histories (5, steps); prints one
     line per episode; ``plot=True`` draws them if matplotlib is available."""
     names = ("attitude error", "body rate", "wheel speed / limit", "battery / capacity", "sunlit fraction")
-    env = leoPowerAttEnv()
+    env = make_env(**(env_kwargs or {}))
     histories = []
     for ep in range(episodes):
         env.reset()

@@ -74,6 +74,103 @@ def parse(argv=None):
 
 
 # ---------------------------------------------------------------------------------------------
+# The ONE line the driver reads is the LAST line of stdout and stays small (the driver keeps a bounded tail of stdout: round 5's
+# 20.9 KB line did not parse).  Everything else of the run - the other measurement points, sample statistics, prose - goes to
+# bench_extra.json beside this file and to an EARLIER stdout line prefixed "EXTRA ".
+HEADLINE_LIMIT = 4096
+EXTRA_PREFIX = "EXTRA "
+EXTRA_FILE = "bench_extra.json"
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "kernel", "kernel_us", "algorithmic_bytes", "traffic", "traffic_source",
+                 "working_set_bytes", "frac_of_copy_ceiling", "flop_per_launch")
+
+
+def _sig(x, digits=6):
+    """Floats of the headline at ``digits`` significant figures (the full-precision record is the EXTRA line)."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    return float("%.*g" % (digits, x))
+
+
+def _pick(d, keys, keep_null=("traffic",)):
+    return {k: _sig(d[k]) for k in keys if k in d and (d[k] is not None or k in keep_null)}
+
+
+def headline(out):
+    """-> dict: the contract keys + ``roofline`` reduced to what a reader recomputes from + ``cpu_baseline`` + (ranks > 1) the
+    rank / device / communicator counts and the exchange timings; ``json.dumps`` of it is < HEADLINE_LIMIT bytes by
+    construction (tests/test_bench_host.py::test_headline_line_is_small)."""
+    cfg = out.get("config", {})
+    h = {k: _sig(out[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                   "vs_baseline", "dtype", "data") if k in out}
+    h["config"] = {"workload": str(cfg.get("workload", ""))[:200]}
+    for k in ("envs_per_gpu", "substeps", "scenario", "batch_stats", "sharding", "kernel_fingerprint"):
+        if cfg.get(k) is not None:
+            h["config"][k] = cfg[k]
+    for k in ("value_with_join", "rk4_substeps_per_s"):
+        if out.get(k) is not None:
+            h[k] = _sig(out[k])
+    if "roofline" in out:
+        h["roofline"] = _pick(out["roofline"], ROOFLINE_KEYS)
+    cb = out.get("cpu_baseline")
+    if cb:
+        h["cpu_baseline"] = {k: _sig(cb[k]) for k in ("value", "unit", "cores", "kind") if k in cb}
+        h["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
+        if cb.get("single_thread"):
+            h["cpu_baseline"]["single_thread"] = {"value": _sig(cb["single_thread"]["value"])}
+    ex = out.get("extra", {})
+    if out.get("small_batch_crossover_n") is not None:
+        h["small_batch_crossover_n"] = out["small_batch_crossover_n"]
+    if out.get("n_gpus", 1) > 1 or "gather" in out:
+        if "ranks" in out:
+            h["ranks"] = len(out["ranks"])
+            h["distinct_devices"] = out.get("distinct_devices")
+        g = out.get("gather", {})
+        keep = {"gather_to_rank0_ms": "torch_gather_ms", "all_gather_ms": "torch_all_gather_ms", "direct_rccl_gather7_to_rank0_ms": "direct_7row_ms",
+                "direct_rccl_gather7_rank_major_ms": "direct_rank_major_ms", "all_reduce_stats_ms": "all_reduce_stats_ms",
+                "nccl_comm_count": "nccl_comm_count", "direct_rccl": "direct_rccl", "direct_rccl_error": "direct_rccl_error"}
+        hg = {v: (_sig(g[k]) if not isinstance(g[k], str) else g[k][:120]) for k, v in keep.items() if k in g}
+        if hg:
+            h["gather"] = hg
+        if "gather_ms" in out:
+            h["gather_ms"] = _sig(out["gather_ms"])
+        st = ex.get("strong_65536_total")
+        if st:
+            h["strong_65536_total"] = {"envs_per_gpu": st.get("envs_per_gpu"), "k1_env_steps_per_s": _sig(st.get("k1_env_steps_per_s")),
+                                       "full_k1800_env_steps_per_s": _sig(st.get("full_k1800_env_steps_per_s"))}
+        c3 = ex.get("config3")
+        if c3:
+            h["config3_env_steps_per_s"] = _sig(c3.get("env_steps_per_s"))
+    h["extra"] = EXTRA_FILE + " / the 'EXTRA ' line above"
+    return h
+
+
+def headline_line(out):
+    """The compact line as text; if a future key ever pushes it over the limit the optional parts go first, never the contract keys."""
+    h = headline(out)
+    line = json.dumps(h)
+    for k in ("gather", "strong_65536_total", "small_batch_crossover_n", "rk4_substeps_per_s", "extra"):
+        if len(line) < HEADLINE_LIMIT:
+            break
+        h.pop(k, None)
+        line = json.dumps(h)
+    return line
+
+
+def emit(out, stream=None, extra_path=None):
+    """Rank 0's output: bench_extra.json + the EXTRA line (the whole record), then - LAST - the compact line."""
+    stream = stream or sys.stdout
+    full = json.dumps(out)
+    try:
+        with open(extra_path or os.environ.get("BENCH_EXTRA_FILE") or os.path.join(ROOT, EXTRA_FILE), "w") as f:
+            f.write(full + "\n")
+    except OSError as e:          # a read-only tree must not cost the line
+        sys.stderr.write("bench: could not write %s: %r\n" % (EXTRA_FILE, e))
+    stream.write(EXTRA_PREFIX + full + "\n")
+    stream.write(headline_line(out) + "\n")
+    stream.flush()
+
+
+# ---------------------------------------------------------------------------------------------
 # N > 1 as typed: spawn the launcher as a child.  Nothing above or in here imports torch or touches HIP, so the
 # parent never initialises the GPU (a process that has must not exec or be replaced; it may start children).
 def _free_port():
@@ -91,7 +188,7 @@ def launcher_command(gpus, argv, port):
 
 def self_launch(gpus, argv, popen=subprocess.Popen, out=None, err=None):
     """Run ``bench.py argv`` on ``gpus`` ranks in a child ``torch.distributed.run``; relay its stdout line by
-    line (rank 0 prints the one JSON line) and return its exit code."""
+    line (rank 0 prints the EXTRA line and, last, the one compact JSON line) and return its exit code."""
     out = out or sys.stdout
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
@@ -100,23 +197,32 @@ def self_launch(gpus, argv, popen=subprocess.Popen, out=None, err=None):
     for line in proc.stdout:
         # the bench line goes to stdout; whatever else the ranks or their libraries print there (gloo / RCCL
         # banners) is passed on through stderr, so that stdout carries exactly the one JSON line
-        dst = out if line.lstrip().startswith("{") else (err or sys.stderr)
+        dst = out if line.lstrip().startswith(("{", EXTRA_PREFIX)) else (err or sys.stderr)
         dst.write(line)
         dst.flush()
     return proc.wait()
 
 
 # ---------------------------------------------------------------------------------------------
-def timed_run(prop, d_act_ptr, substeps, steps, warmup, barrier, device_sync):
-    """Wall time of exactly ``steps`` un-stamped launches between two barrier + device synchronisations."""
+def timed_run(prop, d_act_ptr, substeps, steps, warmup, barrier, device_sync, join=False):
+    """Wall time of exactly ``steps`` un-stamped launches between two barrier + device synchronisations.  ``join``: every step is
+    followed by bsk_get_batch_stats_device (the batch's sum of rewards / number of done envs joined on the device, no
+    synchronisation): ``value_with_join``."""
     for _ in range(warmup):
         prop.step_device(d_act_ptr, substeps)
+        if join:
+            prop.batch_stats_device()
     prop.sync()
     barrier()
     device_sync()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        prop.step_device(d_act_ptr, substeps)
+    if join:
+        for _ in range(steps):
+            prop.step_device(d_act_ptr, substeps)
+            prop.batch_stats_device()
+    else:
+        for _ in range(steps):
+            prop.step_device(d_act_ptr, substeps)
     device_sync()
     t1 = time.perf_counter()   # this rank's K steps are done; the MAX over ranks is taken by the caller
     barrier()
@@ -499,7 +605,7 @@ def guarded_leg(out, rank, seconds, leg, exit_fn=os._exit):
     def give_up():
         out.setdefault("gather", {})["direct_rccl"] = "timeout after %g s: leg abandoned" % seconds
         if rank == 0:
-            print(json.dumps(out), flush=True)
+            emit(out)
         exit_fn(3)
 
     if os.environ.get("BENCH_FAULT_HANG_LEG") == "1":
@@ -650,6 +756,20 @@ def rollout_point(torch, cfg, n, n_rw, local, sample_ic_batch, BatchedPropagator
     out["kernel"] = p.kernel_info()
     p.close()
     return out
+
+
+def small_batch_crossover(small_batch, cpu_single):
+    """The reference's own operating point is ONE spacecraft (simulators/leoPowerAttitudeSimulator.py:213): below which batch size is
+    one host core (the oracle, single thread) the faster engine for a 180 s env step of the full scenario?  -> {"n": smallest measured
+    batch the GPU wins at, "cpu_core_ms_per_env_step": ..., "gpu_ms_per_env_step": {N: ms}} or None.  (The GPU's time is flat in N
+    down here - a launch of three waves per spacecraft costs what it costs - while the core's grows with N.)"""
+    if not small_batch or not cpu_single or "error" in small_batch or not cpu_single.get("value"):
+        return None
+    cpu_ms = 1e3 / float(cpu_single["value"])                # one core: ms per env step of one spacecraft
+    gpu = {int(k): float(v["ms_per_env_step"]) for k, v in small_batch.items() if k.isdigit()}
+    wins = sorted(nn for nn, ms in gpu.items() if ms < nn * cpu_ms)
+    return {"n": wins[0] if wins else None, "cpu_core_ms_per_env_step": cpu_ms, "gpu_ms_per_env_step": {str(k): gpu[k] for k in sorted(gpu)},
+            "rule": "smallest measured N with GPU wall time of one env step (launch + kernel + sync) < N x one core's time per env step"}
 
 
 def vecenv_episode_end(n, device_pool):
@@ -809,12 +929,22 @@ def main():
         cfg = prop.cfg
         prop.set_gravity_sh(70, *synthetic_sh_coefficients(70))
     prop.reset(ic)
+    # The wave-level reductions of the path inside the timed launch: every step launch forms the done
+    # ballot AND the per-wave reward sums (bsk_set_step_stats; measured at <= 0.06 us on the K = 1 launch); the join of the wave
+    # sums into the two batch scalars is a request of its own (bsk_get_batch_stats_device) - `value_with_join` times it after
+    # every step.
+    prop.set_step_stats(True)
     d_act = torch.zeros(n, dtype=torch.int32, device="cuda")  # action 0 = nadir pointing (reward mode)
     torch.cuda.synchronize()
     sync = torch.cuda.synchronize
 
     el_local = timed_run(prop, d_act.data_ptr(), a.substeps, a.steps, a.warmup, barrier, sync)
     el = max_over_ranks(el_local)
+    el_join = max_over_ranks(timed_run(prop, d_act.data_ptr(), a.substeps, a.steps, a.warmup, barrier, sync, join=True))
+    rsum_dev, ndone_dev = prop.batch_stats()
+    _, rew_j, _, why_j = prop.get_obs()
+    join_ok = bool(abs(rsum_dev - float(rew_j.sum())) <= 1e-9 * max(1.0, abs(float(rew_j.sum()))) and ndone_dev == int((why_j != 0).sum()))
+    assert join_ok or os.environ.get("BENCH_ALLOW_NONFINITE") == "1", "device-side batch scalars differ from the host sums of the same step"
     kernel_ms, n_launch, kstats = kernel_time(prop, d_act.data_ptr(), a.substeps, min(STAMPED_LAUNCHES, max(a.steps, 4)))
     obs, rew, done, why = prop.get_obs()
     # (BENCH_ALLOW_NONFINITE=1: timing-only ablation builds whose results are deliberately wrong)
@@ -855,14 +985,13 @@ def main():
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[%s]: %d envs/GPU, %s gravity + 4 reaction wheels (pyramid) + "
-                               "nadir-pointing reward, fp64, dt 0.1 s, %d RK4 sub-step(s) per env step, fsw every 10 "
-                               "sub-steps (reference FSW task order and priorities: fsw_lag = nav_lag = 1), synthetic random-orbit batch PCG64(rank)"
-                               % ("4" if sh else "2", n, "degree-70 spherical-harmonic (synthetic Kaula field)" if sh else "J2",
-                                  a.substeps),
+        "config": {"workload": "BASELINE configs[%s]: %d envs/GPU, %s + 4 reaction wheels (pyramid) + nadir reward, f64, dt 0.1 s, "
+                               "K=%d RK4 sub-step(s)/env step, FSW every 10 (fsw_lag=nav_lag=1), synthetic PCG64(rank)"
+                               % ("4" if sh else "2", n, "degree-70 harmonics (synthetic Kaula)" if sh else "J2", a.substeps),
                    "envs_per_gpu": n, "substeps": a.substeps, "scenario": a.scenario, "lds_scratch": bool(a.lds_scratch), "fsw_timing": a.fsw_timing, "features": a.features,
                    "sharding": "env ranges, no step-path collective", "kernel_fingerprint": fp,
-                   "batch_stats": "on demand (bsk_get_batch_stats*: stats_kernel + stats_join_kernel; a step produces the per-wave done ballot and no reward reduction unless bsk_set_step_stats asks for the per-wave sums: extra.batch_stats_us)"},
+                   "batch_stats": "per-wave sums in the step launch; join on demand"},
+        "value_with_join": n * world * a.steps / el_join, "ms_per_step_with_join": el_join / a.steps * 1e3, "join_matches_host_sum": join_ok,
         "roofline": fp64 if fp64_bound else hbm,
         "rk4_substeps_per_s": value * a.substeps,
     }
@@ -959,7 +1088,7 @@ def main():
         # scenario - launch + kernel + stream synchronisation - for 1 / 64 / 8 192 spacecraft (pair form of the kernel)
         try:
             sb = {}
-            for ns in (1, 64, 8192):
+            for ns in (1, 2, 4, 64, 8192):
                 c6 = cfg.copy()
                 c6.flags |= scenario_flags("full")
                 p6 = BatchedPropagator(c6, ns, device=local)
@@ -1072,6 +1201,10 @@ def main():
             c5 = default_config(n_rw=n_rw, gravity_model=GRAV_SH)
             c5.sh_degree = 70
             extra["sh70"]["cpu_baseline"] = cpu_baseline(c5, n_rw, 1, budget_s=5.0, n=256, sh=70)
+        cross = small_batch_crossover(extra.get("small_batch"), extra.get("full_k1800", {}).get("cpu_baseline", {}).get("single_thread"))
+        if cross:
+            extra["small_batch"]["crossover"] = cross
+            out["small_batch_crossover_n"] = cross["n"]
     hang = os.environ.get("BENCH_FAULT_HANG_LEG") == "1"
     if dist is not None and (not rehearsal or hang) and os.environ.get("BSKGPU_DIRECT_RCCL", "1") != "0":
         # last, and under a watchdog: if the direct-RCCL leg (a second communicator, never run on more than one rank
@@ -1079,7 +1212,7 @@ def main():
         guarded_leg(out, rank, float(os.environ.get("BENCH_LEG_DEADLINE_S", "90")), lambda: direct_rccl_leg(prop, dist, torch, world, clock))
     prop.close()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

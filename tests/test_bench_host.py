@@ -6,6 +6,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -102,7 +104,7 @@ def test_self_launch_composes_the_launcher_as_a_child_and_relays():
     seen = {}
 
     class FakeProc(object):
-        stdout = io.StringIO("warning line\n{\"metric\": \"m\"}\n")
+        stdout = io.StringIO("warning line\nEXTRA {\"extra\": 1}\n{\"metric\": \"m\"}\n")
 
         def wait(self):
             return 7
@@ -117,7 +119,8 @@ def test_self_launch_composes_the_launcher_as_a_child_and_relays():
         rc = b.self_launch(4, ["--gpus", "4", "--steps", "20"], popen=fake_popen, out=out, err=err)
     finally:
         del os.environ["RANK"]
-    assert rc == 7 and out.getvalue() == '{"metric": "m"}\n' and err.getvalue() == "warning line\n"
+    # (the EXTRA line - the whole record - and, LAST, the compact line the driver reads are the child's stdout; the rest is stderr)
+    assert rc == 7 and out.getvalue() == 'EXTRA {"extra": 1}\n{"metric": "m"}\n' and err.getvalue() == "warning line\n"
     cmd = seen["cmd"]
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd
     assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
@@ -185,6 +188,88 @@ def test_committed_bench_line_has_the_contract_keys():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     with open(os.path.join(ROOT, "BASELINE.json")) as f:
         assert d["metric"] == json.load(f)["metric"]
+
+
+def _canned_run(n_gpus=1):
+    """A run dict shaped like main()'s, with every optional part present and long-winded (what pushed round 5's line over)."""
+    b = _load_bench()
+    info = {"name": "step_kernel<PM_J2,4,diag>", "vgprs": 244, "lds_bytes": 0, "block": 64, "grid": 1024}
+    roof = b.hbm_roofline(65536, 7.02e-6, info, 25.9e6, "profiles/r06/summary_latest.json", 64)
+    roof.update({"kernel_us_rule": "x" * 300, "working_set": "y" * 200, "stamping": "z" * 150})
+    out = {"metric": json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"], "value": 9.1e9, "unit": "env-steps/s", "n_gpus": n_gpus,
+           "steps": 20, "warmup": 5, "ms_per_step": 0.0072, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+           "data": "synthetic", "config": {"workload": "w" * 400, "envs_per_gpu": 65536, "substeps": 1, "scenario": "bare",
+                                           "batch_stats": "per-wave sums in the step launch; join on demand",
+                                           "sharding": "env ranges, no step-path collective", "kernel_fingerprint": "0123456789abcdef"},
+           "value_with_join": 6.6e9, "rk4_substeps_per_s": 9.1e9, "roofline": roof, "small_batch_crossover_n": 2,
+           "cpu_baseline": {"value": 1.77e7, "unit": "env-steps/s", "cores": 16, "kind": "port", "sample": "s" * 300,
+                            "single_thread": {"value": 2.74e6, "unit": "env-steps/s", "cores": 1, "sample": "t" * 100}},
+           "extra": {k: {"note": "n" * 400, "roofline": dict(roof)} for k in ("k1800", "power_k1800", "full_k1800", "sh70", "large_n", "config3_per_gpu",
+                                                                            "fp64_ceiling", "small_batch", "host_buffers_k1", "batch_stats_us", "rollout",
+                                                                            "vecenv_episode_end_ms", "rl_loop")}}
+    if n_gpus > 1:
+        out["ranks"] = [{"rank": r, "hip_device": r, "name": "AMD Instinct MI355X", "pci_bus_id": "0000:%02x:00.0" % r, "uuid": "u" * 36} for r in range(n_gpus)]
+        out["distinct_devices"] = n_gpus
+        out["gather_ms"] = 0.21
+        out["gather"] = {"shard_bytes": 2621440, "gather_to_rank0_ms": 0.3, "all_gather_ms": 0.21, "direct_d2h_per_gpu_ms": 0.1,
+                         "direct_rccl_gather7_to_rank0_ms": 0.2, "direct_rccl_gather7_rank_major_ms": 0.15, "all_reduce_stats_ms": 0.03,
+                         "nccl_comm_count": n_gpus, "direct_rccl_form": "f" * 300, "bytes": {"a": 1}, "messages_on_root": {"x": 14}}
+        out["extra"]["strong_65536_total"] = {"envs_per_gpu": 65536 // n_gpus, "k1_env_steps_per_s": 5e9, "k1800_env_steps_per_s": 3e7,
+                                              "full_k1800_env_steps_per_s": 2.6e7, "full_k1800_kernel": "k" * 60}
+        out["extra"]["config3"] = {"env_steps_per_s": 1.1e11, "gather": {"all_gather_ms": 1.0}}
+    return b, out
+
+
+def test_headline_line_is_small():
+    """the LAST stdout line is a compact JSON object (< 4 096 bytes, the driver keeps a bounded tail of stdout) with
+    the contract keys, the reduced roofline and the CPU baseline; the whole record goes to an EARLIER line prefixed 'EXTRA ' and
+    to bench_extra.json."""
+    import io
+    import tempfile
+    for n_gpus in (1, 8):
+        b, out = _canned_run(n_gpus)
+        assert len(json.dumps(out)) > 20000                   # the record itself is as large as round 5's
+        line = b.headline_line(out)
+        assert len(line) < b.HEADLINE_LIMIT == 4096 and "\n" not in line
+        d = json.loads(line)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline", "cpu_baseline", "value_with_join"):
+            assert k in d, k
+        assert d["dtype"] == "f64" and d["vs_baseline"] is None and d["scaling"] == "weak" and d["n_gpus"] == n_gpus
+        assert 0 < len(d["config"]["workload"]) <= 200 and "model" not in d["config"]
+        assert d["config"]["batch_stats"] == "per-wave sums in the step launch; join on demand"
+        r = d["roofline"]
+        assert set(r) <= set(b.ROOFLINE_KEYS) and r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
+        assert abs(r["achieved"] - r["algorithmic_bytes"] / r["kernel_us"] / 1e3) < 1e-2 * r["achieved"] and r["traffic"] > r["algorithmic_bytes"]
+        c = d["cpu_baseline"]
+        assert c["kind"] == "port" and c["cores"] == 16 and c["value"] > 0 and c["single_thread"]["value"] > 0 and len(c["sample"]) <= 160
+        assert "extra" not in d or isinstance(d["extra"], str)   # the sub-reports never ride on the headline
+        if n_gpus > 1:
+            assert d["ranks"] == n_gpus == d["distinct_devices"] == d["gather"]["nccl_comm_count"] and d["gather_ms"] == 0.21
+            assert {"torch_gather_ms", "direct_7row_ms", "direct_rank_major_ms"} <= set(d["gather"])
+            assert d["strong_65536_total"]["full_k1800_env_steps_per_s"] == 2.6e7 and d["strong_65536_total"]["k1_env_steps_per_s"] == 5e9
+        # emit(): EXTRA line first, compact line LAST, the record in the file
+        buf, path = io.StringIO(), os.path.join(tempfile.mkdtemp(), "bench_extra.json")
+        b.emit(out, stream=buf, extra_path=path)
+        lines = buf.getvalue().splitlines()
+        assert len(lines) == 2 and lines[0].startswith(b.EXTRA_PREFIX) and lines[1] == line
+        assert json.loads(lines[0][len(b.EXTRA_PREFIX):]) == json.load(open(path)) == json.loads(json.dumps(out))
+    # a record with traffic unknown keeps the key (null), as the contract says
+    b, out = _canned_run(1)
+    out["roofline"]["traffic"] = None
+    assert json.loads(b.headline_line(out))["roofline"]["traffic"] is None
+
+
+def test_committed_headline_of_this_round_is_small_and_complete():
+    """The line committed under profiles/ for the driver's own command (tools/bench_lines.sh) obeys the limit."""
+    path = os.path.join(ROOT, "profiles", "r06", "bench_steps20_warmup5.json")
+    if not os.path.exists(path):
+        pytest.skip("no committed round-6 bench line yet")
+    text = open(path).read().strip().splitlines()
+    assert len(text[-1]) < 4096
+    d = json.loads(text[-1])
+    assert d["dtype"] == "f64" and d["roofline"]["bound"] == "hbm" and d["cpu_baseline"]["kind"] == "port" and d["value_with_join"] > 0
+    assert d["value"] > d["value_with_join"] and len(d["config"]["workload"]) <= 200
 
 
 def test_roofline_is_priced_on_the_more_conservative_duration(monkeypatch):
@@ -292,15 +377,20 @@ def test_a_hung_collective_leg_ends_in_status_3_with_exactly_one_json_line():
         "out = {'metric': 'm', 'value': 1.0, 'gather': {'all_gather_ms': 0.5}}",
         "b.guarded_leg(out, int(sys.argv[1]), 0.3, lambda: {'never': 'reached'})",
         "print('not reached')"])
-    env = dict(os.environ, BENCH_FAULT_HANG_LEG="1")
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    env = dict(os.environ, BENCH_FAULT_HANG_LEG="1", BENCH_EXTRA_FILE=os.path.join(tmp, "bench_extra.json"))
     for rank in (0, 1):
         res = subprocess.run([sys.executable, "-c", code, str(rank)], capture_output=True, text=True, timeout=60, env=env)
         assert res.returncode == 3, (res.returncode, res.stderr[-500:])
         lines = [l for l in res.stdout.splitlines() if l.strip()]
         if rank == 0:
-            assert len(lines) == 1, lines
-            d = json.loads(lines[0])
-            assert d["value"] == 1.0 and d["gather"]["all_gather_ms"] == 0.5 and "timeout after 0.3 s" in d["gather"]["direct_rccl"]
+            # the whole record as an EXTRA line (and in bench_extra.json), then - last - the ONE compact JSON line
+            assert len(lines) == 2 and lines[0].startswith("EXTRA {") and lines[1].startswith("{"), lines
+            full, d = json.loads(lines[0][len("EXTRA "):]), json.loads(lines[1])
+            assert full["value"] == 1.0 and full["gather"]["all_gather_ms"] == 0.5 and "timeout after 0.3 s" in full["gather"]["direct_rccl"]
+            assert d["value"] == 1.0 and d["gather"]["torch_all_gather_ms"] == 0.5 and "timeout after 0.3 s" in d["gather"]["direct_rccl"]
+            assert json.load(open(env["BENCH_EXTRA_FILE"])) == full
         else:
             assert lines == []
     # ... and a leg that returns in time is merged into the line, its byte counts beside the others', no exit

@@ -459,6 +459,90 @@ def test_in_launch_wave_sums_are_not_trusted_once_a_graph_steps_the_handle():
         p.close()
 
 
+def test_reset_then_stats_on_a_captured_handle_report_the_last_steps_sums():
+    """on a handle whose launches live in a HIP graph the host's "snapshot is fresh" flag is not trusted, so a
+    stats request used to re-form the sums from the reward buffer - AFTER a reset entry point had zeroed the restarted envs' rewards:
+    their terminal rewards and penalties dropped out.  The reset now seals the snapshot on the device (bsk_aux.hip: stats_sealed:
+    env 0's counter word + episode number, changed by every step launch) and the join kernel leaves a sealed snapshot alone:
+    step (graph) -> reset_from_pool_device(mask) -> stats = the step's sums; a further replayed step lifts the seal."""
+    import torch
+    n = 3000
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        cfg = default_config(4, GRAV_PM_J2)
+        cfg.max_length = 2
+        cfg.flags |= FLAG_AUTO_RESET
+        p = BatchedPropagator(cfg, n, stream=side.cuda_stream)
+        p.reset(sample_ic_batch(n, 4, seed=51))
+        p.set_ic_pool(sample_ic_batch(64, 4, seed=52))
+        act = torch.zeros(n, dtype=torch.int32, device="cuda")
+        for _ in range(2):
+            p.step_device(act.data_ptr(), 1)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            p.step_device(act.data_ptr(), 1)
+        graph.replay()                                      # the third step: max_length reached, every env finishes
+        torch.cuda.synchronize()
+        obs, rew, done, why = p.get_obs()
+        want_s, want_d = _stats_order(rew), int((why != 0).sum())
+        assert want_d == n and want_s > 0.0
+        mask = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        mask[::2] = 1                                        # env 0 among the restarted ones
+        p.reset_from_pool_device(mask.data_ptr())
+        torch.cuda.synchronize()
+        assert np.all(p.get_obs()[1][::2] == 0.0) and np.all(p.get_obs()[1][1::2] > 0.0)
+        assert p.batch_stats() == (want_s, want_d)           # the snapshot, not the zeroed buffer's sums
+        sp = p.batch_stats_device()                          # ... and through the device-resident entry
+        torch.cuda.synchronize()
+        assert p.batch_stats() == (want_s, want_d)
+        mask[:] = 0
+        mask[1::2] = 1                                       # env 0 NOT among them: the seal rests on its unchanged counters
+        p.reset_from_pool_device(mask.data_ptr())
+        torch.cuda.synchronize()
+        assert np.all(p.get_obs()[1] == 0.0) and p.batch_stats() == (want_s, want_d)
+        graph.replay()                                       # a step nobody told the host about lifts the seal
+        torch.cuda.synchronize()
+        obs, rew, done, why = p.get_obs()
+        s2, d2 = p.batch_stats()
+        assert s2 == _stats_order(rew) and d2 == int((why != 0).sum()) and (s2, d2) != (want_s, want_d)
+        del graph, sp
+        p.close()
+
+
+def test_a_captured_stats_request_alone_never_freezes_the_join_only_form():
+    """bsk_set_step_stats(1), an eager step (it writes the per-wave sums), then a capture that holds ONLY the stats
+    request: the join-only form must not be recorded - replays follow steps that no longer write the sums (a replayable handle
+    steps in the two-level form)."""
+    import torch
+    n = 4096 + 17
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        p = BatchedPropagator(default_config(4, GRAV_PM_J2), n, stream=side.cuda_stream)
+        p.reset(sample_ic_batch(n, 4, seed=61))
+        a0 = torch.zeros(n, dtype=torch.int32, device="cuda")
+        a1 = torch.ones(n, dtype=torch.int32, device="cuda")
+        p.set_step_stats(True)
+        p.step_device(a0.data_ptr(), 1)                     # eager, writes the wave sums
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            p.batch_stats_device()                           # the request alone
+        graph.replay()
+        torch.cuda.synchronize()
+        s0, _ = p.batch_stats()
+        assert s0 == _stats_order(p.get_obs()[1]) and s0 > 0.0
+        p.step_device(a1.data_ptr(), 1)                     # replayable handle: no in-launch sums any more; rewards all 0
+        graph.replay()
+        torch.cuda.synchronize()
+        dptr = p.batch_stats_device()
+        torch.cuda.synchronize()
+        rew = p.get_obs()[1]
+        assert np.all(rew == 0.0) and p.batch_stats()[0] == 0.0
+        del graph, dptr
+        p.close()
+
+
 def test_step_tensors_loop_is_hip_graph_capturable():
     """The device-resident loop - policy kernels + step kernel + device-side auto-reset - captured in a HIP graph and replayed
     gives exactly what the eager loop gives: step_tensors launches on the capturing stream and issues nothing a capture
