@@ -505,6 +505,19 @@ int validate(const bsk_config& c) {
     return BSK_OK;
 }
 
+// Extra elements per field row of the state slab.  An EMPIRICAL constant, not a derived one: with the slab's rows an odd multiple of
+// 256 B apart the K = 1 launch of 65 536 spacecraft is 2 - 3 % shorter than with rows at a power-of-two distance (6.20 against 6.36 us
+// wall per launch; profiles/r05/stride_pad.txt, ten alternations in stride_pad_ab.txt), a micro-benchmark of the bare access pattern
+// does not reproduce it (tools/micro/row_channels.hip) and the mechanism is not established.  Applied only over the range of batch
+// sizes it was measured to help at (profiles/r06/stride_pad.txt, one box, alternating: 65 536 -2.7 %, 98 304 -0.5 %; 32 768 and
+// 131 072 nothing either way, 4 Mi slightly slower); everywhere else the rows are N rounded up to 256 like every other per-env
+// array of the handle.
+#ifndef BSK_TUNABLES
+#define BSK_TUNABLES 0
+#endif
+constexpr int SLAB_PAD_ELEMS = 32, SLAB_PAD_MIN_ENVS = 65536, SLAB_PAD_MAX_ENVS = 98304;
+int slab_row_pad(int n_envs) { return (n_envs >= SLAB_PAD_MIN_ENVS && n_envs <= SLAB_PAD_MAX_ENVS) ? SLAB_PAD_ELEMS : 0; }
+
 int ensure_stage(bsk_handle* h, size_t m) {
     if (m <= h->stage_cap) return BSK_OK;
     if (h->d_ic_stage) (void)hipFree(h->d_ic_stage);
@@ -782,30 +795,30 @@ int bsk_create(const bsk_config* cfg, int n_envs, int device_id, void* stream, b
     h->nf = BSK_NF_BASE + cfg->n_rw + BSK_NF_TAIL;
     h->device = device_id;
     // Rows of N rounded up to 256 elements for everything a consumer sees (observation / reward rows, per-env arrays: a shard that
-    // fills its rows is one contiguous block for the exchange step) - and 256 B MORE per field row of the state slab.  Measured, not
-    // derived: with the slab's rows at a power-of-two distance the K = 1 launch of 65 536 spacecraft takes 6.33 - 6.38 us wall per
-    // launch, with an odd multiple of 256 B between them 6.20 - 6.22 (same-box sweep and three boxes' plain lines; 512 B buys a third
-    // of it, 4 KB nothing; no change at 131 072, at 4 Mi or at K = 1 800: profiles/r05/stride_pad.txt).  A micro-benchmark of the bare
-    // access pattern does NOT reproduce it (tools/micro/row_channels.hip: there the power-of-two stride is the fastest), with or
-    // without the launch's other per-env arrays beside the slab), so "all of a wave's rows queue in one L2 channel" is not the
-    // explanation; the mechanism is not established, the effect is (ten alternations on one box: 6.39 -> 6.22 us, stride_pad_ab.txt).
+    // fills its rows is one contiguous block for the exchange step); the state slab's field rows carry slab_row_pad() more.
     h->ostride = ((int64_t)n_envs + 255) / 256 * 256;
-    if (const char* sp = std::getenv("BSKGPU_OSTRIDE_PAD")) {  // measurement override: extra elements per observation / reward row too
+    h->stride = h->ostride + slab_row_pad(n_envs);
+#if BSK_TUNABLES
+    // measurement overrides, `make tunables` builds only (variants/tunables.so; the product library never reads them):
+    // extra elements per observation / reward row too; the slab's extra elements per row (multiples of 16)
+    if (const char* sp = std::getenv("BSKGPU_OSTRIDE_PAD")) {
         const int v = std::atoi(sp);
         if (v > 0 && v % 16 == 0) h->ostride += v;
     }
-    h->stride = ((int64_t)n_envs + 255) / 256 * 256 + 32;
-    if (const char* sp = std::getenv("BSKGPU_STRIDE_PAD")) {   // measurement override: the slab's extra elements per row (multiples of 16)
+    if (const char* sp = std::getenv("BSKGPU_STRIDE_PAD")) {
         const int v = std::atoi(sp);
         if (v >= 0 && v % 16 == 0) h->stride = ((int64_t)n_envs + 255) / 256 * 256 + v;
     }
+#endif
     // 64-lane workgroups spread a small batch over more CUs (65 536 envs = 1 024 waves = 4 per CU);
     // large batches use 256 so the dispatcher has fewer workgroups to place.
     h->block = n_envs >= (1 << 20) ? 256 : 64;
+#if BSK_TUNABLES
     if (const char* b = std::getenv("BSKGPU_BLOCK")) {   // measurement override: 64, 128 or 256
         const int v = std::atoi(b);
         if (v == 64 || v == 128 || v == 256) h->block = v;
     }
+#endif
     // the power-system kernels carry 37.6 KB of LDS per wave: one wave per workgroup at every batch size
     if (cfg->flags & BSK_FLAG_POWER) h->block = 64;
     // both wave-split forms pay while every workgroup has a CU (and its LDS) to itself: 64 spacecraft per CU of THIS device
@@ -813,7 +826,9 @@ int bsk_create(const bsk_config* cfg, int n_envs, int device_id, void* stream, b
     if (prop.multiProcessorCount > 0) h->pair_max_envs = h->tri_max_envs = 64 * prop.multiProcessorCount;
     h->pair_ok = bsk::pair_available(cfg->gravity_model, h->diag, h->sp.feat);
     h->sp.pair_shift = 31;     // no swap: the hardware already places one wave 0 and one wave 1 of different workgroups on a SIMD (tools/micro/placement.hip)
+#if BSK_TUNABLES
     if (const char* ps = std::getenv("BSKGPU_PAIR_SHIFT")) h->sp.pair_shift = std::max(0, std::min(31, std::atoi(ps)));
+#endif
     if (const char* pv = std::getenv("BSKGPU_PAIR")) {
         const int v = std::atoi(pv);
         if (v == 0) h->pair_ok = false;

@@ -176,7 +176,12 @@ class DirectRcclGather(object):
         others = [s for r, s in enumerate(self.sizes) if r != self.root and s]
         if layout == "rank-major":
             self.rm = rccl.RankMajorBufs(ptr("obs"), v["stride"] * 8, ptr("reward"), ptr("reason"), o, o + 6 * n * 8)
-            self.messages_on_root = rccl.rank_major_messages(self.sizes, self.root)
+            # one block or six rows: each rank says what ITS buffers are (real pitch, reward directly behind the observation rows),
+            # exchanged here once - the root posts the receives that match, whatever row pitch a rank's library was built with
+            flags = [None] * self.world
+            dist.all_gather_object(flags, bool(self.rm.contiguous(prop.n_envs)), group=group)
+            self.contig = [bool(f) for f in flags]
+            self.messages_on_root = rccl.rank_major_messages(self.sizes, self.root, self.contig)
         else:
             self.messages_on_root = len(others) * sum(b.rows for b in self.bufs)
         self.stream = prop.stream_ptr()
@@ -191,7 +196,7 @@ class DirectRcclGather(object):
         from . import rccl
         rccl.group_start()
         if self.layout == "rank-major":
-            rccl.enqueue_gather_rank_major(self.comm, self.stream, self.root, self.sizes, self.rm)
+            rccl.enqueue_gather_rank_major(self.comm, self.stream, self.root, self.sizes, self.rm, self.contig)
         else:
             rccl.enqueue_gather(self.comm, self.stream, self.root, self.sizes, self.bufs)
         rccl.group_end()

@@ -207,13 +207,21 @@ def copy_own(comm, stream, root, sizes, bufs):
 # and the library keeps observation rows and reward row in ONE allocation f64[6][stride] (bsk_create), so a shard whose size
 # equals its stride (n_r a multiple of 256: BASELINE configs[3]'s 131 072 and configs[2]'s 65 536 are) is one contiguous
 # 6 n_r doubles: TWO messages per rank (f64 block, u8 reasons) instead of seven, 14 receives on the root instead of 49.
-# A shard with padding (n_r not a multiple of 256) sends its six rows one by one into the same block (seven messages, as before).
-# Which of the two a rank does is a function of sizes[r] alone, so sender and receiver agree without talking.
+# A shard with padding (n_r not a multiple of 256, or a library built with another row pitch) sends its six rows one by one into
+# the same block (seven messages, as before).  Which of the two a rank does is decided ONCE, by the sender from its real buffers
+# (RankMajorBufs.contiguous: pitch and reward address), and exchanged when the gather object is built (`contig`, one flag per rank:
+# DirectRcclGather.__init__ all-gathers them), so that sender and receiver post matching messages whatever the pitch is and nothing
+# has to be refused between group_start() and group_end().
 STRIDE_QUANTUM = 256          # bsk_create pads the env stride to a multiple of this
 
 
 def rank_major_contiguous(n_r):
+    """What a shard of n_r envs is with the library's default row pitch (the exchanged flags are authoritative)."""
     return int(n_r) > 0 and int(n_r) % STRIDE_QUANTUM == 0
+
+
+def rank_major_flags(sizes, contig=None):
+    return [bool(c) and int(n) > 0 for n, c in zip(sizes, contig)] if contig is not None else [rank_major_contiguous(n) for n in sizes]
 
 
 class RankMajorBufs(object):
@@ -230,23 +238,28 @@ class RankMajorBufs(object):
         return self.obs_pitch_bytes == 8 * int(n_r) and self.reward_ptr == self.obs_ptr + 5 * self.obs_pitch_bytes
 
 
-def rank_major_messages(sizes, root):
+def rank_major_messages(sizes, root, contig=None):
     """Receives the root posts per gather (= sends of all other ranks together)."""
-    return sum((2 if rank_major_contiguous(n) else 7) for r, n in enumerate(sizes) if r != root and n)
+    flags = rank_major_flags(sizes, contig)
+    return sum((2 if flags[r] else 7) for r, n in enumerate(sizes) if r != root and n)
 
 
-def enqueue_gather_rank_major(comm, stream, root, sizes, b):
-    """This rank's part of the rank-major gather (between group_start() and group_end(), every rank of the communicator)."""
+def enqueue_gather_rank_major(comm, stream, root, sizes, b, contig=None):
+    """This rank's part of the rank-major gather (between group_start() and group_end(), every rank of the communicator).
+    ``contig``: one flag per rank, exchanged beforehand - rank r sends its f64 part as one block; None: the default pitch's rule.
+    A sender whose buffers do not bear out its flag is refused BEFORE any message is posted (nothing raises inside an open group
+    once the flags come from RankMajorBufs.contiguous itself)."""
     lib = load()
     offs, n_total = column_offsets(sizes)
     vp = C.c_void_p
+    flags = rank_major_flags(sizes, contig)
     if comm.rank == root:
         for r in range(comm.world):
             n_r = int(sizes[r])
             if r == root or n_r == 0:
                 continue
             blk = b.out_f64 + 48 * offs[r]
-            if rank_major_contiguous(n_r):
+            if flags[r]:
                 _ck(lib.ncclRecv(vp(blk), 6 * n_r, ncclFloat64, r, vp(comm.handle), vp(stream)), "ncclRecv")
             else:
                 for f in range(6):
@@ -256,7 +269,7 @@ def enqueue_gather_rank_major(comm, stream, root, sizes, b):
     n_r = int(sizes[comm.rank])
     if n_r == 0:
         return
-    if rank_major_contiguous(n_r):
+    if flags[comm.rank]:
         if not b.contiguous(n_r):
             raise RcclError("rank-major gather: a shard of %d envs must be one f64[6][%d] block (observation pitch %d bytes, reward at +%d)"
                             % (n_r, n_r, b.obs_pitch_bytes, b.reward_ptr - b.obs_ptr))

@@ -250,9 +250,11 @@ int bsk_get_obs_device(bsk_handle* h, double** d_obs, double** d_reward, uint64_
  * kernel with events / stream waits instead of a host synchronisation (or hand its own stream to bsk_create).
  * bsk_get_terminal_obs_device: device pointers of the terminal observations f64[5][stride] and the per-env
  * finished-episode counts int32[stride] of the device-side auto-reset (NULL until a pool is staged).
- * bsk_get_state_device: the state slab f64[n_fields][*stride] itself (read-only for the caller between steps).  ITS stride is not the
- * observation buffers': the slab's rows carry 256 B of padding each (measured: the K = 1 launch is 2 - 3 % shorter with the slab's rows an
- * odd multiple of 256 B apart; every other [stride] on this page is bsk_get_obs_device's: n_envs rounded up to 256). */
+ * bsk_get_state_device: the state slab f64[n_fields][*stride] itself (read-only for the caller between steps).  ITS stride need not be
+ * the observation buffers' (every other [stride] on this page is bsk_get_obs_device's: n_envs rounded up to 256): for batches of
+ * 65 536 ... 98 304 spacecraft the slab's rows carry 256 B of padding each.  That is an EMPIRICAL constant - the K = 1 launch measured
+ * 2.6 % shorter at 65 536 and 0.5 % at 98 304 with the rows an odd multiple of 256 B apart, nothing either way at 32 768 / 131 072,
+ * slightly longer at 4 Mi (profiles/r06/stride_pad.txt); the mechanism is not established - so always take the stride from here. */
 /* bsk_get_episode_device (BSK_FLAG_EPISODE_STATS / BSK_FLAG_OBS_ROWMAJOR; pointers are NULL where the flag is off):
  *   ep_return   f64[stride]  return of the running episode, this step's reward included; 0 where a device-side reset fired
  *   term_return f64[stride], term_len int32[stride]: 'r' and 'l' of info['episode'] for the envs whose done byte is set at this

@@ -113,3 +113,29 @@ def test_c_consumer_links_against_the_library(tmp_path):
                             "-L", libdir, "-lbskgpu", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)],
                            capture_output=True)
         assert r.returncode == 0, r.stderr.decode()
+
+
+def test_product_library_reads_no_measurement_overrides():
+    """BSKGPU_STRIDE_PAD / BSKGPU_OSTRIDE_PAD (data layout), BSKGPU_BLOCK, BSKGPU_PAIR_SHIFT are measurement knobs:
+    compiled in only with -DBSK_TUNABLES=1 (`make tunables` -> variants/tunables.so), absent from the product library - whose only
+    environment switches are the three kernel-form ones the tests force forms with (bsk_kernel_info names the form that ran)."""
+    import re
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    blob = open(os.path.join(root, "basilisk_env_amd", "libbskgpu.so"), "rb").read()
+    names = set(m.decode() for m in re.findall(rb"BSKGPU_[A-Z_]+", blob))
+    assert names == {"BSKGPU_PAIR", "BSKGPU_TRI", "BSKGPU_SH_FORM"}, names
+    tun = os.path.join(root, "basilisk_env_amd", "variants", "tunables.so")
+    if os.path.exists(tun):
+        got = set(m.decode() for m in re.findall(rb"BSKGPU_[A-Z_]+", open(tun, "rb").read()))
+        assert {"BSKGPU_STRIDE_PAD", "BSKGPU_OSTRIDE_PAD", "BSKGPU_BLOCK", "BSKGPU_PAIR_SHIFT"} <= got
+    src = open(os.path.join(root, "basilisk_env_amd", "csrc", "bsk_capi.hip")).read()
+    outside, depth = [], 0
+    for line in src.splitlines():
+        if line.startswith("#if BSK_TUNABLES"):
+            depth += 1
+        elif line.startswith("#endif") and depth:
+            depth -= 1
+        elif "getenv" in line and not depth:
+            outside.append(line.strip())
+    assert len(outside) == 3, outside

@@ -299,6 +299,36 @@ def test_rank_major_gather_address_arithmetic(monkeypatch):
     bad = rccl.RankMajorBufs(blocks[0].ctypes.data, 256 * 8, why[0].ctypes.data, why[0].ctypes.data, 0, 0)
     with pytest.raises(rccl.RcclError):
         rccl.enqueue_gather_rank_major(rccl.Comm(1, 0, 4, 0), 7, root, sizes, bad)
+    # ADVICE r05 / VERDICT r05 #4c: a rank whose library pads the observation rows (BSKGPU_OSTRIDE_PAD in a tunables build: 256 envs
+    # at a pitch of 288) is NOT one block although its size says so.  The form is the SENDER's statement about its real buffers,
+    # exchanged at construction (`contig`): with rank 0's flag false it sends seven messages and the root posts seven receives -
+    # no exception inside the group, nothing left unmatched.
+    sends.clear()
+    del recvs[:]
+    del hip.copies[:]
+    strides2 = [288, 512, 512, 256]
+    blocks2 = [np.arange(6 * st, dtype=np.float64).reshape(6, st) + 10000 * (r + 1) for r, st in enumerate(strides2)]
+    out_f64[:] = 0
+    bufs = [rccl.RankMajorBufs(blocks2[r].ctypes.data, strides2[r] * 8, blocks2[r][5].ctypes.data, why[r].ctypes.data, out_f64.ctypes.data, out_u8.ctypes.data)
+            for r in range(4)]
+    contig = [bufs[r].contiguous(sizes[r]) for r in range(4)]
+    assert contig == [False, False, True, True] and rccl.rank_major_messages(sizes, root, contig) == 7 + 7 + 2
+    for r in range(4):
+        rccl.enqueue_gather_rank_major(rccl.Comm(1000 + r, r, 4, r), 7, root, sizes, bufs[r], contig)
+        rccl.copy_own_rank_major(rccl.Comm(1000 + r, r, 4, r), 7, root, sizes, bufs[r])
+    assert [len(sends.get(1000 + r, [])) for r in range(4)] == [7, 7, 2, 0] and len(recvs) == 16
+    taken = {}
+    for ptr, count, dtype, peer in recvs:
+        k = taken.get(peer, 0)
+        sptr, scount, sdtype, to = sends[1000 + peer][k]
+        taken[peer] = k + 1
+        assert (scount, sdtype, to) == (count, dtype, root)
+        ctypes.memmove(ptr, sptr, count * (1 if dtype == rccl.ncclUint8 else 8))
+    for dev, dst, dpitch, src, spitch, width, height, kind, stream in hip.copies:
+        for f in range(height):
+            ctypes.memmove(dst + f * dpitch, src + f * spitch, width)
+    for r, n_r in enumerate(sizes):
+        assert np.array_equal(out_f64[6 * offs[r]:6 * offs[r + 1]].reshape(6, n_r), blocks2[r][:, :n_r])
 
 
 def test_all_reduce_stats_twice_between_steps_gives_the_same_sums(monkeypatch):

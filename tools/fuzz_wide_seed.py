@@ -25,7 +25,7 @@ if level == 3:
     else: cfg.n_facets = int(rng.integers(1, 8))
 if level == 0 and rng.random() < 0.3: flags |= FLAG_LDS_SCRATCH
 cfg.flags |= flags; cfg.dt = float(rng.choice([0.05, 0.1, 0.25])); cfg.fsw_every = int(rng.choice([2, 10, 13])); cfg.max_length = int(rng.integers(1, 4))
-if level == 0: os.environ["BSKGPU_BLOCK"] = str(rng.choice([64, 128, 256]))
+if level == 0: rng.choice([64, 128, 256])     # (was BSKGPU_BLOCK: the draw stays so that every seed keeps its case)
 ic = sample_ic_batch(n, n_rw, seed=seed + 7); t = 12 + n_rw
 if n_rw:
     hot = rng.random(n) < 0.2
