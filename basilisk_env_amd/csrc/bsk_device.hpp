@@ -537,15 +537,15 @@ struct TriXch {
     __device__ __forceinline__ V3 finish(TriPend f, double& extra) {
         const int want = nc + 1;
         if (BSK_UNLIKELY(__builtin_amdgcn_ballot_w64(f.tag != want) != 0)) {
-            if constexpr (probe::TRI_XCHG != 0) ++dbg_miss;
-            const probe::Stamp c0 = probe::stamp<probe::TRI_XCHG != 0>();
+            if constexpr (probe::XCH_STATS) ++dbg_miss;
+            const probe::Stamp c0 = probe::stamp<probe::XCH_STATS>();
             for (int spin = 0; !dead; ++spin) {
                 f = prefetch<EXTRA>();
-                if constexpr (probe::TRI_XCHG != 0) ++dbg_spin;
+                if constexpr (probe::XCH_STATS) ++dbg_spin;
                 if (__builtin_amdgcn_ballot_w64(f.tag != want) == 0) break;
                 if (spin > TRI_SPIN_LIMIT) { dead = true; X->err = 1; }
             }
-            probe::since<probe::TRI_XCHG != 0>(dbg_cyc, c0);
+            probe::since<probe::XCH_STATS>(dbg_cyc, c0);
         }
         ++nc;
         if constexpr (EXTRA) extra = f.e;

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
     // of the loop (wave-uniform: the other lanes of the wave wait), so that the FSW chain is instantiated once.
     bool z0 = false;
     if constexpr (NRW > 0) z0 = navlag && tick == 0 && substeps_eff > 0;
-    unsigned long long dbg_waitA = 0, dbg_waitB = 0, dbg_chain = 0;      // (probe builds only: bsk_probes.hpp)
+    unsigned long long dbg_waitA = 0, dbg_waitB = 0, dbg_chain = 0, dbg_bar = 0;      // (probe builds only: bsk_probes.hpp)
     if constexpr (PAIR) {
         static_assert(!PAIR || (FEAT >= FEAT_POWER && FEAT != FEAT_FULLG && GRAV != BSK_GRAV_SH), "pair form: power / full-scenario levels, point mass or J2");
         static_assert(!TRI || FEAT == FEAT_FULL, "three-wave form: the full-scenario level");
@@ -404,8 +404,17 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
             return q;
         };
         int cb = 0;                                        // ring buffer of this chunk
-#define BSK_PAIR_SYNC() __syncthreads()
+        // (probe builds with BSK_PROBE_TRI_ROLE time every barrier; stamp<false> / since<false> are empty: the product's macro is the barrier)
+#define BSK_PAIR_SYNC() do { const probe::Stamp b0_ = probe::stamp<probe::TRI_ROLE>(); __syncthreads(); probe::since<probe::TRI_ROLE>(dbg_bar, b0_); } while (0)
         BSK_PAIR_SYNC();                                   // the environment wave's Sun positions are in LDS
+        const probe::Stamp role_t0 = probe::stamp<probe::TRI_ROLE>();
+        dbg_bar = 0;
+        // role probe: {cycles in the tick loop, of them at barriers, `third`} of the probed role's wave -> the workgroup's debug word
+        auto role_word = [&](unsigned long long third) {
+            if constexpr (TRI && probe::TRI_ROLE) {
+                if (wave_id == probe::TRI_ROLE_WAVE && lane == 0 && a.tail.dbg) a.tail.dbg[blockIdx.x] = probe::pack3(probe::elapsed(role_t0), dbg_bar, third);
+            }
+        };
         if constexpr (TRI) {
           if (isD) {
             // ------------------------------------------------- rotational / translational wave (one loop per role: a shared
@@ -511,6 +520,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
                 }
                 BSK_PAIR_SYNC();                           // the last chunk's ring is complete
                 BSK_PAIR_SYNC();                           // ... and the environment wave has answered
+                role_word(xc.dbg_cyc);
             };
             if (wave_id == 0) dyn_part(std::integral_constant<int, PART_ROT>{});
             else { dyn_part(std::integral_constant<int, PART_TRA>{}); return; }
@@ -601,7 +611,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
             while (j < substeps_eff) {
                 const Chunk q = next_chunk();
                 BSK_PAIR_SYNC();                           // A
-                const probe::Stamp c0 = probe::stamp<probe::PAIR_WAIT>();
+                const probe::Stamp c0 = probe::stamp<probe::PAIR_WAIT || probe::TRI_ROLE>();
                 if (q.fsw_any) {
                     State<NRW> nav;
                     nav.r = mk(PL->box[0][lane], PL->box[1][lane], PL->box[2][lane]);
@@ -628,7 +638,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
                         PL->box[8][lane] = (double)thr_maxn;
                         PL->box[9][lane] = (double)thr_t0n;
                     }
-                    probe::since<probe::PAIR_WAIT>(dbg_chain, c0);
+                    probe::since<probe::PAIR_WAIT || probe::TRI_ROLE>(dbg_chain, c0);
                     BSK_PAIR_SYNC();                       // B (either timing): the commands are there
                 }
                 tick += q.m;
@@ -646,6 +656,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
             if constexpr (probe::PAIR_WAIT) PL->box[10][lane] = (double)(dbg_chain >> 4);
             if constexpr (probe::PAIR_HWID) PL->box[9][lane] = (double)probe::hw_id();
             BSK_PAIR_SYNC();
+            role_word(dbg_chain);
             return;                                        // the dynamics wave writes the launch's results
         }
     } else {
@@ -913,7 +924,7 @@ __global__ __launch_bounds__(256, (SPLIT == 5 || SPLIT == 4 || SPLIT == 2 || SPL
             w = probe::hw_id() | ((unsigned long long)((PairP)lds_dyn)->box[9][0] << 32);
         if constexpr (!PAIR && probe::CHUNK != 0)       // single-wave form: cycles / 16 of the probed part of every chunk | of the whole tick loop << 32
             w = ((dbg_chain >> 4) & 0xFFFFFFFFull) | (((dbg_waitA >> 4) & 0xFFFFFFFFull) << 32);
-        if ((threadIdx.x & 63) == 0 && ta.dbg) ta.dbg[gid >> 6] = w;
+        if ((threadIdx.x & 63) == 0 && ta.dbg && !(TRI && probe::TRI_ROLE)) ta.dbg[gid >> 6] = w;      // (the role probe's wave wrote the word itself)
     }
     if ((threadIdx.x & 63) == 0) {
         ta.done_mask[gid >> 6] = dmask;

@@ -70,6 +70,9 @@ def parse(argv=None):
                         "same-tick: both 0 (measurement A/B only)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true")
+    p.add_argument("--full-line", action="store_true",
+                   help="measurement tooling only: print the whole record as the ONE stdout line (no EXTRA line, no compact line, no "
+                        "bench_extra.json) - what tools/*.sh parse; the driver's commands never pass it")
     return p.parse_args(argv)
 
 
@@ -156,10 +159,17 @@ def headline_line(out):
     return line
 
 
+FULL_LINE = False       # --full-line (set by main): tooling gets the record as one line
+
+
 def emit(out, stream=None, extra_path=None):
     """Rank 0's output: bench_extra.json + the EXTRA line (the whole record), then - LAST - the compact line."""
     stream = stream or sys.stdout
     full = json.dumps(out)
+    if FULL_LINE and extra_path is None:
+        stream.write(full + "\n")
+        stream.flush()
+        return
     try:
         with open(extra_path or os.environ.get("BENCH_EXTRA_FILE") or os.path.join(ROOT, EXTRA_FILE), "w") as f:
             f.write(full + "\n")
@@ -858,6 +868,8 @@ def rl_loop(torch, n, substeps, steps, warmup=10):
 def main():
     argv = sys.argv[1:]
     a = parse(argv)
+    global FULL_LINE
+    FULL_LINE = bool(a.full_line)
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(self_launch(a.gpus, argv))
 

@@ -4,7 +4,7 @@
 # Needs the tunables build (make -C basilisk_env_amd/csrc tunables): the product library does not read BSKGPU_STRIDE_PAD.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
 export BSKGPU_LIB=$R/basilisk_env_amd/variants/tunables.so
-line() { BSKGPU_STRIDE_PAD=$1 python3 bench.py --no-cpu-baseline --no-extra --envs $2 --steps $3 --warmup 2000 2>/dev/null | tail -n 1 | python3 -c "
+line() { BSKGPU_STRIDE_PAD=$1 python3 bench.py --no-cpu-baseline --no-extra --full-line --envs $2 --steps $3 --warmup 2000 2>/dev/null | tail -n 1 | python3 -c "
 import sys,json
 d=json.loads(sys.stdin.read())
 print('envs %-8s pad %-3s wall_us %7.3f value %.4g' % ('$2', '$1', d['ms_per_step']*1e3, d['value']))"; }
