@@ -34,6 +34,15 @@ def test_no_dpp_hazard_in_the_built_library():
             bad += b
             tbad += d.check_trans(funcs)       # (the other hazard an inline-asm consumer could hide: a transcendental's result read at once)
     assert total > 1000, "the scenario kernels' DPP instructions were not found: %d" % total
+    # EVERY translation unit's code object was looked at: the library holds one offload bundle per unit and clang-offload-bundler reads
+    # only the first of a file - from the eight-unit build of round 5 until round 6 this check saw one eighth of the kernels (30 840 of
+    # 195 296 DPP instructions).  The padding pass leaves its count per unit beside the object it built: the sums must agree.
+    import glob
+    import re
+    notes = sorted(glob.glob(os.path.join(ROOT, "basilisk_env_amd", "csrc", "bsk_kernels_tu*.o.dpp_nops.txt")))
+    if notes:
+        built = sum(int(re.match(r"dpp_nops: (\d+) DPP instructions", open(f).read()).group(1)) for f in notes)
+        assert len(notes) == 8 and total >= built > 100000, (total, built, len(notes))
     assert not bad, "%d DPP hazards, first: %s" % (len(bad), bad[0])
     assert not tbad, "%d transcendental forwarding hazards, first: %s" % (len(tbad), tbad[0])
 

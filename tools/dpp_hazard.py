@@ -33,16 +33,34 @@ def regs(tok):
     return None
 
 
-def disassemble(lib, tmp):
+BUNDLE_MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def code_objects(lib, tmp):
+    """Every gfx950 code object of the library -> list of ELF paths.  The library's .hip_fatbin section holds ONE offload bundle per
+    translation unit, back to back (eleven since the step kernel was cut into eight units), and clang-offload-bundler reads only the
+    first bundle of a file: the section is cut at every bundle magic and each piece unbundled on its own."""
     fat = os.path.join(tmp, "fat.bin")
     subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat], check=True)
-    out = subprocess.run([LLVM + "/clang-offload-bundler", "--list", "--type=o", "--input=" + fat], check=True, capture_output=True, text=True).stdout
-    texts = []
-    for i, tgt in enumerate(t for t in out.split() if "gfx950" in t):
-        obj = os.path.join(tmp, "code%d.o" % i)
-        subprocess.run([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--targets=" + tgt, "--input=" + fat, "--output=" + obj], check=True)
-        texts.append(subprocess.run([LLVM + "/llvm-objdump", "-d", "--no-show-raw-insn", obj], check=True, capture_output=True, text=True).stdout)
-    return texts
+    blob = open(fat, "rb").read()
+    starts = [m.start() for m in re.finditer(re.escape(BUNDLE_MAGIC), blob)]
+    objs = []
+    for k, lo in enumerate(starts):
+        piece = os.path.join(tmp, "bundle%d.bin" % k)
+        with open(piece, "wb") as f:
+            f.write(blob[lo:starts[k + 1] if k + 1 < len(starts) else len(blob)])
+        out = subprocess.run([LLVM + "/clang-offload-bundler", "--list", "--type=o", "--input=" + piece], check=True, capture_output=True, text=True).stdout
+        for i, tgt in enumerate(t for t in out.split() if "gfx950" in t):
+            obj = os.path.join(tmp, "code%d_%d.o" % (k, i))
+            subprocess.run([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--targets=" + tgt, "--input=" + piece, "--output=" + obj], check=True)
+            if os.path.getsize(obj) > 0:
+                objs.append(obj)
+    return objs
+
+
+def disassemble(lib, tmp):
+    return [subprocess.run([LLVM + "/llvm-objdump", "-d", "--no-show-raw-insn", obj], check=True, capture_output=True, text=True).stdout
+            for obj in code_objects(lib, tmp)]
 
 
 def parse(text):
