@@ -70,6 +70,7 @@ def parse(argv=None):
                         "same-tick: both 0 (measurement A/B only)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true")
+    p.add_argument("--no-join", action="store_true", help="measurement tooling only: skip the second timed loop (value_with_join)")
     p.add_argument("--full-line", action="store_true",
                    help="measurement tooling only: print the whole record as the ONE stdout line (no EXTRA line, no compact line, no "
                         "bench_extra.json) - what tools/*.sh parse; the driver's commands never pass it")
@@ -952,7 +953,7 @@ def main():
 
     el_local = timed_run(prop, d_act.data_ptr(), a.substeps, a.steps, a.warmup, barrier, sync)
     el = max_over_ranks(el_local)
-    el_join = max_over_ranks(timed_run(prop, d_act.data_ptr(), a.substeps, a.steps, a.warmup, barrier, sync, join=True))
+    el_join = max_over_ranks(timed_run(prop, d_act.data_ptr(), a.substeps, 1 if a.no_join else a.steps, 0 if a.no_join else a.warmup, barrier, sync, join=True))
     rsum_dev, ndone_dev = prop.batch_stats()
     _, rew_j, _, why_j = prop.get_obs()
     join_ok = bool(abs(rsum_dev - float(rew_j.sum())) <= 1e-9 * max(1.0, abs(float(rew_j.sum()))) and ndone_dev == int((why_j != 0).sum()))
@@ -1003,7 +1004,8 @@ def main():
                    "envs_per_gpu": n, "substeps": a.substeps, "scenario": a.scenario, "lds_scratch": bool(a.lds_scratch), "fsw_timing": a.fsw_timing, "features": a.features,
                    "sharding": "env ranges, no step-path collective", "kernel_fingerprint": fp,
                    "batch_stats": "per-wave sums in the step launch; join on demand"},
-        "value_with_join": n * world * a.steps / el_join, "ms_per_step_with_join": el_join / a.steps * 1e3, "join_matches_host_sum": join_ok,
+        "value_with_join": None if a.no_join else n * world * a.steps / el_join,
+        "ms_per_step_with_join": None if a.no_join else el_join / a.steps * 1e3, "join_matches_host_sum": join_ok,
         "roofline": fp64 if fp64_bound else hbm,
         "rk4_substeps_per_s": value * a.substeps,
     }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Copy what tools/round.sh, tools/isa_mix.sh and tools/bench_lines.sh merged back under gpurun_out/ into profiles/TAG (tracked).
+# Copy what tools/round.sh's phases merged back under gpurun_out/TAG into profiles/TAG (tracked).  Called by `tools/round.sh TAG collect`.
 # Usage (this container, repo root): tools/collect_evidence.sh r03
 TAG=${1:-r05}
 S=gpurun_out/$TAG; D=profiles/$TAG
@@ -69,11 +69,16 @@ if out:
     json.dump(out, open(os.path.join(d, "kt_stats.json"), "w"), indent=1)
     print("stats kernels (level 1 + join, us):", {k: "%.2f + %.2f" % (v.get("stats_kernel", {}).get("trimmed_mean_us", 0.0), v["stats_join_kernel"]["trimmed_mean_us"]) for k, v in out.items()})
 PY
+[ -f $S/isa_mix.json ] && cp $S/isa_mix.json $D/
 [ -f gpurun_out/isa_$TAG/isa_mix.json ] && cp gpurun_out/isa_$TAG/isa_mix.json $D/
+cp $S/bench_*.json $D/ 2>/dev/null        # NAME.json = the compact line the driver reads, NAME.extra.json = the whole record (tools/round.sh: line)
+cp $S/gputest.log $D/gputest_tail.txt 2>/dev/null && tail -n 3 $S/gputest.log > $D/gputest_tail.txt
 [ -d gpurun_out/${TAG}_lines ] && cp gpurun_out/${TAG}_lines/bench_*.json $D/ 2>/dev/null
 python3 - $D <<'PY'
 import json, sys, os
 d = sys.argv[1]
+if not (os.path.exists(os.path.join(d, "kernel_trace.json")) and os.path.exists(os.path.join(d, "isa_mix.json"))):
+    sys.exit(0)
 kt = json.load(open(os.path.join(d, "kernel_trace.json")))
 im = json.load(open(os.path.join(d, "isa_mix.json")))
 print("kernel_trace fingerprint", kt.get("fingerprint"), "isa_mix", im.get("_meta", {}).get("fingerprint"))

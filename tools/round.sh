@@ -2,6 +2,7 @@
 # THE evidence pass of a round - the single entry point.  One gpurun call per group of phases (a call is at most 20 minutes):
 #
 #   gpurun --timeout 1200 -- 'tools/round.sh r06 tests traces'      GPU suite; rocprofv3 kernel traces + un-profiled A/B lines
+#   gpurun --timeout 1200 -- 'BOX=2 tools/round.sh r06 traces'      (and BOX=3) the kernel traces again on another box
 #   gpurun --timeout 1200 -- 'tools/round.sh r06 counters isa'      HBM traffic / issue counter passes; executed instruction mix
 #   gpurun --timeout 1200 -- 'tools/round.sh r06 lines'             the bench lines (after `collect` has put this tree's summaries
 #                                                                   under profiles/TAG, so that every line prices on them)
@@ -13,7 +14,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:?usage: tools/round.sh TAG PHASE...}; shift
 O=$R/gpurun_out/$TAG
 mkdir -p $O
-B="python3 $R/bench.py --no-cpu-baseline --no-extra --full-line"
+B="python3 $R/bench.py --no-cpu-baseline --no-extra --no-join --full-line"
 prof() { tag=$1; shift; ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 "$@" > $O/$tag.log 2>&1 ) && echo $tag ok || echo $tag FAILED; }
 SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"
 # name : bench arguments   (the keys of kernel_trace.json: tools/kernel_trace_summary.py)
@@ -28,11 +29,16 @@ phase_tests() {
 }
 
 phase_traces() {
+  # BOX=2|3 in the environment: the same traces on ONE MORE box (a fresh gpurun call is a fresh box; the boxes of this pool differ by
+  # up to 7 % on the fp64-bound kernels and a 7 us kernel's figure in the tracer depends on the box too): kt_<name>_b<BOX>, summarised
+  # as the MEDIAN over the boxes (tools/kernel_trace_summary.py).  The stats / copy-tracer runs belong to box 1 only.
+  sfx=${BOX:+_b$BOX}
   for run in "${RUNS[@]}"; do
     name=${run%%:*}; args=${run#*:}
-    prof kt_$name --kernel-trace --stats --output-format csv -d $O/kt_$name -- $B $args
-    ( cd $R && $B $args > $O/ab_${name}_plain.json 2>> $O/bench.err )     # the same command un-profiled, same box
+    prof kt_$name$sfx --kernel-trace --stats --output-format csv -d $O/kt_$name$sfx -- $B $args
+    ( cd $R && $B $args > $O/ab_${name}${sfx}_plain.json 2>> $O/bench.err )     # the same command un-profiled, same box
   done
+  if [ -n "$BOX" ]; then cd $R && python3 tools/kernel_trace_summary.py $O $O > $O/kernel_trace.json && echo kernel_trace ok; return 0; fi
   # the batch scalars (row a7): stats_kernel / stats_join_kernel at four batch sizes, a request after every step
   for ns in 65536 131072 1048576 4194304; do
     prof kt_stats_$ns --kernel-trace --stats --output-format csv -d $O/kt_stats_$ns -- python3 $R/tools/exp/stats_trace.py $ns
