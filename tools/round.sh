@@ -108,6 +108,8 @@ phase_lines() {
 }
 
 phase_collect() {   # this container: what the round keeps, tracked
+  # (every box's traces are under gpurun_out/TAG by now: the summary over ALL of them is formed here, not on the last box)
+  cd $R && ls -d $O/kt_65k* > /dev/null 2>&1 && python3 tools/kernel_trace_summary.py $O $O > $O/kernel_trace.json
   cd $R && bash tools/collect_evidence.sh $TAG && python3 tools/profiles_tables.py $TAG && echo "profiles/$TAG written"
 }
 
