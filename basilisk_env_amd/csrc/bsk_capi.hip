@@ -1036,9 +1036,6 @@ int bsk_step_n(bsk_handle* h, const int32_t* d_actions, int32_t constant_action,
     bsk::RolloutBuffers r;
     r.actions = d_actions; r.obs_hist = d_obs_hist; r.reward_hist = d_reward_hist; r.reason_hist = d_reason_hist;
     r.n_steps = n_steps; r.const_action = constant_action;
-#if BSK_TUNABLES
-    if (const char* k1 = std::getenv("BSKGPU_ROLLOUT_K1")) r.k1_form = std::atoi(k1) != 0;      // measurement: the overlapped-epilogue form
-#endif
     hipEvent_t e0, e1;
     { int rc = stamp_events(h, e0, e1); if (rc) return rc; }
     h->last_pair = h->last_tri = false;

@@ -312,274 +312,6 @@ __global__ __launch_bounds__(256, 2) void rollout_kernel(const RolloutArgs<NRW, 
 #undef FLD
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// K = 1 form with a constant action (round 6 experiment): ONE RK4 sub-step per env step, the epilogue of env step s - 1
-// (two Newton square roots, the reward's reciprocal, the history row) placed in the SAME basic block as the tick of step s, so that the
-// scheduler has the tick's FMAs to put behind the epilogue's dependent chains; a lone wave per SIMD has nothing else to overlap them with
-// (profiles/r05/rejected/rollout_fsw_lds.txt: 920 quad-cycles per env step against the bare tick's 506).
-//   * An env step whose epilogue could end an episode is NOT overlapped: a cheap conservative test on the end-of-step state (step count,
-//     |Omega|^2 against 0.99 of the limit's square, empty battery, orbit radius) - a ballot over the wave - sends the whole wave through the
-//     ordinary epilogue (restart from the pool included) before the next tick; everywhere else `why` is 0 by construction.
-//   * Same device functions on the same values in the same order per value as rollout_kernel / step_kernel: bit-identical buffers.
-template <int GRAV, int NRW, bool DIAG>
-__global__ __launch_bounds__(256, 2) void rollout_k1_kernel(const RolloutArgs<NRW, DIAG> a) {
-    constexpr int FEAT = FEAT_BARE, SPLIT = 1;
-    const HotCfg<NRW, DIAG>& c = a.hot;
-    const ColdCfg* __restrict__ cold = a.cold;
-    const TailArgs& ta = a.tail;
-    const int gid = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    const int n = ta.n;
-    const bool valid = gid < n;
-    const int i = valid ? gid : n - 1;
-    const int64_t S = ta.stride;
-    const int64_t SO = ta.ostride;
-    gptr<double> so = uniform_ptr(ta.st);
-    const uint32_t bo = (uint32_t)i * 8u;
-    constexpr int TAIL = BSK_NF_BASE + NRW;
-#define FLD(f) (so + (int64_t)(f) * S)
-    auto ld = [&](int f) __attribute__((always_inline)) { return *(gptr<double>)((gptr<char>)FLD(f) + bo); };
-    State<NRW> x;
-    x.r = mk(ld(BSK_F_R + 0), ld(BSK_F_R + 1), ld(BSK_F_R + 2));
-    x.v = mk(ld(BSK_F_V + 0), ld(BSK_F_V + 1), ld(BSK_F_V + 2));
-    x.s = mk(ld(BSK_F_SIGMA + 0), ld(BSK_F_SIGMA + 1), ld(BSK_F_SIGMA + 2));
-    x.w = mk(ld(BSK_F_OMEGA + 0), ld(BSK_F_OMEGA + 1), ld(BSK_F_OMEGA + 2));
-#pragma unroll
-    for (int k = 0; k < NRW; ++k) x.Om[k] = ld(BSK_NF_BASE + k);
-    V3 lext = mk(ld(TAIL + BSK_T_LEXT + 0), ld(TAIL + BSK_T_LEXT + 1), ld(TAIL + BSK_T_LEXT + 2));
-    double charge = ld(TAIL + BSK_T_CHARGE);
-    double sbr = ld(TAIL + BSK_T_SBR);
-    double u[NRW > 0 ? NRW : 1], up[NRW > 0 ? NRW : 1], un[NRW > 0 ? NRW : 1];
-#pragma unroll
-    for (int k = 0; k < (NRW > 0 ? NRW : 1); ++k) { u[k] = 0.0; up[k] = 0.0; un[k] = 0.0; }
-#pragma unroll
-    for (int k = 0; k < NRW; ++k) {
-        u[k] = ld(TAIL + BSK_T_UCMD + k);
-        up[k] = ld(TAIL + BSK_T_UPEND + k);
-        un[k] = u[k];
-    }
-    const int2 cnt = *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(ta.cnt) + bo);
-    int steps0 = cnt.x & 0xFFFFF, phase = cnt.x >> 20, tick = cnt.y;
-    const int n_pool = ta.n_pool;
-    int ep = (n_pool > 0) ? ta.episodes[i] : 0;
-    double ep_ret = 0.0;
-    if (ta.ep_return) ep_ret = *(gptr<double>)((gptr<char>)uniform_ptr(ta.ep_return) + bo);
-
-    WheelV<NRW> wv;
-    wv.load(c);
-    Env ev;
-    const int fsw_every = c.fsw_every;
-    const bool navlag = NRW > 0 && ta.nav_lag != 0;
-    const bool lag = ta.fsw_lag != 0;
-    const int hist_n = n;
-    const int action = a.const_action;
-    int action_v = action;                       // (a VGPR copy the compiler cannot prove uniform: the reward's mode test stays a select)
-    asm volatile("" : "+v"(action_v));
-    double o0 = 0.0, o1 = 0.0, o2 = 0.0, o3 = 0.0, o4 = 1.0, rew = 0.0;
-    int why = 0;
-    bool was_reset = false;
-
-    auto fsw_tick = [&](const State<NRW>& nav) {
-        const FswCfg fc = load_fsw(cold);
-        Guid g = guidance<NRW>(fc.sigma_R0N, nav, action);
-        sbr = sqrt_nr(dot(g.sigma_BR, g.sigma_BR));
-        if (lag) {
-#pragma unroll
-            for (int k = 0; k < NRW; ++k) un[k] = up[k];
-            control<NRW>(fc, g, up);
-        } else {
-            control<NRW>(fc, g, un);
-        }
-    };
-    auto latch = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < NRW; ++k) u[k] = un[k];
-    };
-    // everything of an env step in front of its tick: the t = 0 chunk (reference task priorities: zero messages, latched without a
-    // step), then the FSW chain where this lane's phase is due - the chunk machinery of rollout_kernel for substeps == 1
-    auto front = [&]() __attribute__((always_inline)) {
-        if constexpr (NRW > 0) {
-            if (navlag) {
-                const bool z0 = tick == 0;
-                if (BSK_UNLIKELY(__builtin_amdgcn_ballot_w64(z0) != 0)) {
-                    if (z0) {
-                        State<NRW> nav = x;
-                        nav.r = mk(0, 0, 0); nav.v = mk(0, 0, 0); nav.s = mk(0, 0, 0); nav.w = mk(0, 0, 0);
-#pragma unroll
-                        for (int k = 0; k < NRW; ++k) nav.Om[k] = 0.0;
-                        fsw_tick(nav);
-                    }
-                    latch();
-                }
-            }
-            const int trig = navlag ? fsw_every - 1 : 0;
-            if (phase == trig) {
-                fsw_tick(x);
-                if (!navlag) latch();
-            }
-            phase += 1;
-            if (phase >= fsw_every) phase -= fsw_every;
-        }
-    };
-    auto tick1 = [&]() __attribute__((always_inline)) {
-        rk4_step<GRAV, NRW, DIAG, FEAT, SPLIT, false>(c, wv, x, u, lext, (double)tick * c.h, ev, nullptr);
-        ++tick;
-    };
-    // the ordinary epilogue of env step `es` (rollout_kernel's, statement for statement): observation, reward, termination, episode
-    // statistics, device-side restart, the history row
-    auto epilogue_full = [&](int es) {
-        o0 = sbr;
-        if (!(NRW > 0 && ta.nav_lag != 0)) {
-            double sR0N[3] = {ta.obs_cfg.sigma_R0N[0], ta.obs_cfg.sigma_R0N[1], ta.obs_cfg.sigma_R0N[2]};
-            const Guid g = guidance<NRW>(sR0N, x, action);
-            o0 = sqrt_nr(dot(g.sigma_BR, g.sigma_BR));
-        }
-        o1 = sqrt_nr(dot(x.w, x.w));
-        double om2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < NRW; ++k) om2 = fma(x.Om[k], x.Om[k], om2);
-        o2 = sqrt_nr(om2) * ta.obs_cfg.inv_wheel_limit;
-        o3 = charge * ta.obs_cfg.charge_scale;
-        o4 = 1.0;
-        why = 0;
-        rew = (action == 0) ? ta.obs_cfg.reward_mult * rcp_nr(fma(o0, o0, 1.0)) : 0.0;
-        if (steps0 >= ta.obs_cfg.max_length) why |= BSK_DONE_LENGTH;
-        if (o2 > 1.0) { why |= BSK_DONE_WHEELS; rew -= ta.obs_cfg.failure_penalty; }
-        if (o3 == 0.0) { why |= BSK_DONE_BATTERY; rew -= ta.obs_cfg.failure_penalty; }
-        if (dot(x.r, x.r) < ta.obs_cfg.r_min2) why |= BSK_DONE_ORBIT;
-        if (ta.ep_return) {
-            ep_ret += rew;
-            if (why != 0) {
-                if (valid) {
-                    stf(uniform_ptr(ta.term_return), bo, ep_ret);
-                    ta.term_len[i] = steps0;
-                }
-                if (n_pool > 0) ep_ret = 0.0;
-            }
-        }
-        was_reset = false;
-        if (n_pool > 0 && why != 0) {
-            gptr<double> tob = uniform_ptr(ta.term_obs);
-            if (valid) { stf(tob + 0 * SO, bo, o0); stf(tob + 1 * SO, bo, o1); stf(tob + 2 * SO, bo, o2); stf(tob + 3 * SO, bo, o3); stf(tob + 4 * SO, bo, o4); }
-            const unsigned slot = (((unsigned)i + ta.env_base) * 2654435761u + (unsigned)ep * 40503u + 12345u) % (unsigned)n_pool;
-            ep += 1;
-            if (valid) ta.episodes[i] = ep;
-            const double* __restrict__ pool = ta.pool;
-            const int nf = ta.n_fields;
-            if (valid)
-                for (int f = 0; f < nf; ++f) stf(FLD(f), bo, pool[(int64_t)f * n_pool + slot]);
-            auto pl = [&](int f) { return pool[(int64_t)f * n_pool + slot]; };
-            x.r = mk(pl(BSK_F_R + 0), pl(BSK_F_R + 1), pl(BSK_F_R + 2));
-            x.v = mk(pl(BSK_F_V + 0), pl(BSK_F_V + 1), pl(BSK_F_V + 2));
-            x.s = mk(pl(BSK_F_SIGMA + 0), pl(BSK_F_SIGMA + 1), pl(BSK_F_SIGMA + 2));
-            x.w = mk(pl(BSK_F_OMEGA + 0), pl(BSK_F_OMEGA + 1), pl(BSK_F_OMEGA + 2));
-            double pom2 = 0.0;
-#pragma unroll
-            for (int k = 0; k < NRW; ++k) {
-                x.Om[k] = pl(BSK_NF_BASE + k);
-                pom2 = fma(x.Om[k], x.Om[k], pom2);
-                u[k] = pl(TAIL + BSK_T_UCMD + k);
-                up[k] = pl(TAIL + BSK_T_UPEND + k);
-                un[k] = u[k];
-            }
-            lext = mk(pl(TAIL + BSK_T_LEXT + 0), pl(TAIL + BSK_T_LEXT + 1), pl(TAIL + BSK_T_LEXT + 2));
-            charge = pl(TAIL + BSK_T_CHARGE);
-            sbr = pl(TAIL + BSK_T_SBR);
-            o0 = sqrt_nr(dot(x.s, x.s)); o1 = sqrt_nr(dot(x.w, x.w)); o2 = sqrt_nr(pom2) * ta.obs_cfg.inv_wheel_limit;
-            o3 = charge * ta.obs_cfg.charge_scale; o4 = 1.0;
-            steps0 = 0; phase = 0; tick = 0;
-            was_reset = true;
-        } else {
-            steps0 = min(steps0 + 1, 0xFFFFF);
-        }
-        const int64_t row = (int64_t)es * hist_n + i;
-        if (valid && a.obs_hist) {
-            double* __restrict__ oh = a.obs_hist + (int64_t)es * 5 * hist_n + i;
-            oh[0] = o0; oh[(int64_t)hist_n] = o1; oh[2 * (int64_t)hist_n] = o2; oh[3 * (int64_t)hist_n] = o3; oh[4 * (int64_t)hist_n] = o4;
-        }
-        if (valid && a.reward_hist) a.reward_hist[row] = rew;
-        if (valid && a.reason_hist) a.reason_hist[row] = (unsigned char)why;
-    };
-
-    // env step 0
-    front();
-    tick1();
-    if constexpr (NRW > 0) latch();
-    const double inv2 = ta.obs_cfg.inv_wheel_limit * ta.obs_cfg.inv_wheel_limit;
-#pragma nounroll
-    for (int es = 1; es < a.n_steps; ++es) {
-        // ---- could env step es - 1 end an episode?  (conservative; wave-uniform decision)
-        double om2p = 0.0;
-#pragma unroll
-        for (int k = 0; k < NRW; ++k) om2p = fma(x.Om[k], x.Om[k], om2p);
-        const bool maybe = steps0 >= ta.obs_cfg.max_length || om2p * inv2 > 0.99 || charge * ta.obs_cfg.charge_scale == 0.0 || dot(x.r, x.r) < ta.obs_cfg.r_min2;
-        const bool slow = __builtin_amdgcn_ballot_w64(maybe) != 0;
-        if (BSK_UNLIKELY(slow)) epilogue_full(es - 1);
-        double e0 = sbr;                          // obs[0] of step es - 1: the att_guidance message as the last FSW tick left it
-        if (!(NRW > 0 && ta.nav_lag != 0)) {
-            double sR0N[3] = {ta.obs_cfg.sigma_R0N[0], ta.obs_cfg.sigma_R0N[1], ta.obs_cfg.sigma_R0N[2]};
-            const Guid g = guidance<NRW>(sR0N, x, action);
-            e0 = sqrt_nr(dot(g.sigma_BR, g.sigma_BR));
-        }
-        front();                                  // step es: FSW part (reads x, may rewrite sbr / un / up)
-        // ---- ONE block: the overlapped epilogue's chains of step es - 1 (on the state the tick is about to advance) + the tick of step es
-        const double e1 = sqrt_nr(dot(x.w, x.w));
-        double om2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < NRW; ++k) om2 = fma(x.Om[k], x.Om[k], om2);
-        const double e2 = sqrt_nr(om2) * ta.obs_cfg.inv_wheel_limit;
-        const double e3 = charge * ta.obs_cfg.charge_scale;
-        const double rv = ta.obs_cfg.reward_mult * rcp_nr(fma(e0, e0, 1.0));
-        const double er = (action_v == 0) ? rv : 0.0;
-        tick1();
-        if constexpr (NRW > 0) latch();
-        if (!slow) {
-            steps0 = min(steps0 + 1, 0xFFFFF);
-            if (ta.ep_return) ep_ret += er;
-            const int64_t row = (int64_t)(es - 1) * hist_n + i;
-            if (valid && a.obs_hist) {
-                double* __restrict__ oh = a.obs_hist + (int64_t)(es - 1) * 5 * hist_n + i;
-                oh[0] = e0; oh[(int64_t)hist_n] = e1; oh[2 * (int64_t)hist_n] = e2; oh[3 * (int64_t)hist_n] = e3; oh[4 * (int64_t)hist_n] = 1.0;
-            }
-            if (valid && a.reward_hist) a.reward_hist[row] = er;
-            if (valid && a.reason_hist) a.reason_hist[row] = (unsigned char)0;
-        }
-    }
-    epilogue_full(a.n_steps - 1);
-
-    // ---- the launch's results, where step_kernel leaves them
-    const unsigned long long dmask = __ballot(valid && why != 0);
-    if ((threadIdx.x & 63) == 0) ta.done_mask[gid >> 6] = dmask;
-    if (!valid) return;
-    gptr<double> ob = uniform_ptr(ta.obs);
-    stf(ob + 0 * SO, bo, o0); stf(ob + 1 * SO, bo, o1); stf(ob + 2 * SO, bo, o2); stf(ob + 3 * SO, bo, o3); stf(ob + 4 * SO, bo, o4);
-    if (ta.obs_rm) {
-        double* __restrict__ rm = ta.obs_rm + (int64_t)i * 5;
-        rm[0] = o0; rm[1] = o1; rm[2] = o2; rm[3] = o3; rm[4] = o4;
-    }
-    stf(uniform_ptr(ta.reward), bo, rew);
-    ta.reason[i] = (unsigned char)why;
-    if (ta.ep_return) {
-        stf(uniform_ptr(ta.ep_return), bo, ep_ret);
-        ta.done[i] = why != 0 ? 1 : 0;
-    }
-    if (!was_reset) {
-        stf(FLD(BSK_F_R + 0), bo, x.r.x); stf(FLD(BSK_F_R + 1), bo, x.r.y); stf(FLD(BSK_F_R + 2), bo, x.r.z);
-        stf(FLD(BSK_F_V + 0), bo, x.v.x); stf(FLD(BSK_F_V + 1), bo, x.v.y); stf(FLD(BSK_F_V + 2), bo, x.v.z);
-        stf(FLD(BSK_F_SIGMA + 0), bo, x.s.x); stf(FLD(BSK_F_SIGMA + 1), bo, x.s.y); stf(FLD(BSK_F_SIGMA + 2), bo, x.s.z);
-        stf(FLD(BSK_F_OMEGA + 0), bo, x.w.x); stf(FLD(BSK_F_OMEGA + 1), bo, x.w.y); stf(FLD(BSK_F_OMEGA + 2), bo, x.w.z);
-#pragma unroll
-        for (int k = 0; k < NRW; ++k) {
-            stf(FLD(BSK_NF_BASE + k), bo, x.Om[k]);
-            stf(FLD(TAIL + BSK_T_UCMD + k), bo, u[k]);
-            stf(FLD(TAIL + BSK_T_UPEND + k), bo, up[k]);
-        }
-        if constexpr (NRW > 0) stf(FLD(TAIL + BSK_T_SBR), bo, sbr);
-    }
-    const unsigned long long packed = (unsigned long long)(unsigned)(steps0 | (phase << 20)) | ((unsigned long long)(unsigned)tick << 32);
-    *(gptr<unsigned long long>)((gptr<char>)uniform_ptr(ta.cnt) + bo) = packed;
-#undef FLD
-}
-
 template <int GRAV, int NRW, bool DIAG, bool ACT>
 static hipError_t launch_r(const StepParams& p, const StepBuffers& b, const RolloutBuffers& r, int block, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     RolloutArgs<NRW, DIAG> a;
@@ -597,12 +329,6 @@ static hipError_t launch_r(const StepParams& p, const StepBuffers& b, const Roll
     a.actions = r.actions; a.obs_hist = r.obs_hist; a.reward_hist = r.reward_hist; a.reason_hist = r.reason_hist;
     a.n_steps = r.n_steps; a.const_action = r.const_action;
     const int grid = (b.n + block - 1) / block;
-    if constexpr (!ACT) {
-        if (r.k1_form && b.substeps == 1) {       // (round 6 experiment: tunables builds only ask for it)
-            hipExtLaunchKernelGGL((rollout_k1_kernel<GRAV, NRW, DIAG>), dim3(grid), dim3(block), 0, s, ev0, ev1, 0, a);
-            return hipGetLastError();
-        }
-    }
     hipExtLaunchKernelGGL((rollout_kernel<GRAV, NRW, DIAG, ACT>), dim3(grid), dim3(block), 0, s, ev0, ev1, 0, a);
     return hipGetLastError();
 }

@@ -10,7 +10,6 @@ struct RolloutBuffers {
     double* reward_hist;           // [T][n]
     unsigned char* reason_hist;    // [T][n]
     int n_steps, const_action;
-    int k1_form = 0;               // constant action, one sub-step per env step: the overlapped-epilogue kernel (experiment; bsk_rollout.hip)
 };
 
 // built for: point mass / J2 at the bare level (every wheel set, diagonal and general hub)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Rollout kernel, K = 1, constant action: the ordinary kernel against the overlapped-epilogue form (round 6 experiment; `make tunables`
+"""(needs profiles/r06/rejected/rollout_k1_overlap.diff applied and `make tunables`; expects to sit in tools/exp/)
+Rollout kernel, K = 1, constant action: the ordinary kernel against the overlapped-epilogue form (round 6 experiment; `make tunables`
 library, BSKGPU_ROLLOUT_K1=0|1 read by bsk_step_n).  One process per form, alternating on one box; wall time per env step and the
 buffers' hash (the two forms must leave identical bits).  usage (GPU box): python3 tools/exp/rollout_k1.py [N [T [ROUNDS]]]"""
 import hashlib, os, subprocess, sys, time
