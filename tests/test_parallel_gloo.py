@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: env-range sharding with no step-path collective, and the
+"""CPU, world_size 2 and 4 over gloo: env-range sharding with no step-path collective, and the
 observation all-gather / gather-to-root reproduce the single-process batch exactly."""
 import os
 import socket
@@ -36,9 +36,9 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("n_total", [128, 131])     # equal and ragged shards
-def test_two_rank_sharded_step_and_gather(tmp_path, n_total):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+@pytest.mark.parametrize("world,n_total", [(2, 128), (2, 131), (4, 130)])     # equal and ragged shards; four ranks (33, 33, 32, 32)
+def test_two_rank_sharded_step_and_gather(tmp_path, world, n_total):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(HERE, "_dist_worker.py"), str(n_total), str(tmp_path)]
     env = dict(os.environ, OMP_NUM_THREADS="1")
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
@@ -54,5 +54,6 @@ def test_two_rank_sharded_step_and_gather(tmp_path, n_total):
     assert full.shape == (5, n_total)
     assert np.array_equal(full, obs)                                   # env-index order preserved
     assert np.array_equal(np.load(tmp_path / "obs_root.npy"), obs)
-    assert np.array_equal(np.load(tmp_path / "obs_rank1.npy"), obs)    # all-gather: every rank has it
+    for r in range(1, world):
+        assert np.array_equal(np.load(tmp_path / ("obs_rank%d.npy" % r)), obs)    # all-gather: every rank has it
     assert abs(np.load(tmp_path / "rew_sum.npy")[0] - rew.sum()) < 1e-12
