@@ -318,7 +318,10 @@ def test_committed_kernel_trace_is_consistent_with_its_dispatch_files():
     base = os.path.dirname(path)
     for key, rec in d["runs"].items():
         for box in rec.get("boxes", [rec]):
-            rows = list(csv.DictReader(open(os.path.join(base, box["csv"]))))
+            f = os.path.join(base, box["csv"])
+            if not os.path.exists(f):                      # (since round 6 the raw per-dispatch files sit in the round's traces/ sub-directory)
+                f = os.path.join(base, "traces", box["csv"])
+            rows = list(csv.DictReader(open(f)))
             dur = [(float(r["start_offset_us"]), int(r["duration_ns"])) for r in rows]
             n_ramp = min(sum(1 for s, _ in dur if s < 25.0 * 1e3), len(dur) // 2)
             steady = sorted(x for _, x in dur[n_ramp:])

@@ -5,8 +5,10 @@ TAG=${1:-r05}
 S=gpurun_out/$TAG; D=profiles/$TAG
 mkdir -p $D
 cp $S/kernel_trace.json $S/summary_latest.json $D/ 2>/dev/null
-cp $S/kt_*_dispatches.csv $S/kt_*_kernel_stats.csv $D/ 2>/dev/null
-cp $S/ab_*_plain.json $D/ 2>/dev/null
+# the raw per-dispatch files and the un-profiled twins of every traced command: one sub-directory, so that the round's top level stays readable
+mkdir -p $D/traces
+cp $S/kt_*_dispatches.csv $S/kt_*_kernel_stats.csv $D/traces/ 2>/dev/null
+cp $S/ab_*_plain.json $D/traces/ 2>/dev/null
 [ -f $S/latency.json ] && cp $S/latency.json $D/latency_box.json
 # the device-resident loop under rocprofv3 --kernel-trace --memory-copy-trace (tools/exp/rl_nocopy.py): kernels per name, copies
 if [ -d $S/memcopy_rl ]; then
@@ -48,7 +50,8 @@ for run in sorted(glob.glob(s + "/kt_stats_*")):
             rows[name].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r.get("Grid_Size_X") or r.get("Grid_Size")))
     if not rows["stats_join_kernel"]:
         continue
-    with open(os.path.join(d, "kt_stats_%s.csv" % n), "w") as g:
+    os.makedirs(os.path.join(d, "traces"), exist_ok=True)
+    with open(os.path.join(d, "traces", "kt_stats_%s.csv" % n), "w") as g:
         g.write("kernel,dispatch,start_offset_us,duration_ns,grid\n")
         t0 = min(v[0][0] for v in rows.values() if v)
         for name, v in rows.items():

@@ -47,8 +47,8 @@ if kt:
             ("full_k1800", "full_k1800", "... full scenario (the drop-in env's kernel)"), ("sh70", "sh", "65 536 envs, degree-70 harmonics, K = 1")]
     out += ["## Kernel durations: rocprofv3 per-dispatch traces in steady state, beside the same commands un-profiled", "",
             "`kernel_trace.json` (key -> statistics; `boxes`, `trimmed_mean_us_median_of_boxes` where a key was traced on several boxes),",
-            "`kt_<run>[_b2|_b3]_dispatches.csv` (every dispatch of the step kernel: index, start offset, duration - recompute anything from these),",
-            "`kt_<run>..._kernel_stats.csv` (rocprofv3's own `--stats` table of the same run), `ab_<run>[_b2|_b3]_plain.json` (the identical command",
+            "`traces/kt_<run>[_b2|_b3]_dispatches.csv` (every dispatch of the step kernel: index, start offset, duration - recompute anything from these),",
+            "`traces/kt_<run>..._kernel_stats.csv` (rocprofv3's own `--stats` table of the same run), `traces/ab_<run>[_b2|_b3]_plain.json` (the identical command",
             "un-profiled on the same box: its own dispatch stamps and wall time per launch).  Steady state = dispatches that start >= 25 ms after the",
             "kernel's first one; trimmed mean = mean of their middle 80 %.  All us:", "",
             "| key | dispatches | trimmed mean per box | **median over boxes (what `bench.py` uses)** | un-profiled, per box: stamped / wall per launch |", "|---|---|---|---|---|"]
@@ -59,7 +59,7 @@ if kt:
         boxes = q.get("boxes") or [q]
         plain = []
         for suf in ("", "_b2", "_b3"):
-            p = J("ab_%s%s_plain.json" % (ab, suf))
+            p = J("traces/ab_%s%s_plain.json" % (ab, suf))
             if p:
                 plain.append("%s / %s" % (us(p["roofline"].get("kernel_us_stamped")), us(p["roofline"].get("wall_us_per_launch"))))
         out.append("| `%s` (%s) | %d | %s | **%s** | %s |" % (key, desc, q["dispatches"], " / ".join(us(b["trimmed_mean_us"]) for b in boxes),
@@ -144,7 +144,7 @@ if co:
 # ---------------------------------------------------------------- batch scalars
 if st:
     bs = (rec or {}).get("extra", {}).get("batch_stats_us", {})
-    out += ["## Batch scalars (`kt_stats.json`, `kt_stats_<N>.csv`; `tools/exp/stats_trace.py N`: a K = 1 step + a request per iteration, 3 000 iterations)", "",
+    out += ["## Batch scalars (`kt_stats.json`, `traces/kt_stats_<N>.csv`; `tools/exp/stats_trace.py N`: a K = 1 step + a request per iteration, 3 000 iterations)", "",
             "| spacecraft | `stats_kernel` (level 1) | `stats_join_kernel` | both | added per step in the stepping loop | with `bsk_set_step_stats` (the headline's setting): join alone | added per step |", "|---|---|---|---|---|---|---|"]
     for n in ("65536", "131072", "1048576", "4194304"):
         v, f = st.get(n), st.get("fused_" + n)
