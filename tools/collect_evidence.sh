@@ -46,8 +46,12 @@ for run in sorted(glob.glob(s + "/kt_stats_*")):
     fs = sorted(glob.glob(run + "/*/*_kernel_trace.csv"), key=os.path.getmtime)
     for r in csv.DictReader(open(fs[-1])) if fs else []:
         name = r["Kernel_Name"].split("(")[0].split("::")[-1]
-        if name in rows:
+        if name.startswith("stats_join"):                  # stats_join_kernel (1 024 threads) or stats_join1_kernel<MAX_WAVES> (one wave, <= 4 096 waves of rewards)
+            rows.setdefault("_join_name", name)
+            name = "stats_join_kernel"
+        if name in rows and name != "_join_name":
             rows[name].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r.get("Grid_Size_X") or r.get("Grid_Size")))
+    join_name = rows.pop("_join_name", None)
     if not rows["stats_join_kernel"]:
         continue
     os.makedirs(os.path.join(d, "traces"), exist_ok=True)
@@ -66,6 +70,8 @@ for run in sorted(glob.glob(s + "/kt_stats_*")):
         cut = len(dur) // 10
         core = dur[cut:len(dur) - cut] or dur
         rec[name] = {"dispatches": len(v), "median_us": dur[len(dur) // 2] / 1e3, "trimmed_mean_us": sum(core) / len(core) / 1e3, "min_us": dur[0] / 1e3, "grid": v[0][2]}
+    if join_name and "stats_join_kernel" in rec:
+        rec["stats_join_kernel"]["kernel"] = join_name
     rec["both_trimmed_mean_us"] = sum(rec[k]["trimmed_mean_us"] for k in ("stats_kernel", "stats_join_kernel") if k in rec)
     out[n] = rec
 if out:

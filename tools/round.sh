@@ -39,14 +39,18 @@ phase_traces() {
     ( cd $R && $B $args > $O/ab_${name}${sfx}_plain.json 2>> $O/bench.err )     # the same command un-profiled, same box
   done
   if [ -n "$BOX" ]; then cd $R && python3 tools/kernel_trace_summary.py $O $O > $O/kernel_trace.json && echo kernel_trace ok; return 0; fi
-  # the batch scalars (row a7): stats_kernel / stats_join_kernel at four batch sizes, a request after every step
+  phase_stats
+  cd $R && python3 tools/kernel_trace_summary.py $O $O > $O/kernel_trace.json && echo kernel_trace ok
+}
+
+phase_stats() {   # (a phase of its own too: these depend on csrc/bsk_aux.hip only, which is not part of the step kernels' fingerprint)
+  # the batch scalars (row a7): stats_kernel / stats_join*_kernel at four batch sizes, a request after every step
   for ns in 65536 131072 1048576 4194304; do
     prof kt_stats_$ns --kernel-trace --stats --output-format csv -d $O/kt_stats_$ns -- python3 $R/tools/exp/stats_trace.py $ns
     prof kt_stats_fused_$ns --kernel-trace --stats --output-format csv -d $O/kt_stats_fused_$ns -- python3 $R/tools/exp/stats_trace.py $ns 3000 fused
   done
   # the device-resident loop under the copy tracer: reset_tensors + step_tensors must show NO memory copy (row f4)
   prof memcopy_rl --kernel-trace --memory-copy-trace --output-format csv -d $O/memcopy_rl -- python3 $R/tools/exp/rl_nocopy.py
-  cd $R && python3 tools/kernel_trace_summary.py $O $O > $O/kernel_trace.json && echo kernel_trace ok
 }
 
 phase_counters() {
@@ -116,8 +120,8 @@ phase_collect() {   # this container: what the round keeps, tracked
 rc=0
 for ph in "$@"; do
   case $ph in
-    tests|traces|counters|isa|lines|collect) phase_$ph || rc=1 ;;
-    *) echo "unknown phase $ph (tests traces counters isa lines collect)"; exit 2 ;;
+    tests|traces|stats|counters|isa|lines|collect) phase_$ph || rc=1 ;;
+    *) echo "unknown phase $ph (tests traces stats counters isa lines collect)"; exit 2 ;;
   esac
 done
 exit $rc
