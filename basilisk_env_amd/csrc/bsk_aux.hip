@@ -27,8 +27,8 @@ namespace bsk {
 //   stats_join_kernel (one workgroup, launched behind it on the same stream): thread t of 256 adds wave_sum[w], w = t (mod 256),
 //     in ascending order, a halving tree joins the 256 partials - the documented tree of
 //     tests/test_gpu_device_surface.py::_stats_order, bit for bit what the single-workgroup kernel of round 4 produced.
-//     Up to 4 096 waves of rewards (262 144 spacecraft) the same additions are made by ONE wave without LDS or barriers
-//     (stats_join1_kernel, round 6: 2.6 us added per step at 65 536 spacecraft instead of 3.7).
+//     Up to 1 024 waves of rewards (65 536 spacecraft) the same additions are made by ONE wave without LDS or barriers
+//     (stats_join1_kernel, round 6: 2.6 - 2.7 us added per step at 65 536 spacecraft instead of 3.5 - 3.7).
 // Measured and rejected (profiles/r05/rejected/stats_forms.txt): ONE launch whose last workgroup joins the partials - with
 // agent-scope fences 24 us at 65 536 envs and 236 us at 4 Mi (every fence walks the L2), with write-through publications and a
 // ticket 7.6 / 99 us; the kernel boundary is the cheap device-wide synchronisation here.
@@ -146,15 +146,16 @@ __global__ __launch_bounds__(JOIN_THREADS) void stats_join_kernel(StatsScratch s
     }
 }
 
-// The same join by ONE wave, for batches of up to JOIN1_MAX_WAVES waves (262 144 spacecraft; round 6): a 1 024-thread workgroup spends
+// The same join by ONE wave, for batches of up to JOIN1_MAX_WAVES waves (65 536 spacecraft; round 6 - measured at 2 048 waves too, with
+// 4 096-wave instantiation: +0.2 us against the workgroup form there, so the limit is where it pays): a 1 024-thread workgroup spends
 // most of its 3.7 us starting sixteen waves and walking a ten-level LDS tree with a barrier per level for work that is one memory round
 // trip.  Lane l stands for the four "threads" t = l, l + 64, l + 128, l + 192 of the documented order: each chain adds wave_sum[w],
 // w = t (mod 256), ascending (rows beyond the batch contribute +0.0, which leaves a sum that started from +0.0 unchanged bit for bit);
 // the halving tree's levels 128 and 64 pair values of the SAME lane, its levels 32 ... 1 are shuffles (sr[t] += sr[t + off], t < off) -
 // the same additions on the same operands as stats_join_kernel's, no LDS, no barrier; every load of the launch is in flight before
 // the first add.  The done count (integers, any order) rides along.
-constexpr int JOIN1_MAX_WAVES = 4096;
-template <int MAX_WAVES>      // 1 024 (65 536 spacecraft: 8 + 16 loads per lane) or 4 096
+constexpr int JOIN1_MAX_WAVES = 1024;
+template <int MAX_WAVES>      // 1 024: 65 536 spacecraft, 16 + 16 loads per lane
 __global__ __launch_bounds__(64) void stats_join1_kernel(StatsScratch sc, int n_waves, int n_parts, const unsigned long long* __restrict__ done_mask,
                                                          double* out_sum, long long* out_done, double* out2, const StatsSeal seal) {
     constexpr int JOIN1_ROWS = MAX_WAVES / 256;
@@ -345,17 +346,14 @@ hipError_t launch_stats(const double* reward, int n, const unsigned long long* d
                         hipStream_t s) {
     const bool one_wave = n_waves <= JOIN1_MAX_WAVES;
     if (have_wave_sums) {     // the step kernel wrote wave_sum[] itself: the second level alone
-        if (n_waves <= 1024) hipLaunchKernelGGL(stats_join1_kernel<1024>, dim3(1), dim3(64), 0, s, StatsScratch{wsum, done_part}, n_waves, 0, done_mask, out_sum, out_done, out2, seal);
-        else if (one_wave) hipLaunchKernelGGL(stats_join1_kernel<JOIN1_MAX_WAVES>, dim3(1), dim3(64), 0, s, StatsScratch{wsum, done_part}, n_waves, 0, done_mask, out_sum, out_done, out2, seal);
+        if (one_wave) hipLaunchKernelGGL(stats_join1_kernel<JOIN1_MAX_WAVES>, dim3(1), dim3(64), 0, s, StatsScratch{wsum, done_part}, n_waves, 0, done_mask, out_sum, out_done, out2, seal);
         else hipLaunchKernelGGL(stats_join_kernel, dim3(1), dim3(JOIN_THREADS), 0, s, StatsScratch{wsum, done_part}, n_waves, 0, done_mask, out_sum, out_done, out2, seal);
         return hipGetLastError();
     }
     // one 256-thread workgroup per four waves of rewards, at most STATS_MAX_GRID of them
     const int grid = std::max(1, std::min((n_waves + 3) / 4, STATS_MAX_GRID));
     hipLaunchKernelGGL(stats_kernel, dim3(grid), dim3(256), 0, s, reward, n, done_mask, n_waves, StatsScratch{wsum, done_part});
-    if (n_waves <= 1024) hipLaunchKernelGGL(stats_join1_kernel<1024>, dim3(1), dim3(64), 0, s, StatsScratch{wsum, done_part}, n_waves, grid, (const unsigned long long*)nullptr,
-                                            out_sum, out_done, out2, seal);
-    else if (one_wave) hipLaunchKernelGGL(stats_join1_kernel<JOIN1_MAX_WAVES>, dim3(1), dim3(64), 0, s, StatsScratch{wsum, done_part}, n_waves, grid, (const unsigned long long*)nullptr,
+    if (one_wave) hipLaunchKernelGGL(stats_join1_kernel<JOIN1_MAX_WAVES>, dim3(1), dim3(64), 0, s, StatsScratch{wsum, done_part}, n_waves, grid, (const unsigned long long*)nullptr,
                                           out_sum, out_done, out2, seal);
     else hipLaunchKernelGGL(stats_join_kernel, dim3(1), dim3(JOIN_THREADS), 0, s, StatsScratch{wsum, done_part}, n_waves, grid, (const unsigned long long*)nullptr,
                             out_sum, out_done, out2, seal);
