@@ -15,8 +15,16 @@ of the metric).  Envs are independent: ranks shard them with no collective on th
 the timed region (``gather``: RCCL gather to rank 0, RCCL all-gather, and each GPU's direct D2H).
 
 A "step" = one pass of the hot path over the whole batch (one kernel launch per GPU): mode
-switch, FSW chain when due, RK4, observation, reward, done mask, wave reductions.  Actions and
-state are resident in HBM when the timed region starts.
+switch, FSW chain when due, RK4, observation, reward, done mask, and the wave-level reductions (the done
+ballot and the per-wave reward sums: bsk_set_step_stats is on).  Actions and state are resident in HBM when
+the timed region starts.  ``value_with_join`` is the same loop with the two batch scalars joined on the
+device after every step (bsk_get_batch_stats_device).
+
+Output.  The LAST stdout line is the compact JSON record the driver reads (< 4 096 bytes: contract keys,
+``value_with_join``, ``roofline``, ``cpu_baseline``, at N > 1 the rank / device / communicator counts and the
+exchange timings).  The whole record of the run - every other measurement point - is an EARLIER line
+prefixed ``EXTRA `` and ``bench_extra.json`` beside this file.  (``--full-line``: tooling gets the whole record
+as the one line instead.)
 
 Timing.  ``value`` / ``ms_per_step`` come from the wall clock around EXACTLY ``--steps`` launches that
 carry no timestamps (nothing but the launches is enqueued between the two synchronisations), so they do
@@ -26,10 +34,10 @@ bounded from above by the timed loop's wall time per launch (launches of one str
 says which of the two is reported).  ``--scenario`` / ``--features`` / ``--fsw-timing`` / ``--lds-scratch`` select
 other kernels of the same path for measurement; the default line is the contract's.
 
-Besides the contract keys the JSON line carries ``roofline`` (dominant kernel: HBM-bound at K = 1 with
+Besides the contract keys the record carries ``roofline`` (dominant kernel: HBM-bound at K = 1 with
 340 algorithmic bytes per env-step; fp64-issue-bound for K >> 1, the harmonics and the
 scenario levels, with EXECUTED flops from the committed SQ_INSTS_VALU_*_F64 counter passes),
-``cpu_baseline`` (the CPU oracle on this box's host cores, rank 0 at N = 1 only) and ``extra``.
+``cpu_baseline`` (the CPU oracle on this box's host cores, rank 0 at N = 1 only) and ``extra`` (EXTRA line only).
 """
 import argparse
 import json
