@@ -284,8 +284,11 @@ int bsk_get_state_device(bsk_handle* h, double** d_state, int64_t* stride);
  * reproducible: per 64 envs an xor butterfly, the wave sums w = t mod 256 added in ascending order by thread t, a halving tree
  * over the 256 partials) from the reward buffer and the per-wave done ballots by two small launches of their own (a
  * multi-workgroup first level: one sum per 64 envs; a single workgroup joins them) - once, when first asked for, or just before
- * a reset entry point zeroes the restarted envs' rewards.  A step does NOT produce them unless bsk_set_step_stats says so: its
- * epilogue carries the done ballot (one 64-bit mask per wave) and no reward reduction.  (Synchronises.) */
+ * a reset entry point zeroes the restarted envs' rewards (up to 65 536 spacecraft the join is one wave making the same additions).
+ * A step does NOT produce them unless bsk_set_step_stats says so: its epilogue carries the done ballot (one 64-bit mask per wave) and
+ * no reward reduction.  After a reset entry point the scalars stay the last STEP's until the next step launch - also on a handle whose
+ * launches replay from a HIP graph: the reset seals the snapshot on the device (env 0's counter word and episode number, which every
+ * step launch changes) and a later request leaves a sealed snapshot alone.  (Synchronises.) */
 int bsk_get_batch_stats(bsk_handle* h, double* reward_sum, int64_t* n_done);
 /* The same two scalars left ON the device as f64[2] = {sum of rewards, number of done envs}, enqueued on the handle's stream
  * without synchronising: the operand of the one all-reduce a sharded batch needs. */
