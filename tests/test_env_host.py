@@ -523,3 +523,14 @@ def test_demo_batch_runs_whole_episodes_in_one_call_each(capsys):
     obs, ret, length = out[0]
     assert obs.shape[1:] == (5, 5) and ret.shape == (5,) and np.all(length >= 1) and np.all(ret > 0.0)       # (action 0 earns the nadir reward)
     assert capsys.readouterr().out.count("episode") == 2
+
+
+def test_demo_main_rolls_whole_episodes_of_one_action(capsys):
+    """What the reference module does when run as a script (envs/leoPowerAttitudeEnvironment.py:218-231: make the env, reset, seed,
+    step action 0 until the episode is over, keep the observation history) - `demo()`, here on the oracle-backed engine; with gym
+    absent `make_env` builds the class itself (tests/test_gym_boundary.py runs the gym.make branch)."""
+    from basilisk_env_amd.envs.leoPowerAttitudeEnvironment import demo
+    hists = demo(episodes=1, env_kwargs={"simulator_kwargs": dict(KW)})
+    assert len(hists) == 1 and hists[0].shape[0] == 5 and 1 <= hists[0].shape[1] <= 541
+    assert np.isfinite(hists[0]).all() and np.all(hists[0][4] >= 0.0) and np.all(hists[0][4] <= 1.0)      # obs[4]: sunlit fraction
+    assert capsys.readouterr().out.count("episode 0:") == 1

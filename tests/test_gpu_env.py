@@ -72,3 +72,14 @@ def test_device_views_zero_copy():
     r = torch.as_tensor(v["reward"], device="cuda")
     assert np.array_equal(r.cpu().numpy(), rew)
     env.close()
+
+
+def test_demo_main_runs_on_the_gpu_engine(capsys):
+    """The reference module's own main (envs/leoPowerAttitudeEnvironment.py:218-231) through this package: `demo()` = make the env the way
+    the reference does, reset, seed(12345), step action 0 until the episode ends - one whole episode on the HIP engine."""
+    from basilisk_env_amd.envs.leoPowerAttitudeEnvironment import demo
+    hists = demo(episodes=1)
+    h = hists[0]
+    assert h.shape[0] == 5 and 1 <= h.shape[1] <= 541 and np.isfinite(h).all()
+    assert np.all(h[4] >= 0.0) and np.all(h[4] <= 1.0) and np.all(h[3] >= 0.0)
+    assert capsys.readouterr().out.count("episode 0:") == 1
