@@ -145,7 +145,7 @@ if co:
 if st:
     bs = (rec or {}).get("extra", {}).get("batch_stats_us", {})
     out += ["## Batch scalars (`kt_stats.json`, `traces/kt_stats_<N>.csv`; `tools/exp/stats_trace.py N`: a K = 1 step + a request per iteration, 3 000 iterations)", "",
-            "| spacecraft | `stats_kernel` (level 1) | `stats_join_kernel` | both | added per step in the stepping loop | with `bsk_set_step_stats` (the headline's setting): join alone | added per step |", "|---|---|---|---|---|---|---|"]
+            "| spacecraft | `stats_kernel` (level 1) | join (`stats_join1_kernel`, one wave, up to 65 536; `stats_join_kernel` above) | both | added per step in the stepping loop | with `bsk_set_step_stats` (the headline's setting): join alone | added per step |", "|---|---|---|---|---|---|---|"]
     for n in ("65536", "131072", "1048576", "4194304"):
         v, f = st.get(n), st.get("fused_" + n)
         if not v or not f:
