@@ -417,7 +417,7 @@ def settle_roofline(roof, key, stamped_us, wall_us, work, peak, fp=None):
 
 def pmc_traffic(n_envs, substeps):
     """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC passes
-    (tools/prof.sh -> profiles/*/summary_latest.json; separate FETCH_SIZE / WRITE_SIZE runs of this
+    (tools/round.sh TAG counters -> profiles/*/summary_latest.json; separate FETCH_SIZE / WRITE_SIZE runs of this
     same command, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  None when no matching profile."""
     if substeps != 1:
         return None, None
@@ -433,7 +433,7 @@ def pmc_traffic(n_envs, substeps):
 
 def isa_mix(key):
     """fp64 instructions the step kernel EXECUTES per RK4 sub-step and wave, by class, from the committed
-    SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 counter passes (tools/isa_mix.sh -> profiles/*/isa_mix.json).
+    SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 counter passes (tools/round.sh TAG isa -> profiles/*/isa_mix.json).
     key: 'bare' | 'power' | 'full' | 'sh'.  -> (dict, source, fingerprint of the tree it was counted on)."""
     best = _latest_profile("isa_mix.json")
     if not best:
@@ -468,7 +468,7 @@ def fp64_roofline(key, rk4_steps_per_gpu, kernel_s, info):
                 "isa_mix_fresh": mix_fp == kernel_fingerprint()})
     if not out["isa_mix_fresh"]:
         out["isa_mix_note"] = ("instruction mix counted on other kernel sources (fingerprint %s): executed-flop figures are "
-                               "indicative until tools/isa_mix.sh has been re-run on this tree" % mix_fp)
+                               "indicative until tools/round.sh TAG isa has been re-run on this tree" % mix_fp)
     return out
 
 
@@ -868,7 +868,7 @@ def rl_loop(torch, n, substeps, steps, warmup=10):
             "steps": steps, "torch_kernels_per_step": 2, "policy_only_ms_per_step": el_policy / steps * 1e3,
             "env_share_over_kernel": ((el - el_policy) / steps * 1e3) / km,
             "note": "loop time minus the policy's own two kernels, over the step kernel's time: what the env adds per step beyond its "
-                    "kernel (1.0 = nothing); the loop captured in a HIP graph runs at the eager loop's rate (tools/exp/rl_graph.py, "
+                    "kernel (1.0 = nothing); the loop captured in a HIP graph runs at the eager loop's rate (tools/attic/exp/rl_graph.py, "
                     "tests/test_gpu_device_surface.py): it is bound by the three dependent kernels, not by launches",
             "policy": "obs(N,5) @ W(5,3) -> argmax (int64, consumed in place), torch on the env's (non-default) stream; episode returns / lengths / done byte kept by the step kernel",
             "env": "LeoPowerAttVecEnv.step_tensors, full reference scenario, J2 + 4 wheels, device IC pool 4096 (Philox), device-side auto-reset"}

@@ -261,7 +261,7 @@ def test_headline_line_is_small():
 
 
 def test_committed_headline_of_this_round_is_small_and_complete():
-    """The line committed under profiles/ for the driver's own command (tools/bench_lines.sh) obeys the limit."""
+    """The line committed under profiles/ for the driver's own command (tools/round.sh TAG lines) obeys the limit."""
     path = os.path.join(ROOT, "profiles", "r06", "bench_steps20_warmup5.json")
     if not os.path.exists(path):
         pytest.skip("no committed round-6 bench line yet")

@@ -296,7 +296,7 @@ def test_c_program_runs_the_env_step_the_reference_binding_would(tmp_path):
         info = prop.kernel_info()
         steps, ticks = prop.get_counters()
         tail = lines[3].split()
-        # (one spacecraft, 1 800 sub-steps: the three-wave form - unless a form is forced for the whole suite, tools/forced_forms.sh)
+        # (one spacecraft, 1 800 sub-steps: the three-wave form - unless a form is forced for the whole suite, tools/attic/forced_forms.sh)
         form, block = ("pair", 128) if os.environ.get("BSKGPU_TRI") == "0" and os.environ.get("BSKGPU_PAIR") == "1" else ("tri", 192)
         assert tail[0] == info["name"] and form in tail[0]
         assert int(tail[1]) == info["block"] == block and int(tail[2]) == info["grid"]
