@@ -229,3 +229,34 @@ class LEOPowerAttitudeSimulator(object):
 
 def create_leoPowerAttSimulator():
     return LEOPowerAttitudeSimulator(0.1, 0.1, 60.)
+
+
+def demo(steps=2 * 180, action=0, step_duration=60., plot=False, **simulator_kwargs):
+    """What the reference module does when run as a script (:657-694): one simulator with 60 s steps, ``steps`` calls of
+    ``run_sim(action)`` (the reference draws none at random either: ``act = 0``), the observation history kept and - with
+    ``plot=True`` and matplotlib at hand - drawn with the reference's labels.  -> observations (steps, 5)."""
+    sim = LEOPowerAttitudeSimulator(0.1, 1.0, step_duration, **simulator_kwargs)
+    obs = []
+    for _ in range(steps):
+        ob, _, over = sim.run_sim(action)
+        obs.append(ob[:, 0].copy())
+        if over:
+            break
+    sim.close_gracefully()
+    if hasattr(sim, "release"):
+        sim.release()
+    obs = np.asarray(obs)
+    print("simulator demo: %d steps of %.0f s under action %d, last observation %s" % (len(obs), step_duration, action, np.array2string(obs[-1], precision=5)))
+    if plot:
+        from matplotlib import pyplot as plt
+        plt.figure()
+        for k, name in enumerate(("sigma_BR", "omega_BN", "omega_rw", "J_bat", "eclipse_ind")):
+            plt.plot(range(len(obs)), obs[:, k], label=name)
+        plt.legend()
+        plt.show()
+    return obs
+
+
+if __name__ == "__main__":
+    import sys
+    demo(plot="--plot" in sys.argv)

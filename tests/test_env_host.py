@@ -534,3 +534,13 @@ def test_demo_main_rolls_whole_episodes_of_one_action(capsys):
     assert len(hists) == 1 and hists[0].shape[0] == 5 and 1 <= hists[0].shape[1] <= 541
     assert np.isfinite(hists[0]).all() and np.all(hists[0][4] >= 0.0) and np.all(hists[0][4] <= 1.0)      # obs[4]: sunlit fraction
     assert capsys.readouterr().out.count("episode 0:") == 1
+
+
+def test_simulator_module_main_runs_360_steps_of_action_0(capsys):
+    """The reference simulator module's own main (simulators/leoPowerAttitudeSimulator.py:657-694): 60 s steps, 360 calls of run_sim(0),
+    the five observation entries kept - `simulators.leoPowerAttitudeSimulator.demo()`, here shortened and on the oracle-backed engine."""
+    from basilisk_env_amd.simulators.leoPowerAttitudeSimulator import create_leoPowerAttSimulator, demo
+    obs = demo(steps=12, **KW)
+    assert obs.shape == (12, 5) and np.isfinite(obs).all() and np.all(obs[:, 4] >= 0.0) and np.all(obs[:, 4] <= 1.0)
+    assert "12 steps of 60 s under action 0" in capsys.readouterr().out
+    assert callable(create_leoPowerAttSimulator)

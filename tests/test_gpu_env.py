@@ -83,3 +83,11 @@ def test_demo_main_runs_on_the_gpu_engine(capsys):
     assert h.shape[0] == 5 and 1 <= h.shape[1] <= 541 and np.isfinite(h).all()
     assert np.all(h[4] >= 0.0) and np.all(h[4] <= 1.0) and np.all(h[3] >= 0.0)
     assert capsys.readouterr().out.count("episode 0:") == 1
+
+
+def test_simulator_module_main_runs_on_the_gpu_engine(capsys):
+    """simulators/leoPowerAttitudeSimulator.py:657-694 through this package: 360 steps of 60 s under action 0 on the HIP engine."""
+    from basilisk_env_amd.simulators.leoPowerAttitudeSimulator import demo
+    obs = demo()
+    assert obs.shape == (360, 5) and np.isfinite(obs).all() and np.all(obs[:, 3] >= 0.0)
+    assert "360 steps of 60 s under action 0" in capsys.readouterr().out
