@@ -341,3 +341,23 @@ def test_random_rollouts_equal_single_steps(seed):
     for key in a:
         assert np.array_equal(a[key], b[key]), (tag, key)
     single.close(); rolled.close()
+
+
+@pytest.mark.parametrize("n", [64, 257, 300])
+def test_out_of_range_actions_and_tail_lanes(n):
+    """(i) a per-step device action outside {0, 1, 2} - 3, 7, 16, 255, -1 - must mean to the rollout what the raw integer means
+    to step_kernel (no mode test matches: no reward, the inertial target), where round 5's four-bit packing made 16 an action 0;
+    (ii) with n not a multiple of the workgroup (tail lanes shadowing env n - 1 in registers) every global store of the rollout,
+    restarts included, is the valid lanes' own.  T launches against one rollout, every buffer bit for bit, restarts inside the launch."""
+    cfg = default_config(4, GRAV_PM_J2)
+    cfg.max_length = 3
+    cfg.flags |= FLAG_AUTO_RESET | FLAG_EPISODE_STATS
+    single, rolled = _pair(cfg, n, seed=70 + n, pool=16)
+    rng = np.random.default_rng(n)
+    T = 11
+    actions = rng.choice(np.array([0, 1, 2, 3, 7, 15, 16, 255, -1, 0, 0], dtype=np.int32), size=(T, n)).astype(np.int32)
+    _, h_rew, _ = _compare(single, rolled, T, 1, actions, pool=16, tag=("oor", n))
+    odd = ~np.isin(actions, (0, 1, 2))
+    assert odd.any() and np.all(h_rew[odd] <= 0.0) and np.any(h_rew[actions == 0] > 0.0)      # 16 earns nothing; 0 does
+    single.close()
+    rolled.close()

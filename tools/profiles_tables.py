@@ -180,6 +180,7 @@ notes = [("stride_pad.txt", "where the state slab's 256-B row padding pays: one 
          ("rejected/tri_roles.txt", "the ONE-spacecraft env step, role by role (probe `BSK_PROBE_TRI_ROLE`): both dynamics halves issue back to back and are level to 0.2 %; nothing to move - rejected; the crossover N is stated"),
          ("rejected/rollout_k1_overlap.txt", "rollout kernel, K = 1: the epilogue of env step s overlapped with the tick of step s + 1 (+ `.diff`): bit-identical, -1 % at 65 536 (1.55 - 1.58 against 1.58 - 1.59 us; the bar was 1.35), -4.5 % at 4 Mi - rejected"),
          ("rejected/tri_pmc_n64.txt", "SQ counters of the three forms at 64 spacecraft (instructions per tick and workgroup)"),
+         ("fuzz.txt", "the three randomized GPU tests widened to 10 000 seeds each on the final sources: 40 001 passed"),
          ("forced_forms.txt", "the whole GPU suite with the pair / three-wave form forced for every launch: 442 passed each"),
          ("dpp_hazard.txt", "`tools/dpp_hazard.py` over EVERY translation unit's code object of the shipped library (until this round it read the first offload bundle only)")]
 have = [(f, w) for f, w in notes if os.path.exists(D + f)]
