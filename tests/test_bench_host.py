@@ -405,3 +405,16 @@ def test_a_hung_collective_leg_ends_in_status_3_with_exactly_one_json_line():
     out = {}
     b.guarded_leg(out, 0, 5.0, lambda: 1 // 0)
     assert "ZeroDivisionError" in out["gather"]["direct_rccl_error"]
+
+
+def test_round_entry_point_parses_and_refuses_unknown_phases():
+    """tools/round.sh is the single entry of a round's evidence pass: it must at least parse, know its phases, and not
+    start anything for a phase it does not know (a typo must not cost a GPU call)."""
+    sh = os.path.join(ROOT, "tools", "round.sh")
+    assert subprocess.run(["bash", "-n", sh]).returncode == 0
+    assert subprocess.run(["bash", "-n", os.path.join(ROOT, "tools", "collect_evidence.sh")]).returncode == 0
+    res = subprocess.run(["bash", sh, "rXX_test", "nonsense"], capture_output=True, text=True, env=dict(os.environ, GRAFT_REPO_ROOT="/tmp/bsk_round_test"))
+    assert res.returncode == 2 and "unknown phase" in res.stdout and "tests traces stats counters isa lines collect" in res.stdout
+    text = open(sh).read()
+    for ph in ("tests", "traces", "stats", "counters", "isa", "lines", "collect"):
+        assert "phase_%s()" % ph in text
